@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the DPVO per-frame path on MI355X (BASELINE.json metric, config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one `slam(t, image, intrinsics)` call on a synthetic 480x640 stream at the steady state of
+config/default.yaml (96 patches/frame, E = 45 312 active edges): patchify (torch/MIOpen encoders + HIP patch
+gathers) -> edge bookkeeping -> reproject -> two-level correlation -> update operator -> 2 BA iterations ->
+keyframe test + edge removal.  Random-init weights (no dpvo.pth on disk), synthetic images; the two data-dependent
+gates that cannot behave sensibly with random weights are pinned so that the graph reaches and keeps the default
+steady state: the initialisation motion probe is accepted (dpvo.py:441-444) and no keyframe is dropped
+(KEYFRAME_THRESH = -1; the flow test itself, with its host read-backs, still runs every frame).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): replicas only -- every rank tracks its own sequence,
+RCCL is used for the start/stop barriers and the max-reduction of the elapsed time.  `value` is the
+whole-job frames/sec = N*K / max-over-ranks seconds; scaling is "weak".
+
+The JSON line also carries
+  roofline     -- the dominant kernel of the north-star path, corr_pyramid_kernel: ALGORITHMIC bytes per launch
+                  (E x 52 884 B) / its mean duration measured with HIP events on the launch stream
+                  inside the timed region, against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the CPU oracle ("port": oracle/liboracle.so + oracle/update_ref.py) timed on rank 0 at N = 1 on
+                  ONE full hot-path step (reproject, corr, update, 2 BA iterations at E = 45 312).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_EDGE = 52884          # algorithmic bytes per edge, both pyramid levels, f16 features
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_stream(n_frames, ht, wd, device, seed=1234):
+    """Pre-staged synthetic frames: a fixed low-pass random texture, translated a few pixels per frame."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tex = torch.rand(3, ht + 256, wd + 256, generator=g)
+    tex = torch.nn.functional.avg_pool2d(tex[None], 5, 1, 2)[0]
+    tex = (255 * (tex - tex.min()) / (tex.max() - tex.min())).to(torch.uint8)
+    frames = []
+    for t in range(n_frames):
+        dx, dy = (3 * t) % 256, (2 * t) % 256
+        frames.append(tex[:, dy:dy + ht, dx:dx + wd])
+    return torch.stack(frames).to(device)
+
+
+def cpu_baseline():
+    """One hot-path step on the host cores with the oracle (the checker, used here as the CPU 'port')."""
+    import numpy as np
+    import oracle
+    from oracle import update_ref
+    from dpvo_amd import synthetic as S
+    from dpvo_amd.net import Update
+    oracle.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ii, jj, kk = S.replay_graph(40)
+    E = ii.numel()
+    gmap, f0, f1, imap = S.make_features()
+    poses, patches, intr = S.make_scene(40)
+    torch.manual_seed(1234)
+    sd = Update(3).state_dict()
+    g32, a, b = gmap.float().numpy(), f0.float().numpy(), f1.float().numpy()
+    gen = torch.Generator().manual_seed(0)
+    net = torch.randn(E, 384, generator=gen)
+    t0 = time.perf_counter()
+    coords = oracle.reproject(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy(), dtype=np.float32)
+    corr = oracle.corr_pyramid(g32, [a, b], coords, (kk % 3456).numpy(), (jj % 36).numpy(), dtype=np.float32)
+    inp = imap[kk % 3456]
+    _, delta, weight = update_ref.update_forward(sd, net, inp, torch.from_numpy(corr), ii, jj, kk)
+    target = coords[:, :, 1, 1] + delta.numpy().astype(np.float32)
+    oracle.ba(poses.numpy(), patches.numpy(), intr.numpy(), target, weight.numpy(), 1e-4, ii.numpy(), jj.numpy(), kk.numpy(),
+              30, 40, iterations=2, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frames/sec", "cores": cores, "kind": "port",
+            "sample": f"1 hot-path step (reproject+corr+update+2 BA iters) at E={E} on the CPU oracle "
+                      f"(C/OpenMP f32 for corr/reproject/BA, torch-CPU for the update operator); encoders excluded; "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=45)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="default", choices=["default", "fast"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    from dpvo_amd import altcorr
+    from dpvo_amd.altcorr import correlation as corr_mod
+    from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML, FAST_YAML
+    from dpvo_amd.dpvo import DPVO
+    from dpvo_amd.net import VONet
+
+    cfg = base_cfg.clone()
+    cfg.merge_from_dict(DEFAULT_YAML if args.config == "default" else FAST_YAML)
+    cfg.KEYFRAME_THRESH = -1.0                       # keep every keyframe (see module docstring)
+    ht, wd = 480, 640
+    torch.manual_seed(1234 + rank)
+    net = VONet()
+    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device)
+    slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
+    total = args.warmup + args.steps
+    assert total + 2 < cfg.BUFFER_SIZE
+    n_img = 64
+    frames = make_stream(n_img, ht, wd, device, seed=1234 + rank)
+    intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=device)   # calib/tartan.txt
+
+    def step(t):
+        slam(float(t), frames[t % n_img], intr)
+
+    with torch.no_grad():
+        for t in range(args.warmup):
+            step(t)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        corr_mod.PROFILE = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(args.warmup, total):
+            step(t)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    prof = corr_mod.PROFILE
+    corr_mod.PROFILE = None
+    E_now = int(slam.pg.ii.numel())
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    corr_ms = [s.elapsed_time(e) for s, e, _ in prof]
+    corr_edges = [n for _, _, n in prof]
+    roof = None
+    if corr_ms:
+        avg_ms = sum(corr_ms) / len(corr_ms)
+        avg_E = sum(corr_edges) / len(corr_edges)
+        achieved = avg_E * B_EDGE / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "corr_pyramid_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "edges_per_launch": round(avg_E, 1), "bytes_per_edge": B_EDGE,
+                "launches": len(corr_ms)}
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec (480x640, 96 patches/frame)", "value": round(world * args.steps / elapsed, 3),
+            "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 features / f32 accumulate, f32 BA", "data": "synthetic",
+            "config": {"workload": f"synthetic 480x640 stream, {cfg.PATCHES_PER_FRAME} patches/frame, {args.config}.yaml, "
+                                   f"steady state E={E_now} edges, random-init weights, one sequence per GPU",
+                       "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "parallelism": f"replicas x{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

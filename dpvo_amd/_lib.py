@@ -1,0 +1,113 @@
+"""ctypes binding of ``libdpvo_hip.so`` (the C ABI declared in ``include/dpvo_hip.h``).
+
+The library is the product: there is NO fallback.  If the shared object is missing or a symbol is
+absent, importing/using any op raises immediately (``DPVOHipError``), on CPU-only hosts as well as
+on the GPU box.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C dpvo_amd/csrc``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpvo_hip.so")
+
+F16, F32 = 0, 1
+
+# every symbol include/dpvo_hip.h declares (tests/test_capi.py checks the .so exports all of them)
+SYMBOLS = [
+    "dpvo_abi_version",
+    "dpvo_corr_forward", "dpvo_corr_pyramid_forward", "dpvo_patchify_forward",
+    "dpvo_reproject", "dpvo_flow_mag", "dpvo_point_cloud",
+    "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
+    "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build",
+    "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
+    "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads",
+    "dpvo_ba_workspace_bytes", "dpvo_ba",
+]
+
+
+class DPVOHipError(RuntimeError):
+    pass
+
+
+class PlanLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("perm_k", "ku", "kx", "patch_off", "ix", "jx", "perm_p", "pu", "pair_off", "pair_ij", "counts",
+                 "total_ints")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DPVOHipError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU/torch fallback exists). "
+                "Build it with `make -C dpvo_amd/csrc` (hipcc --offload-arch=gfx950).")
+        L = ctypes.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            if not hasattr(L, s):
+                raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
+        for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes"):
+            getattr(L, s).restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration", -3: "workspace too small"}.get(
+            rc, f"hipError_t {rc}")
+        raise DPVOHipError(f"{what} failed: {kind}")
+
+
+def ptr(t):
+    """device pointer of a tensor (or NULL)"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def i32(v):
+    return ctypes.c_int(int(v))
+
+
+def f32(v):
+    return ctypes.c_float(float(v))
+
+
+def strides(t, dims):
+    arr = (ctypes.c_int64 * len(dims))(*[t.stride(d) for d in dims])
+    return arr
+
+
+def dtype_code(dt):
+    if dt == torch.float16:
+        return F16
+    if dt == torch.float32:
+        return F32
+    raise DPVOHipError(f"unsupported feature dtype {dt} (float16 / float32 only)")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DPVOHipError("dpvo_amd ops run on the GPU only (tensor on %s); there is no CPU path" % t.device)
+
+
+def plan_layout(E):
+    L = PlanLayout()
+    check(lib().dpvo_plan_layout(i64(E), ctypes.byref(L)), "dpvo_plan_layout")
+    return L

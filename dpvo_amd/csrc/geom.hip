@@ -1,0 +1,312 @@
+// geom.hip -- SE3 forward ops, fused reprojection, flow magnitude and point cloud for gfx950.
+//
+// Replaces the lietorch_backends SE3 forward kernels (reference dpvo/lietorch/src/lietorch_gpu.cu:21-30,
+// 47-56,73-82,101-110,225-236 with the math of include/se3.h:34-56,124-142 and include/so3.h:31-60,
+// 115-208) and the ~12-launch elementwise chain of pops.transform (dpvo/projective_ops.py:19-68) that
+// DPVO.reproject runs every update (dpvo/dpvo.py:209-213).  All f32, one thread per element / edge
+// pixel; these kernels are latency-trivial (E*9 threads, <200 B per edge) -- the point is removing
+// launches and the materialised 9E x 7 broadcast of lietorch/broadcasting.py:26-29.
+#include "common.h"
+
+namespace {
+
+struct Quat { float x, y, z, w; };
+struct Vec3 { float x, y, z; };
+struct Pose { Vec3 t; Quat q; };
+
+// so3.h:31-37: every SO3 construction normalises the quaternion
+__device__ __forceinline__ Quat qnormalize(Quat q) {
+  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  return {q.x / n, q.y / n, q.z / n, q.w / n};
+}
+__device__ __forceinline__ Quat qmul(Quat a, Quat b) {
+  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+          a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+// so3.h:55-60
+__device__ __forceinline__ Vec3 qrot(Quat q, Vec3 p) {
+  float ux = q.y * p.z - q.z * p.y, uy = q.z * p.x - q.x * p.z, uz = q.x * p.y - q.y * p.x;
+  ux += ux; uy += uy; uz += uz;
+  return {p.x + q.w * ux + (q.y * uz - q.z * uy), p.y + q.w * uy + (q.z * ux - q.x * uz),
+          p.z + q.w * uz + (q.x * uy - q.y * ux)};
+}
+__device__ __forceinline__ Pose load_pose(const float* p) {   // se3.h:34
+  Pose X;
+  X.t = {p[0], p[1], p[2]};
+  X.q = qnormalize({p[3], p[4], p[5], p[6]});
+  return X;
+}
+__device__ __forceinline__ void store_pose(float* p, Pose X) {
+  p[0] = X.t.x; p[1] = X.t.y; p[2] = X.t.z; p[3] = X.q.x; p[4] = X.q.y; p[5] = X.q.z; p[6] = X.q.w;
+}
+__device__ __forceinline__ Pose se3_inv(Pose X) {              // se3.h:36-38
+  Pose Y;
+  Y.q = qnormalize({-X.q.x, -X.q.y, -X.q.z, X.q.w});
+  Vec3 r = qrot(Y.q, X.t);
+  Y.t = {-r.x, -r.y, -r.z};
+  return Y;
+}
+__device__ __forceinline__ Pose se3_mul(Pose A, Pose B) {      // se3.h:45-47
+  Pose C;
+  C.q = qnormalize(qmul(A.q, B.q));
+  Vec3 r = qrot(A.q, B.t);
+  C.t = {A.t.x + r.x, A.t.y + r.y, A.t.z + r.z};
+  return C;
+}
+__device__ __forceinline__ void se3_act4(Pose X, const float* p, float* o) {   // se3.h:53-56
+  Vec3 r = qrot(X.q, {p[0], p[1], p[2]});
+  o[0] = r.x + X.t.x * p[3]; o[1] = r.y + X.t.y * p[3]; o[2] = r.z + X.t.z * p[3]; o[3] = p[3];
+}
+
+__device__ __forceinline__ void hat3(const float* p, float* M) {
+  M[0] = 0; M[1] = -p[2]; M[2] = p[1]; M[3] = p[2]; M[4] = 0; M[5] = -p[0]; M[6] = -p[1]; M[7] = p[0]; M[8] = 0;
+}
+__device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float s = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j];
+      C[3 * i + j] = s;
+    }
+}
+
+constexpr float kEps = 1e-6f;     // common.h:7 of lietorch
+
+__global__ void se3_inv_kernel(const float* X, float* Y, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    store_pose(Y + 7 * i, se3_inv(load_pose(X + 7 * i)));
+}
+__global__ void se3_mul_kernel(const float* X, const float* Y, float* Z, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    store_pose(Z + 7 * i, se3_mul(load_pose(X + 7 * i), load_pose(Y + 7 * i)));
+}
+__global__ void se3_act4_kernel(const float* X, const float* p, float* q, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi[4] = {p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]}, o[4];
+    se3_act4(load_pose(X + 7 * i), pi, o);
+    q[4 * i] = o[0]; q[4 * i + 1] = o[1]; q[4 * i + 2] = o[2]; q[4 * i + 3] = o[3];
+  }
+}
+// se3.h:133-142 + so3.h:152-190
+__global__ void se3_exp_kernel(const float* A, float* X, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* a = A + 6 * i;
+    const float tau[3] = {a[0], a[1], a[2]}, phi[3] = {a[3], a[4], a[5]};
+    const float theta2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    const float theta = sqrtf(theta2);
+    float imag, real;
+    if (theta < kEps) {
+      const float theta4 = theta2 * theta2;
+      imag = 0.5f - (1.0f / 48.0f) * theta2 + (1.0f / 3840.0f) * theta4;
+      real = 1.0f - (1.0f / 8.0f) * theta2 + (1.0f / 384.0f) * theta4;
+    } else {
+      imag = sinf(.5f * theta) / theta;
+      real = cosf(.5f * theta);
+    }
+    Pose P;
+    P.q = qnormalize({imag * phi[0], imag * phi[1], imag * phi[2], real});
+    float Phi[9], Phi2[9];
+    hat3(phi, Phi); mat3mul(Phi, Phi, Phi2);
+    const float c1 = (theta < kEps) ? 0.5f - (1.0f / 24.0f) * theta2 : (1.0f - cosf(theta)) / theta2;
+    const float c2 = (theta < kEps) ? (1.0f / 6.0f) - (1.0f / 120.0f) * theta2 : (theta - sinf(theta)) / (theta2 * theta);
+    float t[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      float s = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s += (((r == c) ? 1.0f : 0.0f) + c1 * Phi[3 * r + c] + c2 * Phi2[3 * r + c]) * tau[c];
+      t[r] = s;
+    }
+    P.t = {t[0], t[1], t[2]};
+    store_pose(X + 7 * i, P);
+  }
+}
+// se3.h:124-131 + so3.h:115-150,192-208
+__global__ void se3_log_kernel(const float* X, float* A, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const Pose P = load_pose(X + 7 * i);
+    const float sn = P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z;
+    const float w = P.q.w;
+    float f;
+    if (sn < kEps * kEps) {
+      const float sw = w * w;
+      f = 2.0f / w - (2.0f / 3.0f) * sn / (w * sw);
+    } else {
+      const float nn = sqrtf(sn);
+      if (fabsf(w) < kEps) f = (w > 0) ? 3.14159265358979323846f / nn : -3.14159265358979323846f / nn;
+      else f = 2.0f * atanf(nn / w) / nn;
+    }
+    const float phi[3] = {f * P.q.x, f * P.q.y, f * P.q.z};
+    float Phi[9], Phi2[9];
+    hat3(phi, Phi); mat3mul(Phi, Phi, Phi2);
+    const float theta2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    const float theta = sqrtf(theta2), ht = 0.5f * theta;
+    const float c2 = (theta < kEps) ? (1.0f / 12.0f) : (1.0f - theta * cosf(ht) / (2.0f * sinf(ht))) / (theta * theta);
+    const float t[3] = {P.t.x, P.t.y, P.t.z};
+    float* a = A + 6 * i;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      float s = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s += (((r == c) ? 1.0f : 0.0f) - 0.5f * Phi[3 * r + c] + c2 * Phi2[3 * r + c]) * t[c];
+      a[r] = s;
+    }
+    a[3] = phi[0]; a[4] = phi[1]; a[5] = phi[2];
+  }
+}
+
+// One thread per (edge, patch pixel).  clamp_z = 1: pops.transform semantics (projective_ops.py:43);
+// clamp_z = 0: the exported cuda_ba.reproject (ba_cuda.cu:379-429): raw Z, intrinsics[0], no quaternion
+// normalisation (relSE3 :74-85).
+__global__ void reproject_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                 const float* __restrict__ intr, const int64_t* __restrict__ ii,
+                                 const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+                                 float* __restrict__ coords, int64_t E, int P, int clamp_z) {
+  const int PP = P * P;
+  const int64_t total = E * PP;
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < total; n += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = n / PP;
+    const int a = (int)(n - e * PP);
+    const int64_t i = ii[e], j = jj[e], k = kk[e];
+    const float* pk = patches + k * 3 * PP;
+    float x1, y1;
+    if (clamp_z) {
+      const Pose Gij = se3_mul(load_pose(poses + 7 * j), se3_inv(load_pose(poses + 7 * i)));
+      const float* Ki = intr + 4 * i; const float* Kj = intr + 4 * j;
+      const float X0[4] = {(pk[a] - Ki[2]) / Ki[0], (pk[PP + a] - Ki[3]) / Ki[1], 1.0f, pk[2 * PP + a]};
+      float X1[4];
+      se3_act4(Gij, X0, X1);
+      const float d = 1.0f / fmaxf(X1[2], 0.1f);
+      x1 = Kj[0] * (d * X1[0]) + Kj[2];
+      y1 = Kj[1] * (d * X1[1]) + Kj[3];
+    } else {
+      const float* pi = poses + 7 * i; const float* pj = poses + 7 * j;
+      const Quat qi = {pi[3], pi[4], pi[5], pi[6]}, qj = {pj[3], pj[4], pj[5], pj[6]};
+      Quat qij;
+      qij.x = -qj.w * qi.x + qj.x * qi.w - qj.y * qi.z + qj.z * qi.y;
+      qij.y = -qj.w * qi.y + qj.y * qi.w - qj.z * qi.x + qj.x * qi.z;
+      qij.z = -qj.w * qi.z + qj.z * qi.w - qj.x * qi.y + qj.y * qi.x;
+      qij.w = qj.w * qi.w + qj.x * qi.x + qj.y * qi.y + qj.z * qi.z;
+      const Vec3 r = qrot(qij, {pi[0], pi[1], pi[2]});
+      const float tij[3] = {pj[0] - r.x, pj[1] - r.y, pj[2] - r.z};
+      const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+      const float X0[4] = {(pk[a] - cx) / fx, (pk[PP + a] - cy) / fy, 1.0f, pk[2 * PP + a]};
+      const Vec3 R = qrot(qij, {X0[0], X0[1], X0[2]});
+      const float X = R.x + X0[3] * tij[0], Y = R.y + X0[3] * tij[1], Z = R.z + X0[3] * tij[2];
+      x1 = fx * (X / Z) + cx;
+      y1 = fy * (Y / Z) + cy;
+    }
+    coords[(e * 2 + 0) * PP + a] = x1;
+    coords[(e * 2 + 1) * PP + a] = y1;
+  }
+}
+
+// pops.flow_mag (projective_ops.py:120-130): per edge, mean over the PxP pixels of
+// beta*|x(Gij) - x(Gii)| + (1-beta)*|x(t-only) - x(Gii)|, and the number of valid pixels (Z > 0.2).
+__global__ void flow_mag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                const float* __restrict__ intr, const int64_t* __restrict__ ii,
+                                const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, float beta,
+                                float* __restrict__ flow, float* __restrict__ valid, int64_t E, int P) {
+  const int PP = P * P;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = ii[e], j = jj[e], k = kk[e];
+    const Pose Gi = load_pose(poses + 7 * i), Gj = load_pose(poses + 7 * j);
+    const Pose Gi_inv = se3_inv(Gi);
+    const Pose Gij = se3_mul(Gj, Gi_inv);
+    const Pose Gii = se3_mul(Gi, Gi_inv);
+    Pose Gt; Gt.t = Gij.t; Gt.q = {0.f, 0.f, 0.f, 1.f};          // tonly (:62-63)
+    const float* Ki = intr + 4 * i; const float* Kj = intr + 4 * j;
+    const float* pk = patches + k * 3 * PP;
+    float fsum = 0.f, vsum = 0.f;
+    for (int a = 0; a < PP; ++a) {
+      const float X0[4] = {(pk[a] - Ki[2]) / Ki[0], (pk[PP + a] - Ki[3]) / Ki[1], 1.0f, pk[2 * PP + a]};
+      float A0[4], A1[4], A2[4];
+      se3_act4(Gii, X0, A0); se3_act4(Gij, X0, A1); se3_act4(Gt, X0, A2);
+      const float d0 = 1.0f / fmaxf(A0[2], 0.1f), d1 = 1.0f / fmaxf(A1[2], 0.1f), d2 = 1.0f / fmaxf(A2[2], 0.1f);
+      const float c0x = Ki[0] * (d0 * A0[0]) + Ki[2], c0y = Ki[1] * (d0 * A0[1]) + Ki[3];
+      const float c1x = Kj[0] * (d1 * A1[0]) + Kj[2], c1y = Kj[1] * (d1 * A1[1]) + Kj[3];
+      const float c2x = Kj[0] * (d2 * A2[0]) + Kj[2], c2y = Kj[1] * (d2 * A2[1]) + Kj[3];
+      const float f1 = sqrtf((c1x - c0x) * (c1x - c0x) + (c1y - c0y) * (c1y - c0y));
+      const float f2 = sqrtf((c2x - c0x) * (c2x - c0x) + (c2y - c0y) * (c2y - c0y));
+      fsum += beta * f1 + (1.0f - beta) * f2;
+      vsum += (A1[2] > 0.2f) ? 1.0f : 0.0f;
+    }
+    flow[e] = fsum / (float)PP;
+    valid[e] = vsum;
+  }
+}
+
+// pops.point_cloud centre pixel, dpvo.py:358-360.
+__global__ void point_cloud_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                   const float* __restrict__ intr, const int64_t* __restrict__ ix,
+                                   float* __restrict__ points, int64_t m, int P) {
+  const int PP = P * P, c = (P / 2) * P + P / 2;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < m; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = ix[k];
+    const Pose Ginv = se3_inv(load_pose(poses + 7 * f));
+    const float* K = intr + 4 * f;
+    const float* pk = patches + k * 3 * PP;
+    const float X0[4] = {(pk[c] - K[2]) / K[0], (pk[PP + c] - K[3]) / K[1], 1.0f, pk[2 * PP + c]};
+    float X1[4];
+    se3_act4(Ginv, X0, X1);
+    points[3 * k + 0] = X1[0] / X1[3]; points[3 * k + 1] = X1[1] / X1[3]; points[3 * k + 2] = X1[2] / X1[3];
+  }
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t g = cdiv64(n, 256);
+  return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+}  // namespace
+
+#define SE3_ENTRY(name, kernel, ...)                                                              \
+  if (n < 0) return DPVO_E_INVALID;                                                               \
+  if (n == 0) return DPVO_OK;                                                                     \
+  hipLaunchKernelGGL(kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+  DPVO_LAUNCH_CHECK();                                                                            \
+  return DPVO_OK;
+
+extern "C" int dpvo_se3_inv(const float* X, float* Y, int64_t n, void* stream) { SE3_ENTRY(inv, se3_inv_kernel, X, Y, n) }
+extern "C" int dpvo_se3_mul(const float* X, const float* Y, float* Z, int64_t n, void* stream) { SE3_ENTRY(mul, se3_mul_kernel, X, Y, Z, n) }
+extern "C" int dpvo_se3_act4(const float* X, const float* p, float* q, int64_t n, void* stream) { SE3_ENTRY(act4, se3_act4_kernel, X, p, q, n) }
+extern "C" int dpvo_se3_exp(const float* a, float* X, int64_t n, void* stream) { SE3_ENTRY(exp, se3_exp_kernel, a, X, n) }
+extern "C" int dpvo_se3_log(const float* X, float* a, int64_t n, void* stream) { SE3_ENTRY(log, se3_log_kernel, X, a, n) }
+
+extern "C" int dpvo_reproject(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                              const int64_t* jj, const int64_t* kk, float* coords, int64_t E, int P, int clamp_z,
+                              void* stream) {
+  if (E < 0 || P <= 0) return DPVO_E_INVALID;
+  if (E == 0) return DPVO_OK;
+  if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !coords) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(reproject_kernel, dim3(grid_for(E * P * P)), dim3(256), 0, (hipStream_t)stream, poses, patches,
+                     intrinsics, ii, jj, kk, coords, E, P, clamp_z);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_flow_mag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                             const int64_t* jj, const int64_t* kk, float beta, float* flow, float* valid, int64_t E,
+                             int P, void* stream) {
+  if (E < 0 || P <= 0) return DPVO_E_INVALID;
+  if (E == 0) return DPVO_OK;
+  if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !flow || !valid) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(flow_mag_kernel, dim3(grid_for(E)), dim3(256), 0, (hipStream_t)stream, poses, patches, intrinsics,
+                     ii, jj, kk, beta, flow, valid, E, P);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                                float* points, int64_t m, int P, void* stream) {
+  if (m < 0 || P <= 0) return DPVO_E_INVALID;
+  if (m == 0) return DPVO_OK;
+  if (!poses || !patches || !intrinsics || !ix || !points) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(point_cloud_kernel, dim3(grid_for(m)), dim3(256), 0, (hipStream_t)stream, poses, patches,
+                     intrinsics, ix, points, m, P);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}

@@ -1,0 +1,485 @@
+"""DPVO front-end state machine with the reference's API (dpvo/dpvo.py:20-473): `DPVO(cfg, network, ht, wd, viz)`,
+`slam(tstamp, image, intrinsics)`, `slam.terminate()`, `.pg`, `.n`, `.m`, so demo.py / evaluate_*.py stay drop-in.
+
+MI355X-first differences (results unchanged):
+  * feature ring buffers are stored channels-last ([mem,H,W,128], [pmem,M,3,3,128]) -- what the MFMA correlation
+    kernel reads with coalesced 16-byte fragments; `fmap1_`, `fmap2_`, `gmap_`, `pyramid`, `gmap` expose the
+    reference's NCHW shapes as permuted views, so external code indexing them keeps working;
+  * `update()` = 1 reproject kernel + 1 fused two-level correlation kernel + the HIP update operator + the HIP
+    BA, sharing ONE device-built graph plan per frame (instead of ~150 launches and ~10 host syncs);
+  * the per-edge hidden state `pg.net` is float32 from the start.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import altcorr, fastba, lietorch
+from . import projective_ops as pops
+from .graph import GraphPlan
+from .lietorch import SE3
+from .net import VONet
+from .patchgraph import PatchGraph
+from .utils import Timer, flatmeshgrid
+
+autocast = torch.autocast
+
+
+class DPVO:
+
+    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.load_weights(network)
+        self.is_initialized = False
+        self.enable_timing = False
+        torch.set_num_threads(2)
+
+        self.M = self.cfg.PATCHES_PER_FRAME
+        self.N = self.cfg.BUFFER_SIZE
+
+        self.ht = ht    # image height
+        self.wd = wd    # image width
+
+        DIM = self.DIM
+        RES = self.RES
+
+        ### state attributes ###
+        self.tlist = []
+        self.counter = 0
+
+        # keep track of global-BA calls
+        self.ran_global_ba = np.zeros(100000, dtype=bool)
+
+        ht = ht // RES
+        wd = wd // RES
+
+        # dummy image for visualization
+        self.image_ = torch.zeros(self.ht, self.wd, 3, dtype=torch.uint8, device="cpu")
+
+        ### network attributes ###
+        if self.cfg.MIXED_PRECISION:
+            self.kwargs = kwargs = {"device": self.device, "dtype": torch.half}
+        else:
+            self.kwargs = kwargs = {"device": self.device, "dtype": torch.float}
+
+        ### frame memory size ###
+        self.pmem = self.mem = 36  # 32 was too small given default settings
+        if self.cfg.LOOP_CLOSURE:
+            self.last_global_ba = -1000  # keep track of time since last global opt
+            self.pmem = self.cfg.MAX_EDGE_AGE  # patch memory
+
+        P = self.P
+        self.imap_ = torch.zeros(self.pmem, self.M, DIM, **kwargs)
+        # channels-last storage, reference-shaped views
+        self._gmap_cl = torch.zeros(self.pmem, self.M, P, P, 128, **kwargs)
+        self.gmap_ = self._gmap_cl.permute(0, 1, 4, 2, 3)                       # [pmem, M, 128, P, P]
+
+        self.pg = PatchGraph(self.cfg, self.P, self.DIM, self.pmem, **kwargs)
+
+        # classic backend
+        if self.cfg.CLASSIC_LOOP_CLOSURE:
+            self.load_long_term_loop_closure()
+
+        self._fmap1_cl = torch.zeros(self.mem, ht // 1, wd // 1, 128, **kwargs)
+        self._fmap2_cl = torch.zeros(self.mem, ht // 4, wd // 4, 128, **kwargs)
+        self.fmap1_ = self._fmap1_cl.permute(0, 3, 1, 2)[None]                  # [1, mem, 128, h, w]
+        self.fmap2_ = self._fmap2_cl.permute(0, 3, 1, 2)[None]
+
+        # feature pyramid
+        self.pyramid = (self.fmap1_, self.fmap2_)
+
+        self._plan = None          # GraphPlan of the active edge list (rebuilt when edges change)
+        self._corr_buf = None
+
+        self.viewer = None
+        if viz:
+            self.start_viewer()
+
+    def load_long_term_loop_closure(self):
+        # classical loop closure (DBoW2 / DISK+LightGlue / pypose PGO) is out of scope
+        self.cfg.CLASSIC_LOOP_CLOSURE = False
+        print("WARNING: CLASSIC_LOOP_CLOSURE is not available in dpvo_amd; continuing without it")
+
+    def load_weights(self, network):
+        # load network from checkpoint file
+        if isinstance(network, str):
+            from collections import OrderedDict
+            state_dict = torch.load(network, map_location="cpu")
+            new_state_dict = OrderedDict()
+            for k, v in state_dict.items():
+                if "update.lmbda" not in k:
+                    new_state_dict[k.replace('module.', '')] = v
+            self.network = VONet()
+            self.network.load_state_dict(new_state_dict)
+        else:
+            self.network = network
+
+        # steal network attributes
+        self.DIM = self.network.DIM
+        self.RES = self.network.RES
+        self.P = self.network.P
+
+        self.network.to(self.device)
+        self.network.eval()
+        self.network.update.pack()
+
+    def start_viewer(self):
+        raise NotImplementedError("DPViewer (Pangolin) is out of scope; run headless")
+
+    @property
+    def poses(self):
+        return self.pg.poses_.view(1, self.N, 7)
+
+    @property
+    def patches(self):
+        return self.pg.patches_.view(1, self.N * self.M, 3, 3, 3)
+
+    @property
+    def intrinsics(self):
+        return self.pg.intrinsics_.view(1, self.N, 4)
+
+    @property
+    def ix(self):
+        return self.pg.index_.view(-1)
+
+    @property
+    def imap(self):
+        return self.imap_.view(1, self.pmem * self.M, self.DIM)
+
+    @property
+    def gmap(self):
+        return self._gmap_cl.view(self.pmem * self.M, self.P, self.P, 128).permute(0, 3, 1, 2)[None]
+
+    @property
+    def n(self):
+        return self.pg.n
+
+    @n.setter
+    def n(self, val):
+        self.pg.n = val
+
+    @property
+    def m(self):
+        return self.pg.m
+
+    @m.setter
+    def m(self, val):
+        self.pg.m = val
+
+    def get_pose(self, t):
+        if t in self.traj:
+            return SE3(self.traj[t])
+        t0, dP = self.pg.delta[t]
+        return dP * self.get_pose(t0)
+
+    def terminate(self):
+        if self.cfg.LOOP_CLOSURE:
+            self.append_factors(*self.pg.edges_loop())
+
+        for _ in range(12):
+            self.ran_global_ba[self.n] = False
+            self.update()
+
+        """ interpolate missing poses """
+        self.traj = {}
+        for i in range(self.n):
+            self.traj[self.pg.tstamps_[i]] = self.pg.poses_[i]
+
+        # iterative version of the reference's recursion (get_pose), avoids Python recursion limits
+        poses = []
+        cache = {}
+        for t in range(self.counter):
+            chain = []
+            s = t
+            while s not in self.traj and s not in cache:
+                t0, dP = self.pg.delta[s]
+                chain.append((s, dP))
+                s = t0
+            base = SE3(self.traj[s]) if s in self.traj else cache[s]
+            for s2, dP in reversed(chain):
+                base = dP * base
+                cache[s2] = base
+            poses.append(base)
+        poses = lietorch.stack(poses, dim=0)
+        poses = poses.inv().data.cpu().numpy()
+        tstamps = np.array(self.tlist, dtype=np.float64)
+
+        # Poses: x y z qx qy qz qw
+        return poses, tstamps
+
+    # ------------------------------------------------------------------------------------------ hot path pieces
+    def corr(self, coords, indicies=None):
+        """ local correlation volume (dpvo.py:200-207): fused two-level MFMA kernel -> [1, E, 882] f16 """
+        ii, jj = indicies if indicies is not None else (self.pg.kk, self.pg.jj)
+        ii1 = ii % (self.M * self.pmem)
+        jj1 = jj % (self.mem)
+        E = ii.numel()
+        if self._gmap_cl.dtype == torch.float16:
+            out = altcorr.corr_pyramid(self._gmap_cl.view(self.pmem * self.M, self.P * self.P, 128), self._fmap1_cl,
+                                       self._fmap2_cl, coords, ii1, jj1, radius=3)
+            return out.unsqueeze(0)
+        corr1 = altcorr.corr(self.gmap, self.pyramid[0], coords / 1, ii1, jj1, 3)
+        corr2 = altcorr.corr(self.gmap, self.pyramid[1], coords / 4, ii1, jj1, 3)
+        return torch.stack([corr1, corr2], -1).view(1, E, -1)
+
+    def reproject(self, indicies=None):
+        """ reproject patch k from i -> j (dpvo.py:209-213): one fused kernel -> coords [1,E,2,P,P] """
+        (ii, jj, kk) = indicies if indicies is not None else (self.pg.ii, self.pg.jj, self.pg.kk)
+        return pops.transform_coords(self.poses, self.patches, self.intrinsics, ii, jj, kk)
+
+    def append_factors(self, ii, jj):
+        self.pg.jj = torch.cat([self.pg.jj, jj])
+        self.pg.kk = torch.cat([self.pg.kk, ii])
+        self.pg.ii = torch.cat([self.pg.ii, self.ix[ii]])
+
+        net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
+        self.pg.net = torch.cat([self.pg.net, net], dim=1)
+        self._plan = None
+
+    def remove_factors(self, m, store: bool):
+        assert self.pg.ii.numel() == self.pg.weight.shape[1]
+        if store:
+            self.pg.ii_inac = torch.cat((self.pg.ii_inac, self.pg.ii[m]))
+            self.pg.jj_inac = torch.cat((self.pg.jj_inac, self.pg.jj[m]))
+            self.pg.kk_inac = torch.cat((self.pg.kk_inac, self.pg.kk[m]))
+            self.pg.weight_inac = torch.cat((self.pg.weight_inac, self.pg.weight[:, m]), dim=1)
+            self.pg.target_inac = torch.cat((self.pg.target_inac, self.pg.target[:, m]), dim=1)
+        self.pg.weight = self.pg.weight[:, ~m]
+        self.pg.target = self.pg.target[:, ~m]
+
+        self.pg.ii = self.pg.ii[~m]
+        self.pg.jj = self.pg.jj[~m]
+        self.pg.kk = self.pg.kk[~m]
+        self.pg.net = self.pg.net[:, ~m]
+        assert self.pg.ii.numel() == self.pg.weight.shape[1]
+        self._plan = None
+
+    def motion_probe(self):
+        """ kinda hacky way to ensure enough motion for initialization (dpvo.py:240-255) """
+        kk = torch.arange(self.m - self.M, self.m, device=self.device)
+        jj = self.n * torch.ones_like(kk)
+        ii = self.ix[kk]
+
+        net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
+        coords = self.reproject(indicies=(ii, jj, kk))
+        corr = self.corr(coords, indicies=(kk, jj))
+        net, (delta, weight, _) = self.network.update(
+            net, self.imap, corr, None, ii, jj, kk, inp_rows=kk, inp_mod=self.M * self.pmem,
+            corr_is_padded=(corr.stride(1) == 896))
+        return torch.quantile(delta.norm(dim=-1).float(), 0.5)
+
+    def motionmag(self, i, j):
+        k = (self.pg.ii == i) & (self.pg.jj == j)
+        ii = self.pg.ii[k]
+        jj = self.pg.jj[k]
+        kk = self.pg.kk[k]
+        flow, _ = pops.flow_mag(self.poses, self.patches, self.intrinsics, ii, jj, kk, beta=0.5)
+        return flow.mean().item()
+
+    def keyframe(self):
+        i = self.n - self.cfg.KEYFRAME_INDEX - 1
+        j = self.n - self.cfg.KEYFRAME_INDEX + 1
+        m = self.motionmag(i, j) + self.motionmag(j, i)
+
+        if m / 2 < self.cfg.KEYFRAME_THRESH:
+            k = self.n - self.cfg.KEYFRAME_INDEX
+            t0 = self.pg.tstamps_[k - 1]
+            t1 = self.pg.tstamps_[k]
+
+            dP = SE3(self.pg.poses_[k]) * SE3(self.pg.poses_[k - 1]).inv()
+            self.pg.delta[t1] = (t0, dP)
+
+            to_remove = (self.pg.ii == k) | (self.pg.jj == k)
+            self.remove_factors(to_remove, store=False)
+
+            self.pg.kk[self.pg.ii > k] -= self.M
+            self.pg.ii[self.pg.ii > k] -= 1
+            self.pg.jj[self.pg.jj > k] -= 1
+
+            # shift the ring buffers down by one slot (the reference does this with a Python loop of
+            # device-to-device copies, dpvo.py:289-299; tstamps_ is a host array)
+            for i in range(k, self.n - 1):
+                self.pg.tstamps_[i] = self.pg.tstamps_[i + 1]
+                self.pg.colors_[i] = self.pg.colors_[i + 1]
+                self.pg.poses_[i] = self.pg.poses_[i + 1]
+                self.pg.patches_[i] = self.pg.patches_[i + 1]
+                self.pg.intrinsics_[i] = self.pg.intrinsics_[i + 1]
+
+                self.imap_[i % self.pmem] = self.imap_[(i + 1) % self.pmem]
+                self._gmap_cl[i % self.pmem] = self._gmap_cl[(i + 1) % self.pmem]
+                self._fmap1_cl[i % self.mem] = self._fmap1_cl[(i + 1) % self.mem]
+                self._fmap2_cl[i % self.mem] = self._fmap2_cl[(i + 1) % self.mem]
+
+            self.n -= 1
+            self.m -= self.M
+            self._plan = None
+
+        to_remove = self.ix[self.pg.kk] < self.n - self.cfg.REMOVAL_WINDOW  # Remove edges falling outside the optimization window
+        if self.cfg.LOOP_CLOSURE:
+            # ...unless they are being used for loop closure
+            lc_edges = ((self.pg.jj - self.pg.ii) > 30) & (self.pg.jj > (self.n - self.cfg.OPTIMIZATION_WINDOW))
+            to_remove = to_remove & ~lc_edges
+        self.remove_factors(to_remove, store=True)
+
+    def __run_global_BA(self):
+        """ Global bundle adjustment
+         Includes both active and inactive edges """
+        full_target = torch.cat((self.pg.target_inac, self.pg.target), dim=1)
+        full_weight = torch.cat((self.pg.weight_inac, self.pg.weight), dim=1)
+        full_ii = torch.cat((self.pg.ii_inac, self.pg.ii))
+        full_jj = torch.cat((self.pg.jj_inac, self.pg.jj))
+        full_kk = torch.cat((self.pg.kk_inac, self.pg.kk))
+
+        self.pg.normalize()
+        t0 = self.pg.ii.min().item()
+        fastba.BA(self.poses, self.patches, self.intrinsics,
+                  full_target, full_weight, 1e-4, full_ii, full_jj, full_kk, t0, self.n, M=self.M, iterations=2,
+                  eff_impl=True)
+        self.ran_global_ba[self.n] = True
+
+    def plan(self):
+        if self._plan is None or self._plan.E != self.pg.ii.numel():
+            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk)
+        return self._plan
+
+    def update(self):
+        with Timer("other", enabled=self.enable_timing):
+            plan = self.plan()
+            coords = self.reproject()
+            corr = self.corr(coords)
+            self.pg.net, (delta, weight, _) = self.network.update(
+                self.pg.net, self.imap, corr, None, self.pg.ii, self.pg.jj, self.pg.kk, plan=plan,
+                inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896))
+
+            lmbda = 1e-4
+            weight = weight.float()
+            target = coords[..., self.P // 2, self.P // 2] + delta.float()
+
+        self.pg.target = target
+        self.pg.weight = weight
+
+        with Timer("BA", enabled=self.enable_timing):
+            try:
+                # run global bundle adjustment if there exist long-range edges
+                if self.cfg.LOOP_CLOSURE and (self.pg.ii < self.n - self.cfg.REMOVAL_WINDOW - 1).any() \
+                        and not self.ran_global_ba[self.n]:
+                    self.__run_global_BA()
+                else:
+                    t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1
+                    t0 = max(t0, 1)
+                    fastba.BA(self.poses, self.patches, self.intrinsics,
+                              target, weight, lmbda, self.pg.ii, self.pg.jj, self.pg.kk, t0, self.n, M=self.M,
+                              iterations=2, eff_impl=False, plan=plan)
+            except Exception as e:      # the reference swallows everything with a bare except (dpvo.py:355-356)
+                print("Warning BA failed...", repr(e))
+
+            points = pops.point_cloud(self.poses, self.patches[:, :self.m], self.intrinsics, self.ix[:self.m])
+            self.pg.points_[:len(points)] = points[:]
+
+    def _edges_forw(self):
+        r = self.cfg.PATCH_LIFETIME
+        t0 = self.M * max((self.n - r), 0)
+        t1 = self.M * max((self.n - 1), 0)
+        return flatmeshgrid(
+            torch.arange(t0, t1, device=self.device),
+            torch.arange(self.n - 1, self.n, device=self.device), indexing='ij')
+
+    def _edges_back(self):
+        r = self.cfg.PATCH_LIFETIME
+        t0 = self.M * max((self.n - 1), 0)
+        t1 = self.M * max((self.n - 0), 0)
+        return flatmeshgrid(torch.arange(t0, t1, device=self.device),
+                            torch.arange(max(self.n - r, 0), self.n, device=self.device), indexing='ij')
+
+    def __call__(self, tstamp, image, intrinsics, patch_coords=None, depth_init=None):
+        """ track new frame (dpvo.py:377-473).  `patch_coords` / `depth_init` optionally inject the two random
+        draws of the reference (patch centroids net.py:132-133, depth rand_like dpvo.py:427) for reproducible tests """
+
+        if (self.n + 1) >= self.N:
+            raise Exception(f'The buffer size is too small. You can increase it using "--opts BUFFER_SIZE={self.N*2}"')
+
+        image = 2 * (image[None, None] / 255.0) - 0.5
+
+        with autocast(device_type="cuda", enabled=self.cfg.MIXED_PRECISION):
+            fmap, gmap, imap, patches, _, clr = \
+                self.network.patchify(image,
+                                      patches_per_image=self.cfg.PATCHES_PER_FRAME,
+                                      centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
+                                      return_color=True, coords=patch_coords)
+
+        ### update state attributes ###
+        self.tlist.append(tstamp)
+        self.pg.tstamps_[self.n] = self.counter
+        self.pg.intrinsics_[self.n] = intrinsics / self.RES
+
+        # color info for visualization
+        clr = (clr[0, :, [2, 1, 0]] + 0.5) * (255.0 / 2)
+        self.pg.colors_[self.n] = clr.to(torch.uint8)
+
+        self.pg.index_[self.n + 1] = self.n + 1
+        self.pg.index_map_[self.n + 1] = self.m + self.M
+
+        if self.n > 1:
+            if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                P1 = SE3(self.pg.poses_[self.n - 1])
+                P2 = SE3(self.pg.poses_[self.n - 2])
+
+                # To deal with varying camera hz
+                *_, a, b, c = [1] * 3 + self.tlist
+                fac = (c - b) / (b - a)
+
+                xi = self.cfg.MOTION_DAMPING * fac * (P1 * P2.inv()).log()
+                tvec_qvec = (SE3.exp(xi) * P1).data
+                self.pg.poses_[self.n] = tvec_qvec
+            else:
+                tvec_qvec = self.poses[self.n - 1]
+                self.pg.poses_[self.n] = tvec_qvec
+
+        # TODO better depth initialization
+        patches = patches.float()
+        if depth_init is None:
+            patches[:, :, 2] = torch.rand_like(patches[:, :, 2, 0, 0, None, None])
+        else:
+            patches[:, :, 2] = depth_init.view(1, -1, 1, 1).to(patches)
+        if self.is_initialized:
+            s = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
+            patches[:, :, 2] = s
+
+        self.pg.patches_[self.n] = patches
+
+        ### update network attributes ###
+        self.imap_[self.n % self.pmem] = imap.squeeze()
+        self.gmap_[self.n % self.pmem] = gmap.squeeze()
+        self.fmap1_[:, self.n % self.mem] = F.avg_pool2d(fmap[0], 1, 1)
+        self.fmap2_[:, self.n % self.mem] = F.avg_pool2d(fmap[0], 4, 4)
+
+        self.counter += 1
+        if self.n > 0 and not self.is_initialized:
+            if self.motion_probe() < 2.0:
+                self.pg.delta[self.counter - 1] = (self.counter - 2, SE3.Identity(1, device=self.device)[0])
+                return
+
+        self.n += 1
+        self.m += self.M
+
+        if self.cfg.LOOP_CLOSURE:
+            if self.n - self.last_global_ba >= self.cfg.GLOBAL_OPT_FREQ:
+                """ Add loop closure factors """
+                lii, ljj = self.pg.edges_loop()
+                if lii.numel() > 0:
+                    self.last_global_ba = self.n
+                    self.append_factors(lii, ljj)
+
+        # Add forward and backward factors
+        self.append_factors(*self._edges_forw())
+        self.append_factors(*self._edges_back())
+
+        if self.n == 8 and not self.is_initialized:
+            self.is_initialized = True
+
+            for itr in range(12):
+                self.update()
+
+        elif self.is_initialized:
+            self.update()
+            self.keyframe()

@@ -1,0 +1,50 @@
+"""Device-resident patch-graph plan (`dpvo_plan_build`): the sorted/grouped index structures that the
+reference recomputes with host round trips every update -- fastba.neighbors (dpvo/fastba/ba.cpp:59-97),
+torch::_unique in cuda_ba (dpvo/fastba/ba_cuda.cu:447-449) and torch.unique in SoftAgg (dpvo/blocks.py:41).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import workspace
+
+
+class GraphPlan:
+    """All views are int32 device tensors into one buffer; `counts` = [n_patches, n_pairs, 0, 0] stays on the
+    device (no synchronisation); `n_patches()` / `n_pairs()` synchronise and are for tests / host logic only."""
+
+    def __init__(self, ii, jj, kk):
+        L.require_cuda(ii, jj, kk)
+        assert ii.dtype == jj.dtype == kk.dtype == torch.long
+        E = ii.numel()
+        assert jj.numel() == E and kk.numel() == E
+        self.E = E
+        lay = L.plan_layout(E)
+        self.buf = torch.empty(lay.total_ints, dtype=torch.int32, device=ii.device)
+        n = max(E, 1)
+        v = lambda off, cnt: self.buf[off:off + cnt]
+        self.perm_k, self.ku, self.kx = v(lay.perm_k, n), v(lay.ku, n), v(lay.kx, n)
+        self.patch_off = v(lay.patch_off, n + 1)
+        self.ix, self.jx = v(lay.ix, n), v(lay.jx, n)
+        self.perm_p, self.pu = v(lay.perm_p, n), v(lay.pu, n)
+        self.pair_off = v(lay.pair_off, n + 1)
+        self.pair_ij = v(lay.pair_ij, 2 * n)
+        self.counts = v(lay.counts, 4)
+        ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
+        self._keep = (ii, jj, kk)
+        nbytes = L.lib().dpvo_plan_workspace_bytes(L.i64(E))
+        ws = workspace.get(nbytes, ii.device, "plan")
+        L.check(L.lib().dpvo_plan_build(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
+                                        ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_plan_build")
+
+        # one host read-back per plan (= per frame): exact grid sizes for the group-level launches.  The
+        # reference synchronises ~10x per update for the same information.
+        c = self.counts[:2].tolist()
+        self.n_patches_host, self.n_pairs_host = int(c[0]), int(c[1])
+
+    def n_patches(self):
+        return self.n_patches_host
+
+    def n_pairs(self):
+        return self.n_pairs_host

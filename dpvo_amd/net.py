@@ -1,0 +1,292 @@
+"""VONet / Update / Patchifier with the reference's module tree and state-dict keys (dpvo/net.py:27-184,
+dpvo/blocks.py:15-48), so `dpvo.pth` loads unchanged, and `Update.forward` executed by the HIP kernels of
+dpvo_amd/csrc/update.hip instead of ~60 torch / torch_scatter launches.
+
+The nn.Module parameters are the single source of truth; `Update.pack()` derives the f16 operand images the
+kernels consume (what autocast's per-call weight casts produce in the reference, dpvo/dpvo.py:332).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import altcorr
+from .extractor import BasicEncoder4
+from .graph import GraphPlan
+from .utils import coords_grid_with_index
+
+DIM = 384
+
+EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
+
+
+# ------------------------------------------------------------------------------------------ kernels' Python face
+def linear(A, W, bias, out=None, epilogue=EPI_NONE, rows=None, gate=None, n_split=0, K=None):
+    """dpvo_linear: A [M,>=K] f16/f32 (row stride = A.stride(0)), W [N,K] f16, bias [N] f16."""
+    M = A.shape[0]
+    N = W.shape[0]
+    K = K or W.shape[1]
+    assert A.stride(1) == 1 and W.stride(1) == 1
+    if epilogue in (EPI_RESADD, EPI_GATED):
+        assert out is not None and out.dtype == torch.float32
+    elif out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=A.device)
+    L.check(L.lib().dpvo_linear(L.ptr(A), L.i32(L.dtype_code(A.dtype)), L.i64(A.stride(0)), L.ptr(rows), L.ptr(W),
+                                L.i64(W.stride(0)), L.ptr(bias), L.ptr(out), L.i64(out.stride(0)), L.ptr(gate),
+                                L.i64(gate.stride(0) if gate is not None else 0), L.i32(epilogue), L.i32(n_split),
+                                L.i64(M), L.i32(N), L.i32(K), L.stream()), "dpvo_linear")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-3, add1=None, add1_rows=None, add1_mod=0, add2=None, y_f32=None, y_f16=None,
+              relu_f16=False):
+    M, D = x.shape
+    assert x.is_contiguous()
+    L.check(L.lib().dpvo_layernorm(L.ptr(x), L.i32(L.dtype_code(x.dtype)), L.ptr(add1), L.ptr(add1_rows),
+                                   L.i64(add1_mod), L.ptr(add2), L.ptr(gamma), L.ptr(beta), L.f32(eps), L.ptr(y_f32),
+                                   L.ptr(y_f16), L.i32(1 if relu_f16 else 0), L.i64(M), L.i32(D), L.stream()),
+            "dpvo_layernorm")
+
+
+def softagg(fg, perm, off, n_groups_dev, n_groups):
+    y = torch.empty(max(n_groups, 1), DIM, dtype=torch.float16, device=fg.device)
+    L.check(L.lib().dpvo_softagg(L.ptr(fg), L.i64(fg.stride(0)), L.ptr(perm), L.ptr(off), L.ptr(n_groups_dev),
+                                 L.i64(n_groups), L.ptr(y), L.i32(DIM), L.stream()), "dpvo_softagg")
+    return y
+
+
+def gather_add(net, hy, group):
+    L.check(L.lib().dpvo_gather_add(L.ptr(net), L.ptr(hy), L.ptr(group), L.i64(net.shape[0]), L.i32(DIM), L.stream()),
+            "dpvo_gather_add")
+
+
+def heads(net, Wd, bd, Ww, bw):
+    E = net.shape[0]
+    delta = torch.empty(E, 2, dtype=torch.float32, device=net.device)
+    weight = torch.empty(E, 2, dtype=torch.float32, device=net.device)
+    L.check(L.lib().dpvo_heads(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight),
+                               L.i64(E), L.i32(DIM), L.stream()), "dpvo_heads")
+    return delta, weight
+
+
+# ------------------------------------------------------------------------------------------ modules (reference tree)
+class GradientClip(nn.Module):
+    """identity in forward (dpvo/blocks.py:74-89); kept so that Sequential indices match the checkpoint keys"""
+
+    def forward(self, x):
+        return x
+
+
+class GatedResidual(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gate = nn.Sequential(nn.Linear(dim, dim), nn.Sigmoid())
+        self.res = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Linear(dim, dim))
+
+
+class SoftAgg(nn.Module):
+    def __init__(self, dim=512, expand=True):
+        super().__init__()
+        self.dim = dim
+        self.expand = expand
+        self.f = nn.Linear(self.dim, self.dim)
+        self.g = nn.Linear(self.dim, self.dim)
+        self.h = nn.Linear(self.dim, self.dim)
+
+
+class Update(nn.Module):
+    def __init__(self, p):
+        super().__init__()
+        self.c1 = nn.Sequential(nn.Linear(DIM, DIM), nn.ReLU(inplace=True), nn.Linear(DIM, DIM))
+        self.c2 = nn.Sequential(nn.Linear(DIM, DIM), nn.ReLU(inplace=True), nn.Linear(DIM, DIM))
+        self.norm = nn.LayerNorm(DIM, eps=1e-3)
+        self.agg_kk = SoftAgg(DIM)
+        self.agg_ij = SoftAgg(DIM)
+        self.gru = nn.Sequential(
+            nn.LayerNorm(DIM, eps=1e-3), GatedResidual(DIM),
+            nn.LayerNorm(DIM, eps=1e-3), GatedResidual(DIM))
+        self.corr = nn.Sequential(
+            nn.Linear(2 * 49 * p * p, DIM), nn.ReLU(inplace=True), nn.Linear(DIM, DIM),
+            nn.LayerNorm(DIM, eps=1e-3), nn.ReLU(inplace=True), nn.Linear(DIM, DIM))
+        self.d = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(DIM, 2), GradientClip())
+        self.w = nn.Sequential(nn.ReLU(inplace=False), nn.Linear(DIM, 2), GradientClip(), nn.Sigmoid())
+        self.ncorr = 2 * 49 * p * p
+        self.kpad = (self.ncorr + 31) // 32 * 32
+        self._packed = None
+
+    # -------------------------------------------------------------------------------------- operand images
+    def pack(self):
+        """f16 weight images for the kernels (re-run after loading / changing parameters)."""
+        h = lambda t: t.detach().to(torch.float16).contiguous()
+        f = lambda t: t.detach().float().contiguous()
+        dev = self.norm.weight.device
+        P = {}
+        w0 = torch.zeros(DIM, self.kpad, dtype=torch.float16, device=dev)
+        w0[:, :self.ncorr] = h(self.corr[0].weight)
+        P["c0"] = (w0, h(self.corr[0].bias))
+        P["c2"] = (h(self.corr[2].weight), h(self.corr[2].bias))
+        P["cln"] = (f(self.corr[3].weight), f(self.corr[3].bias))
+        P["c5"] = (h(self.corr[5].weight), h(self.corr[5].bias))
+        P["norm"] = (f(self.norm.weight), f(self.norm.bias))
+        for name, mod in (("c1", self.c1), ("c2n", self.c2)):
+            P[name] = (h(mod[0].weight), h(mod[0].bias), h(mod[2].weight), h(mod[2].bias))
+        for name, mod in (("akk", self.agg_kk), ("aij", self.agg_ij)):
+            P[name] = (h(torch.cat([mod.f.weight, mod.g.weight], 0)), h(torch.cat([mod.f.bias, mod.g.bias], 0)),
+                       h(mod.h.weight), h(mod.h.bias))
+        for name, ln, gr in (("g0", self.gru[0], self.gru[1]), ("g1", self.gru[2], self.gru[3])):
+            P[name] = (f(ln.weight), f(ln.bias),
+                       h(torch.cat([gr.res[0].weight, gr.gate[0].weight], 0)),
+                       h(torch.cat([gr.res[0].bias, gr.gate[0].bias], 0)),
+                       h(gr.res[2].weight), h(gr.res[2].bias))
+        P["d"] = (h(self.d[1].weight), h(self.d[1].bias))
+        P["w"] = (h(self.w[1].weight), h(self.w[1].bias))
+        self._packed = P
+        return P
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    # -------------------------------------------------------------------------------------- forward
+    @torch.no_grad()
+    def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False):
+        """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
+        un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
+        Returns net f32 [1,E,384], (delta f32 [1,E,2], weight f32 [1,E,2], None)."""
+        P = self._packed or self.pack()
+        L.require_cuda(net, inp, corr, ii, jj, kk)
+        E = ii.numel()
+        dev = net.device
+        if E == 0:
+            z = torch.zeros(1, 0, 2, device=dev)
+            return net.float(), (z, z.clone(), None)
+        if plan is None:
+            plan = GraphPlan(ii, jj, kk)
+
+        corr2 = corr.reshape(E, -1)
+        if corr_is_padded:
+            # rows of a [E, kpad] f16 buffer whose columns >= 882 are zero (altcorr.corr_pyramid output)
+            assert corr2.dtype == torch.float16 and corr2.stride(1) == 1 and corr2.stride(0) == self.kpad
+        else:
+            buf = torch.zeros(E, self.kpad, dtype=torch.float16, device=dev)
+            buf[:, :corr2.shape[1]] = corr2
+            corr2 = buf
+
+        net2 = net.reshape(E, DIM)
+        if not net2.is_contiguous():
+            net2 = net2.contiguous()
+        inp2 = inp.reshape(-1, DIM)
+        if inp2.dtype != torch.float16:
+            inp2 = inp2.half()
+        inp2 = inp2.contiguous()
+
+        # net = net + inp + self.corr(corr); net = self.norm(net)                              (net.py:77-78)
+        h1 = linear(corr2, P["c0"][0], P["c0"][1], epilogue=EPI_RELU, K=self.kpad)
+        h2 = linear(h1, P["c2"][0], P["c2"][1])
+        layernorm(h2, P["cln"][0], P["cln"][1], y_f16=h1, relu_f16=True)
+        c = linear(h1, P["c5"][0], P["c5"][1], out=h2)
+        x = torch.empty(E, DIM, dtype=torch.float32, device=dev)
+        layernorm(net2, P["norm"][0], P["norm"][1], add1=inp2, add1_rows=inp_rows, add1_mod=inp_mod, add2=c, y_f32=x)
+
+        # net = net + c1(mask_ix * net[:,ix]); net = net + c2(mask_jx * net[:,jx])              (net.py:80-85)
+        for name, rows in (("c1", plan.ix), ("c2n", plan.jx)):
+            W0, b0, W2, b2 = P[name]
+            t = linear(x, W0, b0, out=h1, epilogue=EPI_RELU, rows=rows)
+            linear(t, W2, b2, out=x, epilogue=EPI_RESADD)
+
+        # net = net + agg_kk(net, kk); net = net + agg_ij(net, ii*12345 + jj)                    (net.py:87-88)
+        fg = torch.empty(E, 2 * DIM, dtype=torch.float16, device=dev)
+        for name, perm, off, cnt_dev, cnt, grp in (
+                ("akk", plan.perm_k, plan.patch_off, plan.counts[0:1], plan.n_patches_host, plan.ku),
+                ("aij", plan.perm_p, plan.pair_off, plan.counts[1:2], plan.n_pairs_host, plan.pu)):
+            Wfg, bfg, Wh, bh = P[name]
+            linear(x, Wfg, bfg, out=fg)
+            y = softagg(fg, perm, off, cnt_dev, cnt)
+            hy = linear(y, Wh, bh)
+            gather_add(x, hy, grp)
+
+        # net = self.gru(net): 2 x (LayerNorm, x + gate(x) * res(x))                            (net.py:90)
+        for name in ("g0", "g1"):
+            g, b, Wrg, brg, W2, b2 = P[name]
+            layernorm(x, g, b, y_f32=x, y_f16=h1)
+            linear(h1, Wrg, brg, out=fg, epilogue=EPI_RELU_SIG, n_split=DIM)
+            linear(fg[:, :DIM], W2, b2, out=x, epilogue=EPI_GATED, gate=fg[:, DIM:])
+
+        delta, weight = heads(x, P["d"][0], P["d"][1], P["w"][0], P["w"][1])                   # net.py:92
+        return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
+
+
+class Patchifier(nn.Module):
+    """Patch extraction (net.py:95-157).  Encoders run on MIOpen via PyTorch-ROCm (out of the hot path, 8f)."""
+
+    def __init__(self, patch_size=3):
+        super().__init__()
+        self.patch_size = patch_size
+        self.fnet = BasicEncoder4(output_dim=128, norm_fn='instance')
+        self.inet = BasicEncoder4(output_dim=DIM, norm_fn='none')
+
+    def __image_gradient(self, images):
+        gray = ((images + 0.5) * (255.0 / 2)).sum(dim=2)
+        dx = gray[..., :-1, 1:] - gray[..., :-1, :-1]
+        dy = gray[..., 1:, :-1] - gray[..., :-1, :-1]
+        g = torch.sqrt(dx ** 2 + dy ** 2)
+        g = F.avg_pool2d(g, 4, 4)
+        return g
+
+    def forward(self, images, patches_per_image=80, disps=None, centroid_sel_strat='RANDOM', return_color=False,
+                coords=None):
+        """`coords` ([n, patches, 2] float, optional) injects the patch centroids (deterministic tests / oracle
+        replay); otherwise they are drawn exactly like the reference (x then y, net.py:131-133)."""
+        fmap = self.fnet(images) / 4.0
+        imap = self.inet(images) / 4.0
+        b, n, c, h, w = fmap.shape
+        P = self.patch_size
+        dev = fmap.device
+
+        if coords is None:
+            if centroid_sel_strat == 'GRADIENT_BIAS':
+                g = self.__image_gradient(images)
+                x = torch.randint(1, w - 1, size=[n, 3 * patches_per_image], device=dev)
+                y = torch.randint(1, h - 1, size=[n, 3 * patches_per_image], device=dev)
+                coords = torch.stack([x, y], dim=-1).float()
+                g = altcorr.patchify(g[0, :, None], coords, 0).view(n, 3 * patches_per_image)
+                ix = torch.argsort(g, dim=1)
+                x = torch.gather(x, 1, ix[:, -patches_per_image:])
+                y = torch.gather(y, 1, ix[:, -patches_per_image:])
+            elif centroid_sel_strat == 'RANDOM':
+                x = torch.randint(1, w - 1, size=[n, patches_per_image], device=dev)
+                y = torch.randint(1, h - 1, size=[n, patches_per_image], device=dev)
+            else:
+                raise NotImplementedError(f"Patch centroid selection not implemented: {centroid_sel_strat}")
+            coords = torch.stack([x, y], dim=-1).float()
+
+        imap = altcorr.patchify(imap[0], coords, 0).view(b, -1, DIM, 1, 1)
+        gmap = altcorr.patchify(fmap[0], coords, P // 2).view(b, -1, 128, P, P)
+        if return_color:
+            clr = altcorr.patchify(images[0], 4 * (coords + 0.5), 0).view(b, -1, 3)
+        if disps is None:
+            disps = torch.ones(b, n, h, w, device=dev)
+        grid, _ = coords_grid_with_index(disps, device=dev)
+        patches = altcorr.patchify(grid[0], coords, P // 2).view(b, -1, 3, P, P)
+        index = torch.arange(n, device=dev).view(n, 1)
+        index = index.repeat(1, patches_per_image).reshape(-1)
+        if return_color:
+            return fmap, gmap, imap, patches, index, clr
+        return fmap, gmap, imap, patches, index
+
+
+class VONet(nn.Module):
+    def __init__(self, use_viewer=False):
+        super().__init__()
+        self.P = 3
+        self.patchify = Patchifier(self.P)
+        self.update = Update(self.P)
+        self.DIM = DIM
+        self.RES = 4
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("VONet.forward is the training loop of the reference (net.py:187-272): out of scope")

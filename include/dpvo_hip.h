@@ -1,0 +1,215 @@
+/*
+ * dpvo_hip.h -- C ABI of libdpvo_hip.so: the MI355X (gfx950) implementation of DPVO's per-frame
+ * hot path (altcorr correlation -> update operator -> fastba bundle adjustment).
+ *
+ * This header is the drop-in boundary.  Each entry replaces one function the reference binds
+ * through pybind11 (`cuda_corr`, `cuda_ba`, `lietorch_backends`; /root/reference/setup.py:13-36) or
+ * one torch-level stage of `Update.forward`; the reference interface is cited per entry as
+ * file:line relative to the reference checkout.  INTEGRATION.md shows the Python-side stub a
+ * maintainer adds to dpvo/altcorr/correlation.py, dpvo/fastba/ba.py and dpvo/lietorch/group_ops.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); the
+ *     library never frees or retains a pointer after the call returns;
+ *   - `stream` is a hipStream_t passed as void* (NULL = legacy default stream); calls are
+ *     asynchronous with respect to the host and re-entrant per stream, no global mutable state;
+ *   - return value: 0 = ok, <0 = invalid argument / unsupported configuration (DPVO_E_*),
+ *     >0 = a hipError_t from the launch; nothing ever calls exit();
+ *   - index tensors are int64 exactly as the reference passes them (torch.long);
+ *   - workspaces: `*_workspace_bytes` returns the size the matching call needs in `ws`.
+ */
+#ifndef DPVO_HIP_H
+#define DPVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPVO_OK 0
+#define DPVO_E_INVALID (-1)      /* bad argument (null pointer, negative size, ...)            */
+#define DPVO_E_UNSUPPORTED (-2)  /* configuration outside what this entry implements           */
+#define DPVO_E_WORKSPACE (-3)    /* workspace too small                                        */
+
+#define DPVO_F16 0
+#define DPVO_F32 1
+
+/* ABI version: bumped on any signature change. */
+int dpvo_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * altcorr  (replaces cuda_corr: dpvo/altcorr/correlation.cpp:57-63)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* cuda_corr.forward(fmap1, fmap2, coords, ii, jj, radius) -- correlation.cpp:28-35,58 ->
+ * corr_cuda_forward, correlation_kernel.cu:193-233 (kernel :82-136 + bilinear :221-232), batch 1.
+ *   fmap1  [N1,C,P,P]   strides s1 = {n,c,i,j} in elements (any layout)
+ *   fmap2  [N2,C,H2,W2] strides s2 = {n,c,h,w} in elements (any layout)
+ *   coords [E,2,P,P] f32 contiguous, multiplied by coord_scale before use (DPVO.corr passes coords/4
+ *          for level 1, dpvo/dpvo.py:206)
+ *   us,vs  [E] int64 indices into fmap1 / fmap2
+ *   out    [E, D-1 (y), D-1 (x), P, P] contiguous, dtype = feature dtype; the reference returns
+ *          out.permute(0,1,3,2,4,5) of exactly this tensor (:232); D = 2*radius+2.
+ * Accumulates in f32 (the reference accumulates in the feature dtype), rounds once on store. */
+int dpvo_corr_forward(const void* fmap1, const int64_t* s1, const void* fmap2, const int64_t* s2,
+                      const float* coords, float coord_scale, const int64_t* us, const int64_t* vs,
+                      void* out, int dtype, int64_t E, int C, int P, int64_t N1, int64_t N2, int H2, int W2,
+                      int radius, void* stream);
+
+/* Fused two-level correlation == DPVO.corr (dpvo/dpvo.py:200-207): both altcorr.corr calls, the
+ * bilinear blend, the permute, torch.stack(...,-1) and .view(1,E,-1) in one MFMA kernel.
+ *   gmap   [N1, P*P, C]      f16 channels-last  (logical [N1,C,P,P])
+ *   fmap0  [N2, H0, W0, C]   f16 channels-last  (logical [N2,C,H0,W0]), level 0 (coords/1)
+ *   fmap1  [N2, H1, W1, C]   f16 channels-last, level 1 (coords/4)
+ *   coords [E,2,P,P] f32; us,vs [E] int64 (already reduced modulo the ring sizes)
+ *   order  [E] int32 or NULL: processing order of edges (an L2 / XCD locality hint; any permutation
+ *          of 0..E-1; results do not depend on it)
+ *   out    [E, ld_out] f16, ld_out >= 2*49*P*P, feature index ((((x*7+y)*P+i0)*P+j0)*2+level)
+ *          exactly as the reference's stacked view; columns >= 882 of a padded row are zeroed.
+ * Supported: C == 128, P == 3, radius == 3 (the only configuration DPVO uses, net.py:53,
+ * dpvo.py:205-206); anything else returns DPVO_E_UNSUPPORTED and callers use dpvo_corr_forward. */
+int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, const void* fmap1, const float* coords,
+                              const int64_t* us, const int64_t* vs, const int32_t* order, void* out,
+                              int64_t ld_out, int64_t E, int C, int P, int64_t N1, int64_t N2, int H0, int W0,
+                              int H1, int W1, int radius, void* stream);
+
+/* cuda_corr.patchify_forward(net, coords, radius) -- correlation.cpp:46-49,61 ->
+ * correlation_kernel.cu:16-47,286-306.  Integer-floor gather of (2R+2)^2 windows, zeros when OOB.
+ *   net [C,H,W] strides sn={c,h,w}; coords [M,2] f32; out [M,C,D,D] contiguous (D=2R+2). */
+int dpvo_patchify_forward(const void* net, const int64_t* sn, const float* coords, void* out, int dtype,
+                          int64_t M, int C, int H, int W, int radius, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * projective ops  (replaces the lietorch + elementwise chain of pops.transform)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* DPVO.reproject (dpvo/dpvo.py:209-213) == pops.transform(SE3(poses), patches, intrinsics, ii,jj,kk)
+ * (dpvo/projective_ops.py:53-68: iproj :19-29, Gj*Gi^-1 via lietorch se3.h:36-56, act4, proj with
+ * Z clamp 0.1 :43) followed by permute(0,1,4,2,3).
+ *   poses [NP,7] f32 (t, q_xyzw), patches [NK,3,P,P] f32, intrinsics [NP,4] f32, ii,jj,kk [E] int64
+ *   coords out [E,2,P,P] f32.  Also the exported-but-unused cuda_ba.reproject (ba.cpp:48-56) maps
+ * here with clamp_z=0 (ba_cuda.cu:379-429 divides by raw Z and uses intrinsics[0] for all frames). */
+int dpvo_reproject(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                   const int64_t* jj, const int64_t* kk, float* coords, int64_t E, int P, int clamp_z,
+                   void* stream);
+
+/* pops.flow_mag (projective_ops.py:120-130) reduced as DPVO.motionmag uses it (dpvo.py:257-264):
+ * writes per-edge mean-over-patch flow to flow[E] and validity count to nvalid[E]. */
+int dpvo_flow_mag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                  const int64_t* jj, const int64_t* kk, float beta, float* flow, float* valid, int64_t E, int P,
+                  void* stream);
+
+/* pops.point_cloud centre pixel (projective_ops.py:115-117, dpvo.py:358-360): points[m,3]. */
+int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                     float* points, int64_t m, int P, void* stream);
+
+/* lietorch_backends.{inv,mul,act4,expm,logm}(group_id=3, ...) -- lietorch.cpp:286-316, SE3 forward
+ * only (lietorch_gpu.cu:21-30,47-56,73-82,101-110,225-236; se3.h, so3.h).  f32, n elements. */
+int dpvo_se3_inv(const float* X, float* Y, int64_t n, void* stream);
+int dpvo_se3_mul(const float* X, const float* Y, float* Z, int64_t n, void* stream);
+int dpvo_se3_act4(const float* X, const float* p, float* q, int64_t n, void* stream);
+int dpvo_se3_exp(const float* a, float* X, int64_t n, void* stream);
+int dpvo_se3_log(const float* X, float* a, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * patch-graph plan  (replaces torch::_unique + fastba.neighbors host round trips)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Device-resident index structures of an edge list (ii,jj,kk), all int32, laid out in one
+ * caller-owned buffer of dpvo_plan_bytes(E) bytes.  Built entirely on the device (rocPRIM radix sort),
+ * no host synchronisation.  Offsets (in int32 elements) are returned by dpvo_plan_layout.
+ *   perm_k[E]     edge ids sorted by (kk, jj, edge id)           -- == per-patch stable_sort by jj (ba.cpp:80-82)
+ *   ku[E]         rank of kk[e] among the sorted unique kk      -- torch::_unique inverse (ba_cuda.cu:447-449)
+ *   kx[E]         sorted unique patch ids (first n_patches valid) -- torch::_unique values
+ *   patch_off[E+1] CSR offsets of perm_k per unique patch
+ *   ix[E], jx[E]  fastba.neighbors output (ba.cpp:59-97), -1 = none
+ *   perm_p[E]     edge ids sorted by (ii, jj, edge id)
+ *   pu[E]         rank of (ii,jj) among the sorted unique pairs  -- SoftAgg groups of agg_ij (net.py:88, blocks.py:41)
+ *   pair_off[E+1] CSR offsets of perm_p per unique pair
+ *   pair_ij[2E]   (i,j) of each unique pair
+ *   counts[4]     {n_patches, n_pairs, 0, 0}
+ */
+typedef struct dpvo_plan_layout_t {
+  int64_t perm_k, ku, kx, patch_off, ix, jx, perm_p, pu, pair_off, pair_ij, counts, total_ints;
+} dpvo_plan_layout_t;
+
+int dpvo_plan_layout(int64_t E, dpvo_plan_layout_t* layout);
+size_t dpvo_plan_workspace_bytes(int64_t E);
+int dpvo_plan_build(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* cuda_ba.neighbors(kk, jj) -- ba.cpp:59-97,187: int64 outputs for API parity (device resident). */
+size_t dpvo_neighbors_workspace_bytes(int64_t E);
+int dpvo_neighbors(const int64_t* kk, const int64_t* jj, int64_t* ix, int64_t* jx, int64_t E, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * update operator  (replaces Update.forward, dpvo/net.py:74-92, under autocast: dpvo.py:332)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* epilogue selectors of dpvo_linear */
+#define DPVO_EPI_NONE 0        /* out_f16 = h(acc + bias)                                     */
+#define DPVO_EPI_RELU 1        /* out_f16 = relu(h(acc + bias))                               */
+#define DPVO_EPI_SIGMOID 2     /* out_f16 = sigmoid(h(acc + bias))                            */
+#define DPVO_EPI_RESADD 3      /* res_f32[row] += float(h(acc + bias))  (residual into net)   */
+#define DPVO_EPI_GATED 4       /* res_f32[row] += float(h(gate[row] * h(acc + bias)))         */
+#define DPVO_EPI_RELU_SIG 5    /* columns < n_split: relu, else sigmoid (fused res.0 | gate.0) */
+
+/* nn.Linear under autocast: y = half(x_half @ W_half^T + b_half), f32 accumulate on MFMA
+ * (v_mfma_f32_16x16x32_f16).  A [M,K] f16 or f32 (converted to f16 on load, as autocast does) with
+ * leading dimension lda; optional row gather `rows` (int32, -1 -> zero row: the mask_ix * net[:,ix]
+ * of net.py:81-85); W [N,K] f16 row-major (torch Linear weight layout) with leading dimension ldw;
+ * bias [N] f16; out f16 [M,ldo] or the f32 residual target, see DPVO_EPI_*; K % 32 == 0, N % 16 == 0. */
+int dpvo_linear(const void* A, int a_dtype, int64_t lda, const int32_t* rows, const void* W, int64_t ldw,
+                const void* bias, void* out, int64_t ldo, const void* gate, int64_t ldg, int epilogue, int n_split,
+                int64_t M, int N, int K, void* stream);
+
+/* Fused "net = LayerNorm(net + inp[inp_rows] + corr)" (net.py:77-78) and plain LayerNorm (eps 1e-3):
+ *   x [M,384] f32 or f16 (x_dtype), optional add1 f16 [.,384] gathered by add1_rows (int64 indices
+ *   taken modulo add1_mod, the ctx = imap[:, kk % (M*pmem)] of dpvo.py:334), optional add2 f16 [M,384];
+ *   gamma/beta f32 [384]; y_f32 [M,384] (may alias x when x is f32) and/or y_f16 [M,384] (optionally
+ *   relu'd: the LN -> ReLU -> Linear of Update.corr, net.py:55-59). */
+int dpvo_layernorm(const void* x, int x_dtype, const void* add1, const int64_t* add1_rows, int64_t add1_mod,
+                   const void* add2, const float* gamma, const float* beta, float eps, float* y_f32, void* y_f16,
+                   int relu_f16, int64_t M, int D, void* stream);
+
+/* SoftAgg core (dpvo/blocks.py:31-48 with torch_scatter scatter_softmax / scatter_sum, pytorch-scatter
+ * 2.1.2): for every group g (CSR off/perm from the plan) and channel c
+ *   y[g,c] = sum_e softmax_e(gx[e,c]) * fx[e,c]       (f32 math, one rounding to f16)
+ * fg [E, 2*D] f16 holds f(x) in columns [0,D) and g(x) in [D,2D) (one fused GEMM). */
+int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, const int32_t* off, const int32_t* n_groups,
+                 int64_t max_groups, void* y, int D, void* stream);
+
+/* net[e] += float(hy[group[e]])  -- the `self.h(y)[:,jx]` expand + residual of net.py:87-88. */
+int dpvo_gather_add(float* net, const void* hy, const int32_t* group, int64_t E, int D, void* stream);
+
+/* Heads: delta = d(net), weight = sigmoid(w(net)) (net.py:61-71,92) as one row-dot kernel;
+ * Wd,Ww [2,D] f16, bd,bw [2] f16; outputs f32 [E,2] (the .float() of dpvo.py:339-340 folded in). */
+int dpvo_heads(const float* net, const void* Wd, const void* bd, const void* Ww, const void* bw, float* delta,
+               float* weight, int64_t E, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fastba  (replaces cuda_ba.forward: dpvo/fastba/ba.cpp:32-45,184 -> cuda_ba, ba_cuda.cu:433-582)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Gauss-Newton bundle adjustment over poses [t0,t1) and all patch inverse depths, `iterations`
+ * steps, IN PLACE on poses/patches exactly like the reference (ba_cuda.cu:570-577).
+ *   poses [NP,7], patches [NK,3,P,P], intrinsics [NP,4] (only row 0 is used, ba_cuda.cu:253-259),
+ *   target,weight [E,2] f32, lmbda scalar, ii,jj,kk [E] int64, plan from dpvo_plan_build(ii,jj,kk).
+ * Residual/Jacobian/mask semantics: ba_cuda.cu:232-376; damping S += I*(1e-4*S+1) :546,560; depth
+ * prior Q=1/(C+lmbda) :519; retractions :157-229.  Deterministic (no float atomics).
+ * info (device int32[iterations], may be NULL) receives the Cholesky status per iteration.
+ * Dense Schur path for 6*(t1-t0) <= DPVO_BA_MAX_DIM; larger systems return DPVO_E_UNSUPPORTED
+ * (global BA is routed by the host to the block-sparse path). */
+#define DPVO_BA_MAX_DIM 192
+size_t dpvo_ba_workspace_bytes(int64_t E, int n_free_poses);
+int dpvo_ba(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
+            float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, const int32_t* plan, int64_t E,
+            int P, int t0, int t1, int iterations, int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPVO_HIP_H */

@@ -1,0 +1,121 @@
+"""altcorr parity: HIP kernels (through the C ABI) vs the CPU oracle (float64 math on the same f16 inputs).
+
+Tolerance (stated, float): the kernels accumulate the 128-term dot products in f32 on MFMA and round the blended
+value ONCE to f16, so |err| <= 2^-11 |v| + f32 accumulation error; we assert atol 2e-3 + rtol 2e-3 (values are
+O(1)).  The reference itself accumulates in f16 (correlation_kernel.cu:121,130), i.e. is ~30x less accurate."""
+import numpy as np
+import pytest
+import torch
+
+from dpvo_amd import altcorr
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pyr(oracle, gmap, f0, f1, coords, us, vs):
+    return oracle.corr_pyramid(gmap.float().numpy(), [f0.float().numpy(), f1.float().numpy()], coords.numpy(),
+                               us.numpy(), vs.numpy(), radius=3, levels=(1, 4))
+
+
+@pytest.mark.parametrize("E,seed", [(1, 0), (7, 1), (300, 2)])
+def test_pyramid_vs_oracle(oracle, dev, E, seed):
+    gmap, f0, f1, coords, us, vs = H.corr_inputs(E, seed=seed)
+    ref = _oracle_pyr(oracle, gmap, f0, f1, coords, us, vs)
+    out = altcorr.corr_pyramid(H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev), coords.to(dev),
+                               us.to(dev), vs.to(dev))
+    assert out.shape == (E, 882) and out.stride(0) == 896
+    H.assert_close(out.float().cpu().numpy(), ref, 2e-3, 2e-3, "corr_pyramid")
+    # padding columns of the [E,896] buffer are zero (they feed the K-padded first Linear)
+    base = out._base if out._base is not None else out
+    assert (base.reshape(E, -1)[:, 882:] == 0).all()
+
+
+def test_pyramid_edge_cases(oracle, dev):
+    coords = H.special_coords()
+    E = coords.shape[0]
+    gmap, f0, f1, _, us, vs = H.corr_inputs(E, seed=5)
+    ref = _oracle_pyr(oracle, gmap, f0, f1, coords, us, vs)
+    out = altcorr.corr_pyramid(H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev), coords.to(dev),
+                               us.to(dev), vs.to(dev))
+    H.assert_close(out.float().cpu().numpy(), ref, 2e-3, 2e-3, "corr_pyramid edge cases")
+
+
+def test_pyramid_empty_and_order(oracle, dev):
+    gmap, f0, f1, coords, us, vs = H.corr_inputs(64, seed=9)
+    g, a, b = H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev)
+    out0 = altcorr.corr_pyramid(g, a, b, coords[:0].to(dev), us[:0].to(dev), vs[:0].to(dev))
+    assert out0.shape == (0, 882)
+    out = altcorr.corr_pyramid(g, a, b, coords.to(dev), us.to(dev), vs.to(dev))
+    order = torch.randperm(64).int().to(dev)
+    out2 = altcorr.corr_pyramid(g, a, b, coords.to(dev), us.to(dev), vs.to(dev), order=order)
+    assert torch.equal(out, out2)        # processing order is a locality hint only: bit-identical results
+
+
+@pytest.mark.parametrize("dtype,radius,P", [(torch.float16, 3, 3), (torch.float32, 3, 3), (torch.float16, 1, 1),
+                                            (torch.float32, 2, 3)])
+def test_generic_corr_vs_oracle(oracle, dev, dtype, radius, P):
+    E, C, Hh, W = 40, 24, 20, 28
+    g = torch.Generator().manual_seed(3)
+    f1 = (torch.randn(1, 16, C, P, P, generator=g) / 2).to(dtype)
+    f2 = (torch.randn(1, 5, C, Hh, W, generator=g) / 2).to(dtype)
+    from dpvo_amd import synthetic as S
+    coords = S.make_coords(E, P, Hh, W, seed=4, oob_frac=0.1)[None]
+    ii = torch.randint(0, 16, (E,), generator=g); jj = torch.randint(0, 5, (E,), generator=g)
+    ref = oracle.corr_forward(f1[0].float().numpy(), f2[0].float().numpy(), coords[0].numpy(), ii.numpy(), jj.numpy(), radius)
+    # NCHW (reference layout) and a permuted channels-last view must both work (stride-aware ABI)
+    for f2d in (f2.to(dev), f2.permute(0, 1, 3, 4, 2).contiguous().to(dev).permute(0, 1, 4, 2, 3)):
+        out = altcorr.corr(f1.to(dev), f2d, coords.to(dev), ii.to(dev), jj.to(dev), radius)
+        assert out.shape == (1, E, 2 * radius + 1, 2 * radius + 1, P, P) and out.dtype == dtype
+        tol = 2e-3 if dtype == torch.float16 else 2e-5
+        H.assert_close(out[0].float().cpu().numpy(), ref, tol, tol, f"corr generic {dtype}")
+
+
+def test_generic_matches_pyramid(dev):
+    """two independent HIP implementations (VALU strided vs MFMA channels-last) agree"""
+    gmap, f0, f1, coords, us, vs = H.corr_inputs(200, seed=11)
+    out = altcorr.corr_pyramid(H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev), coords.to(dev),
+                               us.to(dev), vs.to(dev))
+    c1 = altcorr.corr(gmap[None].to(dev), f0[None].to(dev), coords[None].to(dev), us.to(dev), vs.to(dev), 3)
+    c2 = altcorr.corr(gmap[None].to(dev), f1[None].to(dev), (coords / 4)[None].to(dev), us.to(dev), vs.to(dev), 3)
+    stacked = torch.stack([c1, c2], -1).reshape(200, -1)       # dpvo.py:207
+    H.assert_close(out.float().cpu().numpy(), stacked.float().cpu().numpy(), 2e-3, 2e-3, "generic vs pyramid")
+
+
+def test_patchify_vs_oracle(oracle, dev):
+    g = torch.Generator().manual_seed(6)
+    net = torch.randn(1, 12, 20, 30, generator=g)
+    coords = torch.stack([torch.rand(50, generator=g) * 34 - 2, torch.rand(50, generator=g) * 24 - 2], -1)[None]
+    for radius in (0, 1):
+        ref = oracle.patchify(net[0].numpy(), coords[0].numpy(), radius)
+        out = altcorr.patchify(net.to(dev), coords.to(dev), radius)
+        H.assert_close(out[0].cpu().numpy(), ref, 1e-5, 1e-5, "patchify")
+        outh = altcorr.patchify(net.half().to(dev), coords.to(dev), radius)
+        assert outh.shape == out.shape
+
+
+def test_full_size_properties(oracle, dev):
+    """BASELINE config 2 size (E = 45 312, 36x128x120x160 pyramid): size-independent properties + oracle sample."""
+    from dpvo_amd import synthetic as S
+    ii, jj, kk = S.replay_graph(40)
+    E = ii.numel()
+    assert E == 45312
+    gmap, f0, f1, _ = S.make_features()
+    coords = S.make_coords(E)
+    us = (kk % 3456); vs = (jj % 36)
+    g, a, b = H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev)
+    out = altcorr.corr_pyramid(g, a, b, coords.to(dev), us.to(dev), vs.to(dev))
+    assert torch.isfinite(out).all()
+    # (1) run-to-run determinism, (2) homogeneity: corr(2*gmap) == 2*corr(gmap) (power-of-two scaling is exact in f32/f16)
+    out_b = altcorr.corr_pyramid(g, a, b, coords.to(dev), us.to(dev), vs.to(dev))
+    assert torch.equal(out, out_b)
+    out2 = altcorr.corr_pyramid(g * 2, a, b, coords.to(dev), us.to(dev), vs.to(dev))
+    assert (out2.float() - out.float() * 2).abs().max().item() <= 2.0 ** -23     # exact except f16 subnormal ties
+    # (3) fully out-of-bounds edges give exact zeros
+    oob = (coords[:, 0, 1, 1] > 5000)
+    assert oob.sum() > 100 and (out[oob.to(dev)] == 0).all()
+    # (4) oracle on a seeded sample of 128 edges
+    idx = torch.randperm(E, generator=torch.Generator().manual_seed(0))[:128]
+    ref = oracle.corr_pyramid(gmap.float().numpy(), [f0.float().numpy(), f1.float().numpy()], coords[idx].numpy(),
+                              us[idx].numpy(), vs[idx].numpy())
+    H.assert_close(out[idx.to(dev)].float().cpu().numpy(), ref, 2e-3, 2e-3, "full-size sample")

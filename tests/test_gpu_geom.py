@@ -1,0 +1,109 @@
+"""SE3 / reprojection / plan parity vs the oracle (float64).  Tolerances: coordinates are O(100) px computed in
+f32 -> atol 2e-3 px; SE3 elements O(1) -> atol 2e-5; integer structures bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from dpvo_amd import fastba, lietorch, synthetic as S
+from dpvo_amd import projective_ops as pops
+from dpvo_amd.graph import GraphPlan
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_se3_ops(oracle, dev):
+    g = torch.Generator().manual_seed(0)
+    a = 0.3 * torch.randn(500, 6, generator=g)
+    a[0] = 0; a[1, 3:] = 1e-8; a[2, 3:] = torch.tensor([3.1, 0.0, 0.0])
+    X = lietorch.SE3.exp(a.to(dev))
+    H.assert_close(X.data.cpu().numpy(), oracle.se3_exp(a.numpy()), 2e-5, 2e-5, "exp")
+    H.assert_close(X.log().cpu().numpy(), oracle.se3_log(oracle.se3_exp(a.numpy())), 5e-5, 5e-5, "log")
+    Y = lietorch.SE3.exp(0.5 * torch.randn(500, 6, generator=g).to(dev))
+    H.assert_close(X.inv().data.cpu().numpy(), oracle.se3_inv(X.data.cpu().numpy()), 2e-5, 2e-5, "inv")
+    H.assert_close((X * Y).data.cpu().numpy(), oracle.se3_mul(X.data.cpu().numpy(), Y.data.cpu().numpy()), 2e-5, 2e-5, "mul")
+    p = torch.randn(500, 4, generator=g).to(dev)
+    H.assert_close((X * p).cpu().numpy(), oracle.se3_act4(X.data.cpu().numpy(), p.cpu().numpy()), 2e-5, 2e-5, "act4")
+    # lietorch's own identities (run_tests.py:16-28) in f32
+    H.assert_close(lietorch.SE3.exp(a.to(dev)).log().cpu().numpy()[3:], a.numpy()[3:], 2e-4, 2e-4, "log(exp(a)) == a")
+    I = (X * X.inv()).log()
+    assert I.abs().max().item() < 1e-5
+    # broadcasting + unnormalised quaternion input (SO3 constructor normalises, so3.h:35-37)
+    Z = lietorch.SE3(X.data[None, :3] * torch.tensor([1, 1, 1, 2, 2, 2, 2.0], device=dev))
+    pts = torch.randn(4, 1, 4, generator=g).to(dev)
+    out = Z * pts
+    assert out.shape == (4, 3, 4)
+    ref = oracle.se3_act4(np.broadcast_to(Z.data.cpu().numpy(), (4, 3, 7)).copy(), np.broadcast_to(pts.cpu().numpy(), (4, 3, 4)).copy())
+    H.assert_close(out.cpu().numpy(), ref, 2e-5, 2e-5, "broadcast act4")
+
+
+def test_reproject_flow_points(oracle, dev):
+    ii, jj, kk = S.replay_graph(40)
+    poses, patches, intr = S.make_scene(40)
+    sel = torch.randperm(ii.numel(), generator=torch.Generator().manual_seed(1))[:3000]
+    ii, jj, kk = ii[sel], jj[sel], kk[sel]
+    patches[5::7, 2] *= -1.0          # some points behind the camera -> exercises the Z clamp
+    co = pops.transform_coords(poses.to(dev), patches.to(dev), intr.to(dev), ii.to(dev), jj.to(dev), kk.to(dev))
+    ref = oracle.reproject(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy())
+    assert co.shape == (1, 3000, 2, 3, 3)
+    H.assert_close(co[0].cpu().numpy(), ref, 2e-3, 1e-5, "reproject")
+    x1 = pops.transform(lietorch.SE3(poses[None].to(dev)), patches[None].to(dev), intr[None].to(dev), ii.to(dev), jj.to(dev), kk.to(dev))
+    assert x1.shape == (1, 3000, 3, 3, 2) and torch.equal(x1.permute(0, 1, 4, 2, 3), co)
+    fl, val = pops.flow_mag(poses.to(dev), patches.to(dev), intr.to(dev), ii.to(dev), jj.to(dev), kk.to(dev), beta=0.5)
+    rf, rv = oracle.flow_mag(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy(), beta=0.5)
+    H.assert_close(fl.cpu().numpy(), rf.reshape(3000, -1).mean(1), 2e-3, 1e-4, "flow_mag")
+    assert np.array_equal(val.cpu().numpy(), rv.reshape(3000, -1).sum(1))
+    m = 40 * 96
+    ix = torch.arange(m) // 96
+    pts = pops.point_cloud(poses.to(dev), patches[:m].to(dev), intr.to(dev), ix.to(dev))
+    rp = oracle.point_cloud(poses.numpy(), patches[:m].numpy(), intr.numpy(), ix.numpy())
+    H.assert_close(pts.cpu().numpy(), rp, 1e-3, 1e-4, "point_cloud")
+    # exported-but-unused cuda_ba.reproject semantics (raw Z, intrinsics[0])
+    co2 = fastba.reproject(poses.to(dev), patches.to(dev), intr.to(dev), ii.to(dev), jj.to(dev), kk.to(dev))
+    ok = torch.from_numpy(ref[:, 0, 1, 1]).abs() < 1e4
+    front = (patches[kk, 2, 1, 1] > 0)
+    H.assert_close(co2[0].cpu().numpy()[(ok & front).numpy()], ref[(ok & front).numpy()], 5e-3, 1e-4, "cuda_ba.reproject")
+
+
+@pytest.mark.parametrize("case", ["replay40", "small", "shuffled", "single", "empty"])
+def test_plan_bit_exact(oracle, dev, case):
+    if case == "replay40":
+        ii, jj, kk = S.replay_graph(40)
+    elif case == "small":
+        ii, jj, kk, _ = H.small_graph()
+    elif case == "shuffled":
+        ii, jj, kk = S.replay_graph(30)
+        p = torch.randperm(ii.numel(), generator=torch.Generator().manual_seed(2))
+        ii, jj, kk = ii[p], jj[p], kk[p]
+        # duplicate edges (same patch, same frame) must keep edge order (stable sort, ba.cpp:80-82)
+        ii = torch.cat([ii, ii[:500]]); jj = torch.cat([jj, jj[:500]]); kk = torch.cat([kk, kk[:500]])
+    elif case == "single":
+        ii, jj, kk = torch.tensor([3]), torch.tensor([5]), torch.tensor([300])
+    else:
+        ii = jj = kk = torch.zeros(0, dtype=torch.long)
+    E = ii.numel()
+    plan = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev))
+    if E == 0:
+        assert plan.n_patches() == 0 and plan.n_pairs() == 0
+        return
+    ix, jx = oracle.neighbors(kk.numpy(), jj.numpy())
+    assert np.array_equal(plan.ix.cpu().numpy()[:E], ix) and np.array_equal(plan.jx.cpu().numpy()[:E], jx)
+    ix2, jx2 = fastba.neighbors(kk.to(dev), jj.to(dev))
+    assert ix2.dtype == torch.long and np.array_equal(ix2.cpu().numpy(), ix) and np.array_equal(jx2.cpu().numpy(), jx)
+    kx, ku = oracle.unique(kk.numpy())
+    assert plan.n_patches() == kx.size
+    assert np.array_equal(plan.kx.cpu().numpy()[:kx.size], kx) and np.array_equal(plan.ku.cpu().numpy()[:E], ku)
+    _, pu = np.unique((ii * 12345 + jj).numpy(), return_inverse=True)      # net.py:88 / blocks.py:41
+    assert np.array_equal(plan.pu.cpu().numpy()[:E], pu)
+    assert plan.n_pairs() == pu.max() + 1
+    # CSR consistency
+    perm_k = plan.perm_k.cpu().numpy()[:E]; off = plan.patch_off.cpu().numpy()[:kx.size + 1]
+    assert off[0] == 0 and off[-1] == E and sorted(perm_k.tolist()) == list(range(E))
+    for g in (0, kx.size // 2, kx.size - 1):
+        mem = perm_k[off[g]:off[g + 1]]
+        assert (kk.numpy()[mem] == kx[g]).all() and (np.diff(jj.numpy()[mem]) >= 0).all()
+    perm_p = plan.perm_p.cpu().numpy()[:E]; poff = plan.pair_off.cpu().numpy()[:plan.n_pairs() + 1]
+    pij = plan.pair_ij.cpu().numpy()[:2 * plan.n_pairs()].reshape(-1, 2)
+    for g in (0, plan.n_pairs() - 1):
+        mem = perm_p[poff[g]:poff[g + 1]]
+        assert (ii.numpy()[mem] == pij[g, 0]).all() and (jj.numpy()[mem] == pij[g, 1]).all()

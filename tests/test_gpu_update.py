@@ -1,0 +1,164 @@
+"""Update operator parity: HIP kernels vs oracle/update_ref.py (float64 math with the reference's autocast
+rounding points).  Stated tolerances: a Linear output is one f16 rounding of an O(1) value (2^-11 relative);
+through ~20 layers with LayerNorms the recurrent state `net` (|net| ~ 1..4) agrees to atol 2e-2 / rtol 1e-2 in
+the worst element and ~1e-3 in RMS; delta (pixels) atol 1e-2, weight atol 5e-3."""
+import numpy as np
+import pytest
+import torch
+
+from dpvo_amd import net as N
+from dpvo_amd.graph import GraphPlan
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _h64(x):
+    return x.half().double()
+
+
+@pytest.mark.parametrize("M,Nn,K,adt", [(300, 384, 384, torch.float16), (129, 768, 384, torch.float32),
+                                        (1000, 384, 896, torch.float16), (5, 16, 32, torch.float32)])
+def test_linear_epilogues(dev, M, Nn, K, adt):
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(M, K, generator=g).to(adt)
+    W = (torch.randn(Nn, K, generator=g) / K ** 0.5).half()
+    b = (0.1 * torch.randn(Nn, generator=g)).half()
+    ref = (_h64(A) @ W.double().t() + b.double()).half().double()
+    Ad, Wd, bd = A.to(dev), W.to(dev), b.to(dev)
+    out = N.linear(Ad, Wd, bd)
+    H.assert_close(out.cpu().double().numpy(), ref.numpy(), 2e-3, 2e-3, "linear none")
+    out = N.linear(Ad, Wd, bd, epilogue=N.EPI_RELU)
+    H.assert_close(out.cpu().double().numpy(), torch.relu(ref).numpy(), 2e-3, 2e-3, "linear relu")
+    out = N.linear(Ad, Wd, bd, epilogue=N.EPI_SIGMOID)
+    H.assert_close(out.cpu().double().numpy(), torch.sigmoid(ref).numpy(), 2e-3, 2e-3, "linear sigmoid")
+    if Nn >= 32:
+        out = N.linear(Ad, Wd, bd, epilogue=N.EPI_RELU_SIG, n_split=Nn // 2)
+        r2 = torch.cat([torch.relu(ref[:, :Nn // 2]), torch.sigmoid(ref[:, Nn // 2:])], 1)
+        H.assert_close(out.cpu().double().numpy(), r2.numpy(), 2e-3, 2e-3, "linear relu|sigmoid")
+    res = torch.randn(M, Nn, generator=g)
+    resd = res.clone().to(dev)
+    N.linear(Ad, Wd, bd, out=resd, epilogue=N.EPI_RESADD)
+    H.assert_close(resd.cpu().double().numpy(), (res.double() + ref).numpy(), 3e-3, 2e-3, "linear resadd")
+    gate = torch.rand(M, Nn, generator=g).half()
+    resd = res.clone().to(dev)
+    N.linear(Ad, Wd, bd, out=resd, epilogue=N.EPI_GATED, gate=gate.to(dev))
+    H.assert_close(resd.cpu().double().numpy(), (res.double() + (gate.double() * ref).half().double()).numpy(), 3e-3, 2e-3, "gated")
+    # row gather with -1 -> zero row
+    rows = torch.randint(-1, M, (M,), generator=g).int()
+    out = N.linear(Ad, Wd, bd, rows=rows.to(dev))
+    Ag = torch.where(rows[:, None] >= 0, _h64(A)[rows.long().clamp(min=0)], torch.zeros(1, dtype=torch.double))
+    refg = (Ag @ W.double().t() + b.double()).half().double()
+    H.assert_close(out.cpu().double().numpy(), refg.numpy(), 2e-3, 2e-3, "linear gather")
+
+
+def test_layernorm_softagg_heads(dev):
+    g = torch.Generator().manual_seed(1)
+    E = 777
+    x = torch.randn(E, 384, generator=g) * 2 + 0.3
+    gam = 1 + 0.1 * torch.randn(384, generator=g); bet = 0.1 * torch.randn(384, generator=g)
+    imap = torch.randn(50, 384, generator=g).half(); rows = torch.randint(0, 500, (E,), generator=g)
+    add2 = torch.randn(E, 384, generator=g).half()
+    v = x.double() + imap.double()[rows % 50] + add2.double()
+    mu = v.mean(-1, keepdim=True); var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    ref = (v - mu) / torch.sqrt(var + 1e-3) * gam.double() + bet.double()
+    y32 = torch.empty(E, 384, device=dev); y16 = torch.empty(E, 384, dtype=torch.float16, device=dev)
+    N.layernorm(x.to(dev), gam.to(dev), bet.to(dev), add1=imap.to(dev), add1_rows=rows.to(dev), add1_mod=50,
+                add2=add2.to(dev), y_f32=y32, y_f16=y16, relu_f16=True)
+    H.assert_close(y32.cpu().numpy(), ref.numpy(), 2e-5, 2e-5, "layernorm f32")
+    H.assert_close(y16.cpu().float().numpy(), torch.relu(ref).numpy(), 2e-3, 2e-3, "layernorm f16 relu")
+    # f16 input, in-place f32 not applicable; plain
+    xh = x.half()
+    N.layernorm(xh.to(dev), gam.to(dev), bet.to(dev), y_f32=y32)
+    v = xh.double(); mu = v.mean(-1, keepdim=True); var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    H.assert_close(y32.cpu().numpy(), ((v - mu) / torch.sqrt(var + 1e-3) * gam.double() + bet.double()).numpy(), 2e-5, 2e-5, "ln f16 in")
+
+    # softagg vs direct segmented softmax (f64)
+    ii, jj, kk, _ = H.small_graph()
+    Eg = ii.numel()
+    plan = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev))
+    fg = torch.randn(Eg, 768, generator=g).half()
+    fg[:, 384:] *= 3
+    y = N.softagg(fg.to(dev), plan.perm_k, plan.patch_off, plan.counts[0:1], plan.n_patches())
+    _, inv = np.unique(kk.numpy(), return_inverse=True)
+    inv = torch.from_numpy(inv)
+    ref = torch.zeros(plan.n_patches(), 384, dtype=torch.double)
+    for gi in range(plan.n_patches()):
+        m = inv == gi
+        w = torch.softmax(fg[m, 384:].double(), 0)
+        ref[gi] = (w * fg[m, :384].double()).sum(0)
+    H.assert_close(y.cpu().double().numpy(), ref.numpy(), 2e-3, 2e-3, "softagg")
+    net = torch.randn(Eg, 384, generator=g)
+    netd = net.clone().to(dev)
+    N.gather_add(netd, y, plan.ku)
+    H.assert_close(netd.cpu().numpy(), (net.double() + y.cpu().double()[inv]).numpy(), 1e-6, 1e-6, "gather_add")
+
+    Wd = (torch.randn(2, 384, generator=g) / 20).half(); bd = torch.randn(2, generator=g).half()
+    Ww = (torch.randn(2, 384, generator=g) / 20).half(); bw = torch.randn(2, generator=g).half()
+    d, w = N.heads(net.to(dev), Wd.to(dev), bd.to(dev), Ww.to(dev), bw.to(dev))
+    r = torch.relu(net).half().double()
+    rd = (r @ Wd.double().t() + bd.double()).half().double()
+    rw = torch.sigmoid((r @ Ww.double().t() + bw.double()).half().double()).half().double()
+    H.assert_close(d.cpu().numpy(), rd.numpy(), 2e-3, 2e-3, "head d")
+    H.assert_close(w.cpu().numpy(), rw.numpy(), 2e-3, 2e-3, "head w")
+
+
+@pytest.mark.parametrize("first_call", [True, False])
+def test_update_forward_vs_oracle(oracle, dev, first_call):
+    from oracle import update_ref
+    torch.manual_seed(1234)
+    upd = N.Update(3)
+    # make the LayerNorm affine / biases non-trivial so that every parameter is exercised
+    with torch.no_grad():
+        for p in upd.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    ii, jj, kk, cfg = H.small_graph()
+    E = ii.numel()
+    g = torch.Generator().manual_seed(7)
+    net = torch.zeros(E, 384) if first_call else torch.randn(E, 384, generator=g)
+    inp = torch.randn(E, 384, generator=g).half()
+    corr = torch.randn(E, 882, generator=g).half()
+    sd = {k: v for k, v in upd.state_dict().items()}
+    rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=True)
+    rn2, rd2, rw2 = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
+    upd = upd.to(dev)
+    out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
+    assert out.shape == (1, E, 384) and out.dtype == torch.float32 and d.shape == (1, E, 2) and w.shape == (1, E, 2)
+    for ref_n, ref_d, ref_w, tag in ((rn, rd, rw, "half-scatter"), (rn2, rd2, rw2, "exact-scatter")):
+        H.assert_close(out[0].cpu().numpy(), ref_n.numpy(), 2e-2, 1e-2, f"net ({tag})")
+        rms = float(((out[0].cpu().double() - ref_n) ** 2).mean().sqrt())
+        assert rms < 2e-3, rms
+        H.assert_close(d[0].cpu().numpy(), ref_d.numpy(), 1e-2, 1e-2, f"delta ({tag})")
+        H.assert_close(w[0].cpu().numpy(), ref_w.numpy(), 5e-3, 5e-3, f"weight ({tag})")
+    # fused inputs: un-gathered imap + row ids, zero-padded corr buffer (what DPVO.update passes)
+    imap = torch.randn(40, 384, generator=g).half()
+    rows = torch.randint(0, 4000, (E,), generator=g)
+    buf = torch.zeros(E, 896, dtype=torch.float16); buf[:, :882] = corr
+    bufd = buf.to(dev)
+    out2, (d2, w2, _) = upd(net[None].to(dev), imap[None].to(dev), bufd[:, :882][None], None, ii.to(dev), jj.to(dev),
+                            kk.to(dev), inp_rows=rows.to(dev), inp_mod=40, corr_is_padded=True)
+    out3, (d3, w3, _) = upd(net[None].to(dev), imap[rows % 40][None].to(dev), corr[None].to(dev), None, ii.to(dev),
+                            jj.to(dev), kk.to(dev))
+    assert torch.equal(out2, out3) and torch.equal(d2, d3) and torch.equal(w2, w3)
+
+
+def test_update_full_size_determinism(dev):
+    """E = 45 312 (BASELINE config 2): finite, deterministic, and invariant to edge permutation."""
+    from dpvo_amd import synthetic as S
+    torch.manual_seed(1234)
+    upd = N.Update(3).to(dev)
+    ii, jj, kk = S.replay_graph(40)
+    E = ii.numel()
+    g = torch.Generator().manual_seed(3)
+    net = torch.randn(E, 384, generator=g); inp = torch.randn(E, 384, generator=g).half()
+    corr = torch.randn(E, 882, generator=g).half()
+    a, (da, wa, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
+    b, (db, wb, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(da, db) and torch.equal(wa, wb)
+    p = torch.randperm(E, generator=g)
+    c, (dc, wc, _) = upd(net[p][None].to(dev), inp[p][None].to(dev), corr[p][None].to(dev), None, ii[p].to(dev),
+                         jj[p].to(dev), kk[p].to(dev))
+    # permutation equivariance (group sums change order -> f16-level differences only)
+    assert (c[0] - a[0][p.to(dev)]).abs().max().item() < 2e-2
+    assert (wc[0] - wa[0][p.to(dev)]).abs().max().item() < 5e-3
