@@ -37,7 +37,7 @@ def test_ba_vs_oracle(oracle, dev, case):
     else:
         ii, jj, kk = S.replay_graph(40)
         n, M = 40, 96
-    t0, t1 = {"small": (9, 14), "small_init": (1, 14), "full": (30, 40), "structure_only": (3, 3),
+    t0, t1 = {"small": (9, 14), "small_init": (1, 14), "full": (30, 40), "structure_only": (14, 14),
               "all_fixed_sources": (13, 14)}[case]
     poses, patches, intr, target, weight = _problem(ii, jj, kk, n, M, oracle)
     if case == "small":
