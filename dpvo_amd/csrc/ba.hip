@@ -4,35 +4,30 @@
 // kernel with ~340 float atomics per edge onto a 60x60 tile (:232-376), ~25 ATen launches + cuSOLVER
 // potrf/potrs per iteration (:519-565) and the two retraction kernels (:178-229).
 //
-// MI355X design -- four launches per Gauss-Newton iteration, no float atomics, bit-reproducible:
-//   1. ba_pair_kernel   one wave per (i,j) frame pair (CSR from the plan; ~96 edges): per-edge residuals and
-//                       Jacobians, DPP/shuffle wave reduction of the pair's Hii / Hjj / Hij / vi / vj blocks
-//                       -> pairbuf[g][96]; per-edge depth terms (c, u, Ei[6], Ej[6]) -> edgebuf[e][16].
-//   2. ba_patch_kernel  fixed grid, a block owns chunks of 32 patches (CSR by patch): builds the Schur
-//                       column e_k (6N) of each patch in LDS, stores Q, u, e_k, and accumulates the block's
-//                       partial  sum_k Q_k e_k e_k^T  and  sum_k Q_k u_k e_k  in registers -> spart[block].
-//   3. ba_solve_kernel  one workgroup: assembles B and v from pairbuf in a fixed order, subtracts the Schur
-//                       partials, applies the reference's damping S += I*(1e-4*S + 1), Cholesky-factorises
-//                       the <=120x120 system in LDS, solves, writes dX and retracts the poses (Exp(dX)*T).
-//   4. ba_retr_kernel   dZ_k = Q_k (u_k - e_k . dX), depth retraction with the reference's clamps.
+// MI355X design -- five short launches per Gauss-Newton iteration, no float atomics, bit-reproducible:
+//   1. ba_pair_kernel     two waves per (i,j) frame pair (CSR from the plan; ~96 edges): per-edge residuals and
+//                         Jacobians; the pair's 13x13 Gram block  sum_rows w [Ji Jj r]^T [Ji Jj r]  (= Hii, Hij, Hjj,
+//                         vi, vj) is reduced on the matrix core with v_mfma_f32_16x16x4_f32 (exact f32 fma chain)
+//                         from an LDS row image -> pairbuf[g][16x16]; per-edge depth terms (c, u, Ei, Ej) -> edgebuf.
+//   2. ba_patch_kernel    a block owns 32 patches (CSR by patch), 8 lanes gather one patch's edges: builds the Schur
+//                         column e_k (6N) in LDS, stores Q, u, e_k, and the block's partial  sum_k Q_k e_k e_k^T,
+//                         sum_k Q_k u_k e_k  -> spart[block].
+//   3. ba_assemble_kernel one thread per entry of S / y: B, v from pairbuf in a fixed order, minus the Schur
+//                         partials, plus the reference's damping S += I*(1e-4*S + 1)  -> Sg, yg.
+//   4. ba_solve_kernel    one workgroup: left-looking Cholesky of the <=120x120 system in LDS (one barrier per
+//                         column), column-oriented triangular solves -> dX.
+//   5. ba_retr_kernel     dZ_k = Q_k (u_k - e_k . dX), depth retraction with the reference's clamps; pose
+//                         retraction Exp(dX)*T.
 #include "common.h"
 
 namespace {
 
 constexpr int kMaxN = 20;            // free poses on the dense path
 constexpr int kMaxDim = 6 * kMaxN;   // 120
-constexpr int kPairStride = 96;      // 36 Hii + 36 Hjj(unused upper dup) ... see layout below
-constexpr int kEdgeStride = 16;
+constexpr int kPairStride = 256;     // 16x16 Gram block G = sum_rows w a a^T, a = [Ji(6) Jj(6) r 0 0 0]
+constexpr int kEdgeStride = 16;      // c, u, Ei[6], Ej[6], pad
 constexpr int kPatchChunk = 32;
-constexpr int kPatchBlocks = 64;     // fixed grid of the patch kernel (deterministic partial count)
-
-// pairbuf layout per pair: [0,21) Hii upper-tri, [21,42) Hjj upper-tri, [42,78) Hij full 6x6 (row = i-side),
-// [78,84) vi, [84,90) vj
-constexpr int kHii = 0, kHjj = 21, kHij = 42, kVi = 78, kVj = 84;
-
-__device__ __forceinline__ int tri(int a, int b) {   // a <= b < 6
-  return a * 6 - (a * (a - 1)) / 2 + (b - a);
-}
+constexpr int kSEntries = kMaxDim * kMaxDim + kMaxDim;
 
 // ---- device math of ba_cuda.cu:36-174 (no quaternion normalisation, same operation order) ----
 __device__ __forceinline__ void actSO3(const float* q, const float* X, float* Y) {
@@ -111,15 +106,18 @@ __device__ __forceinline__ void retrSE3(const float* xi, const float* t, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 1. per-pair kernel: one wave per frame pair
+// 1. per-pair kernel: 128 threads (2 waves) per frame pair
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ba_pair_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
-                                                     const float* __restrict__ intr, const float* __restrict__ target,
-                                                     const float* __restrict__ weight, const int64_t* __restrict__ kk,
-                                                     const int32_t* __restrict__ perm_p, const int32_t* __restrict__ pair_off,
-                                                     const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
-                                                     float* __restrict__ pairbuf, float* __restrict__ edgebuf, int P) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(128) void ba_pair_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                      const float* __restrict__ intr, const float* __restrict__ target,
+                                                      const float* __restrict__ weight, const int64_t* __restrict__ kk,
+                                                      const int32_t* __restrict__ perm_p, const int32_t* __restrict__ pair_off,
+                                                      const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
+                                                      float* __restrict__ pairbuf, float* __restrict__ edgebuf, int P) {
+  __shared__ float Arow[2][128][17];     // per wave: 128 residual rows x 16 columns (+1 pad)
+  __shared__ float Wrow[2][128];
+  __shared__ float comb[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ng = *n_pairs;
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];     // intrinsics[0] (ba_cuda.cu:253-259)
   const int PP = P * P, ctr = (P / 2) * P + P / 2;
@@ -131,81 +129,114 @@ __global__ __launch_bounds__(64) void ba_pair_kernel(const float* __restrict__ p
     float tij[3], qij[4];
     relSE3(ti, qi, tj, qj, tij, qij);
 
-    float acc[90];
-#pragma unroll
-    for (int a = 0; a < 90; ++a) acc[a] = 0.f;
-
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
     const int b0 = pair_off[g], b1 = pair_off[g + 1];
-    for (int p = b0 + lane; p < b1; p += 64) {
-      const int e = perm_p[p];
-      const float* pk = patches + kk[e] * 3 * PP;
-      float Xi[4], Xj[4];
-      Xi[0] = (pk[ctr] - cx) / fx;
-      Xi[1] = (pk[PP + ctr] - cy) / fy;
-      Xi[2] = 1.0f;
-      Xi[3] = pk[2 * PP + ctr];
-      actSO3(qij, Xi, Xj);
-      Xj[3] = Xi[3];
-      Xj[0] += Xi[3] * tij[0]; Xj[1] += Xi[3] * tij[1]; Xj[2] += Xi[3] * tij[2];
-      const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
-      const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
-      const float d2 = d * d;
-      const float x1 = fx * (X / Z) + cx;
-      const float y1 = fy * (Y / Z) + cy;
-      const float rx = target[2 * (int64_t)e + 0] - x1;
-      const float ry = target[2 * (int64_t)e + 1] - y1;
-      const bool in_bounds = (sqrtf(rx * rx + ry * ry) < 128.0f) && (Z > 0.2f) && (x1 > -64.0f) && (y1 > -64.0f) &&
-                             (x1 < 2 * cx + 64.0f) && (y1 < 2 * cy + 64.0f);
-      const float mask = in_bounds ? 1.0f : 0.0f;
-      float ce = 0.f, ue = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Ej[6] = {0, 0, 0, 0, 0, 0};
+    for (int c0 = b0 + wave * 64; c0 < b1; c0 += 128) {
+      const int p = c0 + lane;
+      float rowv[2][13];
+      float wv[2] = {0.f, 0.f};
 #pragma unroll
-      for (int row = 0; row < 2; ++row) {
-        float Jj[6], Ji[6], Jz, r, w;
-        if (row == 0) {
-          r = rx; w = mask * weight[2 * (int64_t)e + 0];
-          Jz = fx * (tij[0] * d - tij[2] * (X * d2));
-          Jj[0] = fx * W * d; Jj[1] = 0.f; Jj[2] = fx * -X * W * d2;
-          Jj[3] = fx * -X * Y * d2; Jj[4] = fx * (1 + X * X * d2); Jj[5] = fx * -Y * d;
-        } else {
-          r = ry; w = mask * weight[2 * (int64_t)e + 1];
-          Jz = fy * (tij[1] * d - tij[2] * (Y * d2));
-          Jj[0] = 0.f; Jj[1] = fy * W * d; Jj[2] = fy * -Y * W * d2;
-          Jj[3] = fy * (-1 - Y * Y * d2); Jj[4] = fy * (X * Y * d2); Jj[5] = fy * X * d;
-        }
-        adjSE3(tij, qij, Jj, Ji);
+      for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
+        for (int a = 0; a < 13; ++a) rowv[r2][a] = 0.f;
+      if (p < b1) {
+        const int e = perm_p[p];
+        const float* pk = patches + kk[e] * 3 * PP;
+        float Xi[4], Xj[4];
+        Xi[0] = (pk[ctr] - cx) / fx;
+        Xi[1] = (pk[PP + ctr] - cy) / fy;
+        Xi[2] = 1.0f;
+        Xi[3] = pk[2 * PP + ctr];
+        actSO3(qij, Xi, Xj);
+        Xj[3] = Xi[3];
+        Xj[0] += Xi[3] * tij[0]; Xj[1] += Xi[3] * tij[1]; Xj[2] += Xi[3] * tij[2];
+        const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
+        const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
+        const float d2 = d * d;
+        const float x1 = fx * (X / Z) + cx;
+        const float y1 = fy * (Y / Z) + cy;
+        const float rx = target[2 * (int64_t)e + 0] - x1;
+        const float ry = target[2 * (int64_t)e + 1] - y1;
+        const bool in_bounds = (sqrtf(rx * rx + ry * ry) < 128.0f) && (Z > 0.2f) && (x1 > -64.0f) && (y1 > -64.0f) &&
+                               (x1 < 2 * cx + 64.0f) && (y1 < 2 * cy + 64.0f);
+        const float mask = in_bounds ? 1.0f : 0.0f;
+        float ce = 0.f, ue = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0}, Ej[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-          for (int b = a; b < 6; ++b) {
-            acc[kHii + tri(a, b)] += w * Ji[a] * Ji[b];
-            acc[kHjj + tri(a, b)] += w * Jj[a] * Jj[b];
+        for (int row = 0; row < 2; ++row) {
+          float Jj[6], Ji[6], Jz, r, w;
+          if (row == 0) {
+            r = rx; w = mask * weight[2 * (int64_t)e + 0];
+            Jz = fx * (tij[0] * d - tij[2] * (X * d2));
+            Jj[0] = fx * W * d; Jj[1] = 0.f; Jj[2] = fx * -X * W * d2;
+            Jj[3] = fx * -X * Y * d2; Jj[4] = fx * (1 + X * X * d2); Jj[5] = fx * -Y * d;
+          } else {
+            r = ry; w = mask * weight[2 * (int64_t)e + 1];
+            Jz = fy * (tij[1] * d - tij[2] * (Y * d2));
+            Jj[0] = 0.f; Jj[1] = fy * W * d; Jj[2] = fy * -Y * W * d2;
+            Jj[3] = fy * (-1 - Y * Y * d2); Jj[4] = fy * (X * Y * d2); Jj[5] = fy * X * d;
           }
+          adjSE3(tij, qij, Jj, Ji);
+          // a non-finite residual row with zero weight must not poison the Gram block (0 * inf = NaN)
+          const bool live = (w != 0.f);
 #pragma unroll
-          for (int b = 0; b < 6; ++b) acc[kHij + a * 6 + b] += w * Ji[a] * Jj[b];
-          acc[kVi + a] += w * r * Ji[a];
-          acc[kVj + a] += w * r * Jj[a];
-          Ei[a] += -w * Jz * Ji[a];
-          Ej[a] += w * Jz * Jj[a];
+          for (int a = 0; a < 6; ++a) {
+            rowv[row][a] = live ? Ji[a] : 0.f;
+            rowv[row][6 + a] = live ? Jj[a] : 0.f;
+            Ei[a] += live ? -w * Jz * Ji[a] : 0.f;
+            Ej[a] += live ? w * Jz * Jj[a] : 0.f;
+          }
+          rowv[row][12] = live ? r : 0.f;
+          wv[row] = w;
+          ce += live ? w * Jz * Jz : 0.f;
+          ue += live ? w * r * Jz : 0.f;
         }
-        ce += w * Jz * Jz;
-        ue += w * r * Jz;
+        float* eb = edgebuf + (int64_t)e * kEdgeStride;
+        eb[0] = ce; eb[1] = ue;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { eb[2 + a] = Ei[a]; eb[8 + a] = Ej[a]; }
       }
-      float* eb = edgebuf + (int64_t)e * kEdgeStride;
-      eb[0] = ce; eb[1] = ue;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) { eb[2 + a] = Ei[a]; eb[8 + a] = Ej[a]; }
-    }
-    float* pb = pairbuf + (int64_t)g * kPairStride;
+      for (int r2 = 0; r2 < 2; ++r2) {
 #pragma unroll
-    for (int a = 0; a < 90; ++a) {
-      const float s = wave_sum(acc[a]);
-      if (lane == 0) pb[a] = s;
+        for (int a = 0; a < 13; ++a) Arow[wave][2 * lane + r2][a] = rowv[r2][a];
+#pragma unroll
+        for (int a = 13; a < 16; ++a) Arow[wave][2 * lane + r2][a] = 0.f;
+        Wrow[wave][2 * lane + r2] = wv[r2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // G += (w a)^T a over the wave's 128 rows, 4 rows per MFMA: A operand lane l = A[i=l&15][k=l>>4]
+      const int cidx = lane & 15, ksub = lane >> 4;
+#pragma unroll 8
+      for (int t = 0; t < 32; ++t) {
+        const int k = 4 * t + ksub;
+        const float a = Arow[wave][k][cidx];
+        const float w = Wrow[wave][k];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w * a, a, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+    // combine the two waves in a fixed order, store G[16][16]: lane holds G[4*(l>>4)+r][l&15]
+    if (wave == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) comb[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float* pb = pairbuf + (int64_t)g * kPairStride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = (4 * (lane >> 4) + r) * 16 + (lane & 15);
+        pb[idx] = acc[r] + comb[idx];
+      }
+    }
+    __syncthreads();
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 2. per-patch kernel: Schur columns + partial Schur products
+// 2. per-patch kernel: Schur columns + partial Schur products; block = 32 patches x 8 lanes
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
                                                        const int32_t* __restrict__ perm_k,
@@ -220,74 +251,80 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
   const int np = *n_patches;
   const int tid = threadIdx.x;
   const int nent = n6 * n6 + n6;                       // S entries followed by y entries
-  constexpr int kPer = (kMaxDim * kMaxDim + kMaxDim + 255) / 256;   // 57
-  float part[kPer];
-#pragma unroll
-  for (int a = 0; a < kPer; ++a) part[a] = 0.f;
-
-  const int nchunks = (np + kPatchChunk - 1) / kPatchChunk;
-  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    for (int a = tid; a < kPatchChunk * (kMaxDim + 1); a += 256) (&col[0][0])[a] = 0.f;
-    __syncthreads();
-    if (tid < kPatchChunk) {
-      const int k = ch * kPatchChunk + tid;
-      float C = 0.f, u = 0.f;
-      if (k < np) {
-        const int b0 = patch_off[k], b1 = patch_off[k + 1];
-        for (int p = b0; p < b1; ++p) {
-          const int e = perm_k[p];
-          const float* eb = edgebuf + (int64_t)e * kEdgeStride;
-          C += eb[0]; u += eb[1];
-          const int ix = (int)ii[e] - t0, jx = (int)jj[e] - t0;
-          if (ix >= 0 && ix < N)
-#pragma unroll
-            for (int a = 0; a < 6; ++a) col[tid][6 * ix + a] += eb[2 + a];
-          if (jx >= 0 && jx < N)
-#pragma unroll
-            for (int a = 0; a < 6; ++a) col[tid][6 * jx + a] += eb[8 + a];
+  const int ch = blockIdx.x;
+  for (int a = tid; a < kPatchChunk * (kMaxDim + 1); a += 256) (&col[0][0])[a] = 0.f;
+  __syncthreads();
+  {
+    const int pl = tid >> 3, sub = tid & 7;
+    const int k = ch * kPatchChunk + pl;
+    float C = 0.f, u = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0};
+    int ix = -1;
+    if (k < np) {
+      const int b0 = patch_off[k], b1 = patch_off[k + 1];
+      for (int p = b0 + sub; p < b1; p += 8) {
+        const int e = perm_k[p];
+        const f4* eb = reinterpret_cast<const f4*>(edgebuf + (int64_t)e * kEdgeStride);
+        const f4 v0 = eb[0], v1 = eb[1], v2 = eb[2], v3 = eb[3];
+        C += v0[0]; u += v0[1];
+        Ei[0] += v0[2]; Ei[1] += v0[3]; Ei[2] += v1[0]; Ei[3] += v1[1]; Ei[4] += v1[2]; Ei[5] += v1[3];
+        ix = (int)ii[e] - t0;
+        const int jx = (int)jj[e] - t0;
+        if (jx >= 0 && jx < N) {
+          // distinct (patch, j) edges own distinct slots; duplicates (if any) are folded by the LDS add
+          atomicAdd(&col[pl][6 * jx + 0], v2[0]); atomicAdd(&col[pl][6 * jx + 1], v2[1]);
+          atomicAdd(&col[pl][6 * jx + 2], v2[2]); atomicAdd(&col[pl][6 * jx + 3], v2[3]);
+          atomicAdd(&col[pl][6 * jx + 4], v3[0]); atomicAdd(&col[pl][6 * jx + 5], v3[1]);
         }
+      }
+    }
+    // fixed-order butterfly over the 8 lanes of a patch
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      C += __shfl_xor(C, o); u += __shfl_xor(u, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) Ei[a] += __shfl_xor(Ei[a], o);
+      ix = max(ix, __shfl_xor(ix, o));
+    }
+    __syncthreads();      // all Ej adds of this block are done before the i-side is merged
+    if (sub == 0) {
+      if (k < np) {
+        if (ix >= 0 && ix < N)
+#pragma unroll
+          for (int a = 0; a < 6; ++a) col[pl][6 * ix + a] += Ei[a];
         const float Q = 1.0f / (C + lmbda);               // ba_cuda.cu:519
-        qv[tid] = Q; uv[tid] = u;
+        qv[pl] = Q; uv[pl] = u;
         Qbuf[k] = Q; ubuf[k] = u;
       } else {
-        qv[tid] = 0.f; uv[tid] = 0.f;
+        qv[pl] = 0.f; uv[pl] = 0.f;
       }
     }
-    __syncthreads();
-    // store the columns (patch-major) for the dZ back-substitution
-    for (int a = tid; a < kPatchChunk * n6; a += 256) {
-      const int pl = a / n6, r = a - pl * n6;
-      const int k = ch * kPatchChunk + pl;
-      if (k < np) Ecol[(int64_t)k * n6 + r] = col[pl][r];
-    }
-    // partial S and y
-#pragma unroll
-    for (int s = 0; s < kPer; ++s) {
-      const int ent = tid + 256 * s;
-      if (ent < nent) {
-        float sum = 0.f;
-        if (ent < n6 * n6) {
-          const int a = ent / n6, b = ent - a * n6;
-          for (int pl = 0; pl < kPatchChunk; ++pl) sum += qv[pl] * col[pl][a] * col[pl][b];
-        } else {
-          const int a = ent - n6 * n6;
-          for (int pl = 0; pl < kPatchChunk; ++pl) sum += qv[pl] * uv[pl] * col[pl][a];
-        }
-        part[s] += sum;
-      }
-    }
-    __syncthreads();
   }
-  float* sp = spart + (int64_t)blockIdx.x * (kMaxDim * kMaxDim + kMaxDim);
-#pragma unroll
-  for (int s = 0; s < kPer; ++s) {
-    const int ent = tid + 256 * s;
-    if (ent < nent) sp[ent] = part[s];
+  __syncthreads();
+  // store the columns (patch-major) for the dZ back-substitution
+  for (int a = tid; a < kPatchChunk * n6; a += 256) {
+    const int pl = a / n6, r = a - pl * n6;
+    const int k = ch * kPatchChunk + pl;
+    if (k < np) Ecol[(int64_t)k * n6 + r] = col[pl][r];
+  }
+  // partial S and y of this block
+  float* sp = spart + (int64_t)blockIdx.x * kSEntries;
+  for (int ent = tid; ent < nent; ent += 256) {
+    float sum = 0.f;
+    if (ent < n6 * n6) {
+      const int a = ent / n6, b = ent - a * n6;
+#pragma unroll 8
+      for (int pl = 0; pl < kPatchChunk; ++pl) sum += qv[pl] * col[pl][a] * col[pl][b];
+    } else {
+      const int a = ent - n6 * n6;
+#pragma unroll 8
+      for (int pl = 0; pl < kPatchChunk; ++pl) sum += qv[pl] * uv[pl] * col[pl][a];
+    }
+    sp[ent] = sum;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3. solve kernel: one workgroup
+// 3. assemble kernel: one thread per entry of S (n6 x n6) and y (n6)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int find_pair(const int32_t* pair_ij, int ng, int i, int j) {
   int lo = 0, hi = ng - 1;
@@ -300,127 +337,121 @@ __device__ __forceinline__ int find_pair(const int32_t* pair_ij, int ng, int i, 
   return -1;
 }
 
-__global__ __launch_bounds__(512) void ba_solve_kernel(float* __restrict__ poses, const int32_t* __restrict__ pair_ij,
-                                                       const int32_t* __restrict__ n_pairs, const float* __restrict__ pairbuf,
-                                                       const float* __restrict__ spart, int n_spart, int t0, int N,
-                                                       float* __restrict__ dX, int32_t* __restrict__ info) {
-  __shared__ float S[kMaxDim * (kMaxDim + 1)];
-  __shared__ float y[kMaxDim];
-  __shared__ int bad;
-  const int n6 = 6 * N, ld = kMaxDim + 1;
+__global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restrict__ pair_ij,
+                                                          const int32_t* __restrict__ n_pairs,
+                                                          const float* __restrict__ pairbuf,
+                                                          const float* __restrict__ spart, int n_spart, int t0, int N,
+                                                          float* __restrict__ Sg, float* __restrict__ yg) {
+  const int n6 = 6 * N;
   const int ng = *n_pairs;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  if (tid == 0) bad = 0;
-
-  // ---- assemble B (into S) and v (into y) from the pair blocks, fixed summation order
-  for (int ent = tid; ent < N * N * 36; ent += nt) {
-    const int blk = ent / 36, r = ent - blk * 36;
-    const int p = blk / N, q = blk - p * N;
-    const int a = r / 6, b = r - a * 6;
-    float s = 0.f;
+  const int ent = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ent >= n6 * n6 + n6) return;
+  float s = 0.f;
+  if (ent < n6 * n6) {
+    const int ra = ent / n6, rb = ent - ra * n6;
+    const int p = ra / 6, a = ra - 6 * p, q = rb / 6, b = rb - 6 * q;
     if (p == q) {
       const int f = t0 + p;
-      const int ta = a <= b ? tri(a, b) : tri(b, a);
       for (int g = 0; g < ng; ++g) {
         const int gi = pair_ij[2 * g], gj = pair_ij[2 * g + 1];
         const float* pb = pairbuf + (int64_t)g * kPairStride;
-        if (gi == f) s += pb[kHii + ta];
-        if (gj == f) s += pb[kHjj + ta];
-        if (gi == f && gj == f) s += -pb[kHij + a * 6 + b] - pb[kHij + b * 6 + a];
+        if (gi == f) s += pb[a * 16 + b];                          // w Ji Ji^T      (ba_cuda.cu:338-339)
+        if (gj == f) s += pb[(6 + a) * 16 + 6 + b];                // w Jj Jj^T      (:340-341)
+        if (gi == f && gj == f) s += -pb[a * 16 + 6 + b] - pb[b * 16 + 6 + a];   // self edge: both cross terms
       }
     } else {
-      const int g1 = find_pair(pair_ij, ng, t0 + p, t0 + q);     // i = p, j = q: block (ix,jx) gets -Ji Jj^T
-      const int g2 = find_pair(pair_ij, ng, t0 + q, t0 + p);     // i = q, j = p: block (jx,ix) gets -Jj Ji^T
-      if (g1 >= 0) s += -pairbuf[(int64_t)g1 * kPairStride + kHij + a * 6 + b];
-      if (g2 >= 0) s += -pairbuf[(int64_t)g2 * kPairStride + kHij + b * 6 + a];
+      const int g1 = find_pair(pair_ij, ng, t0 + p, t0 + q);     // i = p, j = q: block (ix,jx) gets -w Ji Jj^T
+      const int g2 = find_pair(pair_ij, ng, t0 + q, t0 + p);     // i = q, j = p: block (jx,ix) gets -w Jj Ji^T
+      if (g1 >= 0) s += -pairbuf[(int64_t)g1 * kPairStride + a * 16 + 6 + b];
+      if (g2 >= 0) s += -pairbuf[(int64_t)g2 * kPairStride + b * 16 + 6 + a];
     }
-    S[(6 * p + a) * ld + 6 * q + b] = s;
-  }
-  for (int ent = tid; ent < n6; ent += nt) {
-    const int p = ent / 6, a = ent - p * 6;
+  } else {
+    const int ra = ent - n6 * n6;
+    const int p = ra / 6, a = ra - 6 * p;
     const int f = t0 + p;
-    float s = 0.f;
     for (int g = 0; g < ng; ++g) {
       const int gi = pair_ij[2 * g], gj = pair_ij[2 * g + 1];
       const float* pb = pairbuf + (int64_t)g * kPairStride;
-      if (gi == f) s += -pb[kVi + a];
-      if (gj == f) s += pb[kVj + a];
-    }
-    y[ent] = s;
-  }
-  __syncthreads();
-  // ---- Schur complement: S = B - sum_k Q e e^T, y = v - sum_k Q u e   (ba_cuda.cu:557-558)
-  const int pstride = kMaxDim * kMaxDim + kMaxDim;
-  for (int ent = tid; ent < n6 * n6 + n6; ent += nt) {
-    float s = 0.f;
-    for (int b = 0; b < n_spart; ++b) s += spart[(int64_t)b * pstride + ent];
-    if (ent < n6 * n6) { const int a = ent / n6, c = ent - a * n6; S[a * ld + c] -= s; }
-    else y[ent - n6 * n6] -= s;
-  }
-  __syncthreads();
-  // ---- damping  S += I * (1e-4 * S + 1.0)   (:560)
-  for (int a = tid; a < n6; a += nt) S[a * ld + a] += 1e-4f * S[a * ld + a] + 1.0f;
-  __syncthreads();
-  // ---- in-place lower Cholesky (right-looking), info like linalg_cholesky_ex (ignored by the reference)
-  for (int j = 0; j < n6; ++j) {
-    if (tid == 0) {
-      const float d = S[j * ld + j];
-      if (!(d > 0.f) && bad == 0) bad = j + 1;
-      S[j * ld + j] = sqrtf(d);
-    }
-    __syncthreads();
-    const float djj = S[j * ld + j];
-    for (int i2 = j + 1 + tid; i2 < n6; i2 += nt) S[i2 * ld + j] /= djj;
-    __syncthreads();
-    const int rem = n6 - j - 1;
-    for (int ent = tid; ent < rem * rem; ent += nt) {
-      const int r = j + 1 + ent / rem, c = j + 1 + ent % rem;
-      if (c <= r) S[r * ld + c] -= S[r * ld + j] * S[c * ld + j];
-    }
-    __syncthreads();
-  }
-  // ---- forward / backward substitution (single wave; n6 <= 120)
-  if (tid < 64) {
-    volatile float* yv = y;
-    for (int i2 = 0; i2 < n6; ++i2) {
-      float s = 0.f;
-      for (int k = tid; k < i2; k += 64) s += S[i2 * ld + k] * yv[k];
-      s = wave_sum(s);
-      if (tid == 0) yv[i2] = (yv[i2] - s) / S[i2 * ld + i2];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    }
-    for (int i2 = n6 - 1; i2 >= 0; --i2) {
-      float s = 0.f;
-      for (int k = i2 + 1 + tid; k < n6; k += 64) s += S[k * ld + i2] * yv[k];
-      s = wave_sum(s);
-      if (tid == 0) yv[i2] = (yv[i2] - s) / S[i2 * ld + i2];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (gi == f) s += -pb[a * 16 + 12];                          // v[i] -= w r Ji     (:364-365)
+      if (gj == f) s += pb[(6 + a) * 16 + 12];                     // v[j] += w r Jj     (:366-367)
     }
   }
-  __syncthreads();
-  for (int a = tid; a < n6; a += nt) dX[a] = y[a];
-  if (tid == 0 && info) *info = bad;
-  // ---- pose retraction (pose_retr_kernel, :178-206)
-  if (tid < N) {
-    float* p = poses + 7 * (int64_t)(t0 + tid);
-    const float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]};
-    const float xi[6] = {y[6 * tid], y[6 * tid + 1], y[6 * tid + 2], y[6 * tid + 3], y[6 * tid + 4], y[6 * tid + 5]};
-    float t1v[3], q1v[4];
-    retrSE3(xi, tt, qq, t1v, q1v);
-    p[0] = t1v[0]; p[1] = t1v[1]; p[2] = t1v[2]; p[3] = q1v[0]; p[4] = q1v[1]; p[5] = q1v[2]; p[6] = q1v[3];
+  // Schur complement: S = B - sum_k Q e e^T, y = v - sum_k Q u e   (ba_cuda.cu:557-558)
+  float sc = 0.f;
+  for (int b = 0; b < n_spart; ++b) sc += spart[(int64_t)b * kSEntries + ent];
+  s -= sc;
+  if (ent < n6 * n6) {
+    const int ra = ent / n6, rb = ent - ra * n6;
+    if (ra == rb) s += 1e-4f * s + 1.0f;                            // S += I * (1e-4 * S + 1.0)   (:560)
+    Sg[ent] = s;
+  } else {
+    yg[ent - n6 * n6] = s;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 4. depth back-substitution + retraction (patch_retr_kernel, :209-229; dZ :563)
+// 4. solve kernel: one workgroup of 128 threads, thread r owns row r
 // ---------------------------------------------------------------------------------------------------
-__global__ void ba_retr_kernel(float* __restrict__ patches, const int32_t* __restrict__ kx,
+__global__ __launch_bounds__(128) void ba_solve_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
+                                                       float* __restrict__ dX, int32_t* __restrict__ info) {
+  __shared__ float S[kMaxDim][kMaxDim + 1];
+  __shared__ float xs[kMaxDim];
+  __shared__ int bad;
+  const int n6 = 6 * N;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  for (int a = tid; a < n6 * n6; a += 128) S[a / n6][a % n6] = Sg[a];
+  __syncthreads();
+  // left-looking Cholesky (lower): column j of L from rows' dot products with row j, one barrier per column;
+  // every thread recomputes the pivot from the same operands in the same order -> identical value.
+  for (int j = 0; j < n6; ++j) {
+    float d = S[j][j];
+    for (int k = 0; k < j; ++k) d -= S[j][k] * S[j][k];
+    if (tid == 0 && !(d > 0.f) && bad == 0) bad = j + 1;           // linalg_cholesky_ex info (ignored by the reference)
+    const float djj = sqrtf(d);
+    float v = 0.f;
+    if (tid > j && tid < n6) {
+      v = S[tid][j];
+      for (int k = 0; k < j; ++k) v -= S[tid][k] * S[j][k];
+      v /= djj;
+    }
+    __syncthreads();
+    if (tid > j && tid < n6) S[tid][j] = v;
+    if (tid == j) S[j][j] = djj;
+    __syncthreads();
+  }
+  // forward substitution L z = y (column oriented: thread r owns b_r)
+  float b = (tid < n6) ? yg[tid] : 0.f;
+  for (int k = 0; k < n6; ++k) {
+    if (tid == k) xs[k] = b / S[k][k];
+    __syncthreads();
+    if (tid > k && tid < n6) b -= S[tid][k] * xs[k];
+  }
+  __syncthreads();
+  // backward substitution L^T x = z
+  b = (tid < n6) ? xs[tid] : 0.f;
+  __syncthreads();
+  for (int k = n6 - 1; k >= 0; --k) {
+    if (tid == k) xs[k] = b / S[k][k];
+    __syncthreads();
+    if (tid < k) b -= S[k][tid] * xs[k];
+  }
+  __syncthreads();
+  if (tid < n6) dX[tid] = xs[tid];
+  if (tid == 0 && info) *info = bad;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 5. depth back-substitution + retractions (patch_retr_kernel :209-229, dZ :563; pose_retr_kernel :178-206)
+// ---------------------------------------------------------------------------------------------------
+__global__ void ba_retr_kernel(float* __restrict__ poses, float* __restrict__ patches, const int32_t* __restrict__ kx,
                                const int32_t* __restrict__ n_patches, const float* __restrict__ Qbuf,
                                const float* __restrict__ ubuf, const float* __restrict__ Ecol,
-                               const float* __restrict__ dX, int n6, int P) {
+                               const float* __restrict__ dX, int t0, int N, int P) {
   const int np = *n_patches;
-  const int PP = P * P;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < np; k += gridDim.x * blockDim.x) {
+  const int PP = P * P, n6 = 6 * N;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = gt; k < np; k += gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int a = 0; a < n6; ++a) s += Ecol[(int64_t)k * n6 + a] * dX[a];
     const float dZ = Qbuf[k] * (ubuf[k] - s);
@@ -430,10 +461,18 @@ __global__ void ba_retr_kernel(float* __restrict__ patches, const int32_t* __res
     d = fmaxf(d, 1e-4f);
     for (int a = 0; a < PP; ++a) pk[a] = d;
   }
+  if (gt < N) {
+    float* p = poses + 7 * (int64_t)(t0 + gt);
+    const float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]};
+    const float xi[6] = {dX[6 * gt], dX[6 * gt + 1], dX[6 * gt + 2], dX[6 * gt + 3], dX[6 * gt + 4], dX[6 * gt + 5]};
+    float t1v[3], q1v[4];
+    retrSE3(xi, tt, qq, t1v, q1v);
+    p[0] = t1v[0]; p[1] = t1v[1]; p[2] = t1v[2]; p[3] = q1v[0]; p[4] = q1v[1]; p[5] = q1v[2]; p[6] = q1v[3];
+  }
 }
 
 struct BaWs {
-  size_t pairbuf, edgebuf, Qbuf, ubuf, Ecol, spart, dX, total;
+  size_t pairbuf, edgebuf, Qbuf, ubuf, Ecol, spart, Sg, yg, dX, total;
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -441,13 +480,16 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 inline void ba_ws_layout(int64_t E, int N, BaWs* L) {
   const size_t n = (size_t)(E > 0 ? E : 1);
   const size_t n6 = (size_t)(6 * (N > 0 ? N : 1));
+  const size_t nblk = (n + kPatchChunk - 1) / kPatchChunk;
   size_t o = 0;
   L->pairbuf = o; o += al(n * kPairStride * 4);
   L->edgebuf = o; o += al(n * kEdgeStride * 4);
   L->Qbuf = o; o += al(n * 4);
   L->ubuf = o; o += al(n * 4);
   L->Ecol = o; o += al(n * n6 * 4);
-  L->spart = o; o += al((size_t)kPatchBlocks * (kMaxDim * kMaxDim + kMaxDim) * 4);
+  L->spart = o; o += al(nblk * (size_t)kSEntries * 4);
+  L->Sg = o; o += al((size_t)kMaxDim * kMaxDim * 4);
+  L->yg = o; o += al(kMaxDim * 4);
   L->dX = o; o += al(kMaxDim * 4);
   L->total = o;
 }
@@ -463,8 +505,8 @@ extern "C" size_t dpvo_ba_workspace_bytes(int64_t E, int n_free_poses) {
 
 extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                        float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, const int32_t* plan,
-                       int64_t E, int P, int t0, int t1, int iterations, int32_t* info, void* ws, size_t ws_bytes,
-                       void* stream) {
+                       int64_t n_patches_hint, int64_t n_pairs_hint, int64_t E, int P, int t0, int t1, int iterations,
+                       int32_t* info, void* ws, size_t ws_bytes, void* stream) {
   if (E < 0 || P <= 0 || t1 < t0 || iterations < 0) return DPVO_E_INVALID;
   const int N = t1 - t0;
   if (6 * N > kMaxDim) return DPVO_E_UNSUPPORTED;
@@ -482,21 +524,31 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
   float* ubuf = (float*)(w + L.ubuf);
   float* Ecol = (float*)(w + L.Ecol);
   float* spart = (float*)(w + L.spart);
+  float* Sg = (float*)(w + L.Sg);
+  float* yg = (float*)(w + L.yg);
   float* dX = (float*)(w + L.dX);
   hipStream_t st = (hipStream_t)stream;
   const int32_t* n_patches = plan + PL.counts + 0;
   const int32_t* n_pairs = plan + PL.counts + 1;
-  const unsigned pair_grid = (unsigned)(E < 4096 ? (E > 0 ? E : 1) : 4096);
+  // exact group counts are a launch-size hint (the plan's device-side counts stay authoritative):
+  // unknown (<= 0) falls back to the E upper bound.
+  const int64_t np_h = (n_patches_hint > 0 && n_patches_hint <= E) ? n_patches_hint : E;
+  const int64_t ng_h = (n_pairs_hint > 0 && n_pairs_hint <= E) ? n_pairs_hint : E;
+  const unsigned pair_grid = (unsigned)(ng_h < 65535 ? ng_h : 65535);
+  const unsigned patch_blocks = (unsigned)((np_h + kPatchChunk - 1) / kPatchChunk);
+  const int nent = 36 * N * N + 6 * N;
   for (int itr = 0; itr < iterations; ++itr) {
-    hipLaunchKernelGGL(ba_pair_kernel, dim3(pair_grid), dim3(64), 0, st, poses, patches, intrinsics, target, weight, kk,
+    hipLaunchKernelGGL(ba_pair_kernel, dim3(pair_grid), dim3(128), 0, st, poses, patches, intrinsics, target, weight, kk,
                        plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, n_pairs, pairbuf, edgebuf, P);
-    hipLaunchKernelGGL(ba_patch_kernel, dim3(kPatchBlocks), dim3(256), 0, st, ii, jj, plan + PL.perm_k, plan + PL.patch_off,
-                       n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, spart);
-    if (N > 0)
-      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(512), 0, st, poses, plan + PL.pair_ij, n_pairs, pairbuf, spart,
-                         kPatchBlocks, t0, N, dX, info ? info + itr : nullptr);
-    hipLaunchKernelGGL(ba_retr_kernel, dim3(64), dim3(256), 0, st, patches, plan + PL.kx, n_patches, Qbuf, ubuf, Ecol, dX,
-                       6 * N, P);
+    hipLaunchKernelGGL(ba_patch_kernel, dim3(patch_blocks), dim3(256), 0, st, ii, jj, plan + PL.perm_k,
+                       plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, spart);
+    if (N > 0) {
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3((nent + 255) / 256), dim3(256), 0, st, plan + PL.pair_ij, n_pairs,
+                         pairbuf, spart, (int)patch_blocks, t0, N, Sg, yg);
+      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(128), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
+    }
+    hipLaunchKernelGGL(ba_retr_kernel, dim3((unsigned)((np_h + 255) / 256)), dim3(256), 0, st, poses, patches,
+                       plan + PL.kx, n_patches, Qbuf, ubuf, Ecol, dX, t0, N, P);
   }
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;

@@ -64,7 +64,8 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M,
     nbytes = L.lib().dpvo_ba_workspace_bytes(L.i64(E), L.i32(N))
     ws = workspace.get(nbytes, poses.device, "ba")
     L.check(L.lib().dpvo_ba(L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight), L.f32(lm),
-                            L.ptr(ii), L.ptr(jj), L.ptr(kk), L.ptr(plan.buf), L.i64(E), L.i32(P), L.i32(t0), L.i32(t1),
+                            L.ptr(ii), L.ptr(jj), L.ptr(kk), L.ptr(plan.buf), L.i64(plan.n_patches_host),
+                            L.i64(plan.n_pairs_host), L.i64(E), L.i32(P), L.i32(t0), L.i32(t1),
                             L.i32(iterations), L.ptr(info), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "dpvo_ba")
     return []

@@ -201,13 +201,16 @@ int dpvo_heads(const float* net, const void* Wd, const void* bd, const void* Ww,
  * Residual/Jacobian/mask semantics: ba_cuda.cu:232-376; damping S += I*(1e-4*S+1) :546,560; depth
  * prior Q=1/(C+lmbda) :519; retractions :157-229.  Deterministic (no float atomics).
  * info (device int32[iterations], may be NULL) receives the Cholesky status per iteration.
+ * n_patches_hint / n_pairs_hint: the host's copy of the plan's counts, used only to size the launches exactly
+ * (<= 0 = unknown, launches are then sized by E); the device-side counts stay authoritative.
  * Dense Schur path for 6*(t1-t0) <= DPVO_BA_MAX_DIM; larger systems return DPVO_E_UNSUPPORTED
  * (global BA is routed by the host to the block-sparse path). */
-#define DPVO_BA_MAX_DIM 192
+#define DPVO_BA_MAX_DIM 120
 size_t dpvo_ba_workspace_bytes(int64_t E, int n_free_poses);
 int dpvo_ba(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
-            float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, const int32_t* plan, int64_t E,
-            int P, int t0, int t1, int iterations, int32_t* info, void* ws, size_t ws_bytes, void* stream);
+            float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, const int32_t* plan,
+            int64_t n_patches_hint, int64_t n_pairs_hint, int64_t E, int P, int t0, int t1, int iterations,
+            int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
