@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
                                                        const int32_t* __restrict__ n_patches,
                                                        const float* __restrict__ edgebuf, float lmbda, int t0, int N,
                                                        float* __restrict__ Qbuf, float* __restrict__ ubuf,
-                                                       float* __restrict__ Ecol, float* __restrict__ spart) {
+                                                       float* __restrict__ Ecol, int64_t ldE,
+                                                       float* __restrict__ spart) {
   __shared__ float col[kPatchChunk][kMaxDim + 1];
   __shared__ float qv[kPatchChunk], uv[kPatchChunk];
   const int n6 = 6 * N;
@@ -300,11 +301,11 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
     }
   }
   __syncthreads();
-  // store the columns (patch-major) for the dZ back-substitution
+  // store the columns for the dZ back-substitution, row-major [n6][ldE] (coalesced over patches)
   for (int a = tid; a < kPatchChunk * n6; a += 256) {
-    const int pl = a / n6, r = a - pl * n6;
+    const int r = a / kPatchChunk, pl = a - r * kPatchChunk;
     const int k = ch * kPatchChunk + pl;
-    if (k < np) Ecol[(int64_t)k * n6 + r] = col[pl][r];
+    if (k < np) Ecol[(int64_t)r * ldE + k] = col[pl][r];
   }
   // partial S and y of this block
   float* sp = spart + (int64_t)blockIdx.x * kSEntries;
@@ -324,15 +325,20 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3. assemble kernel: one thread per entry of S (n6 x n6) and y (n6)
+// 3. assemble kernel: one block per free pose p = block row p of S (6 x n6) and y[6p..6p+5]
+//    wave 0: diagonal block + y: lanes stride over the pairs, per-lane partial sums, fixed-order butterfly;
+//    waves 1..3: off-diagonal blocks (two binary searches in the LDS copy of the sorted pair list);
+//    then all threads: subtract the Schur partials (4 lanes per entry) and apply the damping.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int find_pair(const int32_t* pair_ij, int ng, int i, int j) {
+constexpr int kMaxPairsLds = 4096;
+
+__device__ __forceinline__ int find_pair(const int2* pl, int ng, int i, int j) {
   int lo = 0, hi = ng - 1;
   while (lo <= hi) {
     const int mid = (lo + hi) >> 1;
-    const int pi = pair_ij[2 * mid], pj = pair_ij[2 * mid + 1];
-    if (pi == i && pj == j) return mid;
-    if (pi < i || (pi == i && pj < j)) lo = mid + 1; else hi = mid - 1;
+    const int2 v = pl[mid];
+    if (v.x == i && v.y == j) return mid;
+    if (v.x < i || (v.x == i && v.y < j)) lo = mid + 1; else hi = mid - 1;
   }
   return -1;
 }
@@ -342,102 +348,180 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
                                                           const float* __restrict__ pairbuf,
                                                           const float* __restrict__ spart, int n_spart, int t0, int N,
                                                           float* __restrict__ Sg, float* __restrict__ yg) {
+  __shared__ int2 plist[kMaxPairsLds];
+  __shared__ float rowS[6][kMaxDim];      // block row p of B (then S)
+  __shared__ float rowy[6];
   const int n6 = 6 * N;
   const int ng = *n_pairs;
-  const int ent = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ent >= n6 * n6 + n6) return;
-  float s = 0.f;
-  if (ent < n6 * n6) {
-    const int ra = ent / n6, rb = ent - ra * n6;
-    const int p = ra / 6, a = ra - 6 * p, q = rb / 6, b = rb - 6 * q;
-    if (p == q) {
-      const int f = t0 + p;
-      for (int g = 0; g < ng; ++g) {
-        const int gi = pair_ij[2 * g], gj = pair_ij[2 * g + 1];
-        const float* pb = pairbuf + (int64_t)g * kPairStride;
-        if (gi == f) s += pb[a * 16 + b];                          // w Ji Ji^T      (ba_cuda.cu:338-339)
-        if (gj == f) s += pb[(6 + a) * 16 + 6 + b];                // w Jj Jj^T      (:340-341)
-        if (gi == f && gj == f) s += -pb[a * 16 + 6 + b] - pb[b * 16 + 6 + a];   // self edge: both cross terms
+  const int ngl = ng < kMaxPairsLds ? ng : kMaxPairsLds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = blockIdx.x, f = t0 + p;
+  const int2* pg = reinterpret_cast<const int2*>(pair_ij);
+  for (int g = tid; g < ngl; g += 256) plist[g] = pg[g];
+  for (int a = tid; a < 6 * kMaxDim; a += 256) (&rowS[0][0])[a] = 0.f;
+  __syncthreads();
+  const int2* pl = (ng <= kMaxPairsLds) ? plist : pg;   // (global fallback for very large graphs)
+  if (wave == 0) {
+    float acc[42];
+#pragma unroll
+    for (int a = 0; a < 42; ++a) acc[a] = 0.f;
+    for (int g = lane; g < ng; g += 64) {
+      const int2 ij = pl[g];
+      const float* pb = pairbuf + (int64_t)g * kPairStride;
+      if (ij.x == f) {                                            // i-side: + w Ji Ji^T, v -= w r Ji
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int b = 0; b < 6; ++b) acc[a * 6 + b] += pb[a * 16 + b];
+          acc[36 + a] -= pb[a * 16 + 12];
+        }
       }
-    } else {
-      const int g1 = find_pair(pair_ij, ng, t0 + p, t0 + q);     // i = p, j = q: block (ix,jx) gets -w Ji Jj^T
-      const int g2 = find_pair(pair_ij, ng, t0 + q, t0 + p);     // i = q, j = p: block (jx,ix) gets -w Jj Ji^T
+      if (ij.y == f) {                                            // j-side: + w Jj Jj^T, v += w r Jj
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int b = 0; b < 6; ++b) acc[a * 6 + b] += pb[(6 + a) * 16 + 6 + b];
+          acc[36 + a] += pb[(6 + a) * 16 + 12];
+        }
+      }
+      if (ij.x == f && ij.y == f) {                               // self edge: both cross terms land here
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) acc[a * 6 + b] += -pb[a * 16 + 6 + b] - pb[b * 16 + 6 + a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 42; ++a) {
+      const float s = wave_sum(acc[a]);
+      if (lane == 0) { if (a < 36) rowS[a / 6][6 * p + a % 6] = s; else rowy[a - 36] = s; }
+    }
+  } else {
+    for (int ent = tid - 64; ent < (N - 1) * 36; ent += 192) {
+      int q = ent / 36; const int r = ent - q * 36;
+      if (q >= p) q += 1;
+      const int a = r / 6, b = r - a * 6;
+      const int g1 = find_pair(pl, ng, f, t0 + q);     // i = p, j = q: block (ix,jx) gets -w Ji Jj^T   (:342-345)
+      const int g2 = find_pair(pl, ng, t0 + q, f);     // i = q, j = p: block (jx,ix) gets -w Jj Ji^T
+      float s = 0.f;
       if (g1 >= 0) s += -pairbuf[(int64_t)g1 * kPairStride + a * 16 + 6 + b];
       if (g2 >= 0) s += -pairbuf[(int64_t)g2 * kPairStride + b * 16 + 6 + a];
-    }
-  } else {
-    const int ra = ent - n6 * n6;
-    const int p = ra / 6, a = ra - 6 * p;
-    const int f = t0 + p;
-    for (int g = 0; g < ng; ++g) {
-      const int gi = pair_ij[2 * g], gj = pair_ij[2 * g + 1];
-      const float* pb = pairbuf + (int64_t)g * kPairStride;
-      if (gi == f) s += -pb[a * 16 + 12];                          // v[i] -= w r Ji     (:364-365)
-      if (gj == f) s += pb[(6 + a) * 16 + 12];                     // v[j] += w r Jj     (:366-367)
+      rowS[a][6 * q + b] = s;
     }
   }
-  // Schur complement: S = B - sum_k Q e e^T, y = v - sum_k Q u e   (ba_cuda.cu:557-558)
-  float sc = 0.f;
-  for (int b = 0; b < n_spart; ++b) sc += spart[(int64_t)b * kSEntries + ent];
-  s -= sc;
-  if (ent < n6 * n6) {
-    const int ra = ent / n6, rb = ent - ra * n6;
-    if (ra == rb) s += 1e-4f * s + 1.0f;                            // S += I * (1e-4 * S + 1.0)   (:560)
-    Sg[ent] = s;
-  } else {
-    yg[ent - n6 * n6] = s;
+  __syncthreads();
+  // Schur complement (ba_cuda.cu:557-558) + damping (:560): entry = 6 x n6 of S, then 6 of y; 4 lanes per entry
+  const int nrow = 6 * n6 + 6;
+  for (int base = 0; base < nrow; base += 64) {
+    const int e4 = base + (tid >> 2), sub = tid & 3;
+    float sc = 0.f;
+    int gent = 0;
+    if (e4 < nrow) {
+      gent = (e4 < 6 * n6) ? (6 * p + e4 / n6) * n6 + (e4 % n6) : n6 * n6 + 6 * p + (e4 - 6 * n6);
+      for (int b = sub; b < n_spart; b += 4) sc += spart[(int64_t)b * kSEntries + gent];
+    }
+    sc += __shfl_xor(sc, 1);
+    sc += __shfl_xor(sc, 2);
+    if (e4 < nrow && sub == 0) {
+      if (e4 < 6 * n6) {
+        const int ra = e4 / n6, rb = e4 - ra * n6;
+        float s = rowS[ra][rb] - sc;
+        if (6 * p + ra == rb) s += 1e-4f * s + 1.0f;              // S += I * (1e-4 * S + 1.0)
+        Sg[gent] = s;
+      } else {
+        yg[6 * p + (e4 - 6 * n6)] = rowy[e4 - 6 * n6] - sc;
+      }
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 4. solve kernel: one workgroup of 128 threads, thread r owns row r
+// 4. solve kernel: one workgroup, thread r owns row r.  n6 <= 64: a single wave, no barriers at all
+//    (LDS traffic of one wave is program-ordered; pivots travel by v_readlane); n6 <= 120: two waves.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void ba_solve_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
-                                                       float* __restrict__ dX, int32_t* __restrict__ info) {
-  __shared__ float S[kMaxDim][kMaxDim + 1];
+constexpr int kLdS = kMaxDim + 4;       // 124: 16-byte aligned rows, conflict-free for ds_read_b128
+
+template <bool ONE_WAVE>
+__device__ __forceinline__ void blk_sync() {
+  if constexpr (ONE_WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <bool ONE_WAVE>
+__global__ __launch_bounds__(ONE_WAVE ? 64 : 128) void ba_solve_kernel(const float* __restrict__ Sg,
+                                                                        const float* __restrict__ yg, int N,
+                                                                        float* __restrict__ dX,
+                                                                        int32_t* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) float S[kMaxDim * kLdS];
   __shared__ float xs[kMaxDim];
-  __shared__ int bad;
+  constexpr int NT = ONE_WAVE ? 64 : 128;
   const int n6 = 6 * N;
   const int tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  for (int a = tid; a < n6 * n6; a += 128) S[a / n6][a % n6] = Sg[a];
-  __syncthreads();
-  // left-looking Cholesky (lower): column j of L from rows' dot products with row j, one barrier per column;
-  // every thread recomputes the pivot from the same operands in the same order -> identical value.
+  for (int a = tid; a < n6 * n6; a += NT) S[(a / n6) * kLdS + (a % n6)] = Sg[a];
+  blk_sync<ONE_WAVE>();
+  int bad = 0;
+  const float* rowt = S + tid * kLdS;
+  // left-looking Cholesky (lower): L[t][j] = (S[t][j] - sum_k L[t][k] L[j][k]) / L[j][j]; every thread recomputes
+  // the pivot from the same operands in the same order -> identical value, one sync per column.
   for (int j = 0; j < n6; ++j) {
-    float d = S[j][j];
-    for (int k = 0; k < j; ++k) d -= S[j][k] * S[j][k];
-    if (tid == 0 && !(d > 0.f) && bad == 0) bad = j + 1;           // linalg_cholesky_ex info (ignored by the reference)
+    const float* rowj = S + j * kLdS;
+    float d = rowj[j];
+    float v = (tid < n6) ? rowt[j] : 0.f;
+    int k = 0;
+    for (; k + 4 <= j; k += 4) {
+      const f4 a = *reinterpret_cast<const f4*>(rowj + k);
+      const f4 b = (tid < n6) ? *reinterpret_cast<const f4*>(rowt + k) : (f4)0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d -= a[r] * a[r]; v -= b[r] * a[r]; }
+    }
+    for (; k < j; ++k) {
+      const float a = rowj[k];
+      d -= a * a;
+      if (tid < n6) v -= rowt[k] * a;
+    }
+    if (!(d > 0.f) && bad == 0) bad = j + 1;                       // linalg_cholesky_ex info (ignored by the reference)
     const float djj = sqrtf(d);
-    float v = 0.f;
-    if (tid > j && tid < n6) {
-      v = S[tid][j];
-      for (int k = 0; k < j; ++k) v -= S[tid][k] * S[j][k];
-      v /= djj;
+    blk_sync<ONE_WAVE>();                                          // all reads of column j / row j done
+    if (tid > j && tid < n6) S[tid * kLdS + j] = v / djj;
+    if (tid == j) S[j * kLdS + j] = djj;
+    blk_sync<ONE_WAVE>();
+  }
+  // triangular solves, column oriented: thread r owns b_r
+  float b = (tid < n6) ? yg[tid] : 0.f;
+  if constexpr (ONE_WAVE) {
+    for (int k = 0; k < n6; ++k) {                                 // L z = y
+      const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), k)) / S[k * kLdS + k];
+      if (tid == k) b = xk;
+      if (tid > k && tid < n6) b -= rowt[k] * xk;
+    }
+    for (int k = n6 - 1; k >= 0; --k) {                            // L^T x = z
+      const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), k)) / S[k * kLdS + k];
+      if (tid == k) b = xk;
+      if (tid < k) b -= S[k * kLdS + tid] * xk;
+    }
+    if (tid < n6) dX[tid] = b;
+  } else {
+    for (int k = 0; k < n6; ++k) {
+      if (tid == k) xs[k] = b / S[k * kLdS + k];
+      __syncthreads();
+      if (tid > k && tid < n6) b -= rowt[k] * xs[k];
     }
     __syncthreads();
-    if (tid > j && tid < n6) S[tid][j] = v;
-    if (tid == j) S[j][j] = djj;
+    b = (tid < n6) ? xs[tid] : 0.f;
     __syncthreads();
-  }
-  // forward substitution L z = y (column oriented: thread r owns b_r)
-  float b = (tid < n6) ? yg[tid] : 0.f;
-  for (int k = 0; k < n6; ++k) {
-    if (tid == k) xs[k] = b / S[k][k];
+    for (int k = n6 - 1; k >= 0; --k) {
+      if (tid == k) xs[k] = b / S[k * kLdS + k];
+      __syncthreads();
+      if (tid < k) b -= S[k * kLdS + tid] * xs[k];
+    }
     __syncthreads();
-    if (tid > k && tid < n6) b -= S[tid][k] * xs[k];
+    if (tid < n6) dX[tid] = xs[tid];
   }
-  __syncthreads();
-  // backward substitution L^T x = z
-  b = (tid < n6) ? xs[tid] : 0.f;
-  __syncthreads();
-  for (int k = n6 - 1; k >= 0; --k) {
-    if (tid == k) xs[k] = b / S[k][k];
-    __syncthreads();
-    if (tid < k) b -= S[k][tid] * xs[k];
-  }
-  __syncthreads();
-  if (tid < n6) dX[tid] = xs[tid];
   if (tid == 0 && info) *info = bad;
 }
 
@@ -446,14 +530,14 @@ __global__ __launch_bounds__(128) void ba_solve_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 __global__ void ba_retr_kernel(float* __restrict__ poses, float* __restrict__ patches, const int32_t* __restrict__ kx,
                                const int32_t* __restrict__ n_patches, const float* __restrict__ Qbuf,
-                               const float* __restrict__ ubuf, const float* __restrict__ Ecol,
+                               const float* __restrict__ ubuf, const float* __restrict__ Ecol, int64_t ldE,
                                const float* __restrict__ dX, int t0, int N, int P) {
   const int np = *n_patches;
   const int PP = P * P, n6 = 6 * N;
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   for (int k = gt; k < np; k += gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int a = 0; a < n6; ++a) s += Ecol[(int64_t)k * n6 + a] * dX[a];
+    for (int a = 0; a < n6; ++a) s += Ecol[(int64_t)a * ldE + k] * dX[a];
     const float dZ = Qbuf[k] * (ubuf[k] - s);
     float* pk = patches + (int64_t)kx[k] * 3 * PP + 2 * PP;
     float d = pk[0] + dZ;
@@ -536,19 +620,21 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
   const int64_t ng_h = (n_pairs_hint > 0 && n_pairs_hint <= E) ? n_pairs_hint : E;
   const unsigned pair_grid = (unsigned)(ng_h < 65535 ? ng_h : 65535);
   const unsigned patch_blocks = (unsigned)((np_h + kPatchChunk - 1) / kPatchChunk);
-  const int nent = 36 * N * N + 6 * N;
   for (int itr = 0; itr < iterations; ++itr) {
     hipLaunchKernelGGL(ba_pair_kernel, dim3(pair_grid), dim3(128), 0, st, poses, patches, intrinsics, target, weight, kk,
                        plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, n_pairs, pairbuf, edgebuf, P);
     hipLaunchKernelGGL(ba_patch_kernel, dim3(patch_blocks), dim3(256), 0, st, ii, jj, plan + PL.perm_k,
-                       plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, spart);
+                       plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, np_h, spart);
     if (N > 0) {
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3((nent + 255) / 256), dim3(256), 0, st, plan + PL.pair_ij, n_pairs,
-                         pairbuf, spart, (int)patch_blocks, t0, N, Sg, yg);
-      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(128), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, spart,
+                         (int)patch_blocks, t0, N, Sg, yg);
+      if (6 * N <= 64)
+        hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(64), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
+      else
+        hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(128), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
     }
     hipLaunchKernelGGL(ba_retr_kernel, dim3((unsigned)((np_h + 255) / 256)), dim3(256), 0, st, poses, patches,
-                       plan + PL.kx, n_patches, Qbuf, ubuf, Ecol, dX, t0, N, P);
+                       plan + PL.kx, n_patches, Qbuf, ubuf, Ecol, np_h, dX, t0, N, P);
   }
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
