@@ -64,24 +64,18 @@ def corr_pyramid(gmap_cl, fmap0_cl, fmap1_cl, coords, ii, jj, radius=3, order=No
 
 
 def patchify(net, coords, radius, mode='bilinear'):
-    """altcorr.patchify (correlation.py:51-68): net [B,C,H,W], coords [B,M,2] -> [B,M,C,d,d]."""
+    """altcorr.patchify (correlation.py:51-68): net [B,C,H,W], coords [B,M,2] -> [B,M,C,d,d]
+    (d = 2r+1 with the bilinear blend fused in one kernel, d = 2r+2 for mode != 'bilinear')."""
     L.require_cuda(net, coords)
     B, C, H, W = net.shape
     M = coords.shape[1]
-    D = 2 * radius + 2
     co = coords.float().contiguous()
+    bil = (mode == 'bilinear')
+    D = 2 * radius + (1 if bil else 2)
+    fn = L.lib().dpvo_patchify_bilinear if bil else L.lib().dpvo_patchify_forward
     patches = torch.empty(B, M, C, D, D, dtype=net.dtype, device=net.device)
     for b in range(B):
-        L.check(L.lib().dpvo_patchify_forward(L.ptr(net[b]), L.strides(net, (1, 2, 3)), L.ptr(co[b]), L.ptr(patches[b]),
-                                              L.i32(L.dtype_code(net.dtype)), L.i64(M), L.i32(C), L.i32(H), L.i32(W),
-                                              L.i32(radius), L.stream()), "dpvo_patchify_forward")
-    if mode == 'bilinear':
-        offset = (co - co.floor()).to(net.device)
-        dx, dy = offset[:, :, None, None, None].unbind(dim=-1)
-        d = 2 * radius + 1
-        x00 = (1 - dy) * (1 - dx) * patches[..., :d, :d]
-        x01 = (1 - dy) * (dx) * patches[..., :d, 1:]
-        x10 = (dy) * (1 - dx) * patches[..., 1:, :d]
-        x11 = (dy) * (dx) * patches[..., 1:, 1:]
-        return x00 + x01 + x10 + x11
+        L.check(fn(L.ptr(net[b]), L.strides(net, (1, 2, 3)), L.ptr(co[b]), L.ptr(patches[b]),
+                   L.i32(L.dtype_code(net.dtype)), L.i64(M), L.i32(C), L.i32(H), L.i32(W), L.i32(radius), L.stream()),
+                "dpvo_patchify")
     return patches

@@ -267,6 +267,41 @@ __global__ void patchify_kernel(const T* __restrict__ net, int64_t sc, int64_t s
   }
 }
 
+
+// patchify + the Python bilinear blend of altcorr.patchify (correlation.py:51-68) in one launch:
+// out[m][c][a][b] = blend of the (2R+2)^2 integer-floor window (zeros when OOB) with the centroid's (dx,dy).
+template <typename T>
+__global__ void patchify_bilinear_kernel(const T* __restrict__ net, int64_t sc, int64_t sh, int64_t sw,
+                                         const float* __restrict__ coords, T* __restrict__ out, int64_t M, int C, int H,
+                                         int W, int radius) {
+  const int d = 2 * radius + 1;
+  const int64_t total = M * C * d * d;
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < total; n += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = n;
+    const int b = t % d; t /= d;
+    const int a = t % d; t /= d;
+    const int c = t % C; t /= C;
+    const int64_t m = t;
+    const float x = coords[2 * m + 0], y = coords[2 * m + 1];
+    const float dx = x - floorf(x), dy = y - floorf(y);
+    const int i0 = safe_floor_int(y) + (a - radius), j0 = safe_floor_int(x) + (b - radius);
+    float v[2][2];
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int i = i0 + aa, j = j0 + bb;
+        v[aa][bb] = (i >= 0 && i < H && j >= 0 && j < W) ? (float)net[c * sc + i * sh + j * sw] : 0.f;
+      }
+    // same term order as the reference: x00 + x01 + x10 + x11
+    float o = (1.f - dy) * (1.f - dx) * v[0][0];
+    o += (1.f - dy) * dx * v[0][1];
+    o += dy * (1.f - dx) * v[1][0];
+    o += dy * dx * v[1][1];
+    out[n] = (T)o;
+  }
+}
+
 extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, const void* fmap1, const float* coords,
                                          const int64_t* us, const int64_t* vs, const int32_t* order, void* out,
                                          int64_t ld_out, int64_t E, int C, int P, int64_t N1, int64_t N2, int H0,
@@ -323,6 +358,26 @@ extern "C" int dpvo_patchify_forward(const void* net, const int64_t* sn, const f
                        (const _Float16*)net, sn[0], sn[1], sn[2], coords, (_Float16*)out, M, C, H, W, radius);
   else if (dtype == DPVO_F32)
     hipLaunchKernelGGL(patchify_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)net, sn[0], sn[1], sn[2], coords, (float*)out, M, C, H, W, radius);
+  else
+    return DPVO_E_UNSUPPORTED;
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_patchify_bilinear(const void* net, const int64_t* sn, const float* coords, void* out, int dtype,
+                                      int64_t M, int C, int H, int W, int radius, void* stream) {
+  if (M < 0 || C <= 0 || radius < 0 || !sn) return DPVO_E_INVALID;
+  if (M == 0) return DPVO_OK;
+  if (!net || !coords || !out) return DPVO_E_INVALID;
+  const int d = 2 * radius + 1;
+  const int64_t total = M * C * d * d;
+  const int64_t grid = cdiv64(total, 256) < 65536 ? cdiv64(total, 256) : 65536;
+  if (dtype == DPVO_F16)
+    hipLaunchKernelGGL(patchify_bilinear_kernel<_Float16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)net, sn[0], sn[1], sn[2], coords, (_Float16*)out, M, C, H, W, radius);
+  else if (dtype == DPVO_F32)
+    hipLaunchKernelGGL(patchify_bilinear_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)net, sn[0], sn[1], sn[2], coords, (float*)out, M, C, H, W, radius);
   else
     return DPVO_E_UNSUPPORTED;

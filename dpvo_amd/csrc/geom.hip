@@ -204,39 +204,75 @@ __global__ void reproject_kernel(const float* __restrict__ poses, const float* _
   }
 }
 
-// pops.flow_mag (projective_ops.py:120-130): per edge, mean over the PxP pixels of
+// pops.flow_mag (projective_ops.py:120-130) for one edge: mean over the PxP pixels of
 // beta*|x(Gij) - x(Gii)| + (1-beta)*|x(t-only) - x(Gii)|, and the number of valid pixels (Z > 0.2).
+__device__ __forceinline__ void edge_flow(const float* __restrict__ poses, const float* __restrict__ patches,
+                                          const float* __restrict__ intr, int64_t i, int64_t j, int64_t k, float beta,
+                                          int P, float* flow, float* nvalid) {
+  const int PP = P * P;
+  const Pose Gi = load_pose(poses + 7 * i), Gj = load_pose(poses + 7 * j);
+  const Pose Gi_inv = se3_inv(Gi);
+  const Pose Gij = se3_mul(Gj, Gi_inv);
+  const Pose Gii = se3_mul(Gi, Gi_inv);
+  Pose Gt; Gt.t = Gij.t; Gt.q = {0.f, 0.f, 0.f, 1.f};          // tonly (:62-63)
+  const float* Ki = intr + 4 * i; const float* Kj = intr + 4 * j;
+  const float* pk = patches + k * 3 * PP;
+  float fsum = 0.f, vsum = 0.f;
+  for (int a = 0; a < PP; ++a) {
+    const float X0[4] = {(pk[a] - Ki[2]) / Ki[0], (pk[PP + a] - Ki[3]) / Ki[1], 1.0f, pk[2 * PP + a]};
+    float A0[4], A1[4], A2[4];
+    se3_act4(Gii, X0, A0); se3_act4(Gij, X0, A1); se3_act4(Gt, X0, A2);
+    const float d0 = 1.0f / fmaxf(A0[2], 0.1f), d1 = 1.0f / fmaxf(A1[2], 0.1f), d2 = 1.0f / fmaxf(A2[2], 0.1f);
+    const float c0x = Ki[0] * (d0 * A0[0]) + Ki[2], c0y = Ki[1] * (d0 * A0[1]) + Ki[3];
+    const float c1x = Kj[0] * (d1 * A1[0]) + Kj[2], c1y = Kj[1] * (d1 * A1[1]) + Kj[3];
+    const float c2x = Kj[0] * (d2 * A2[0]) + Kj[2], c2y = Kj[1] * (d2 * A2[1]) + Kj[3];
+    const float f1 = sqrtf((c1x - c0x) * (c1x - c0x) + (c1y - c0y) * (c1y - c0y));
+    const float f2 = sqrtf((c2x - c0x) * (c2x - c0x) + (c2y - c0y) * (c2y - c0y));
+    fsum += beta * f1 + (1.0f - beta) * f2;
+    vsum += (A1[2] > 0.2f) ? 1.0f : 0.0f;
+  }
+  *flow = fsum / (float)PP;
+  *nvalid = vsum;
+}
+
 __global__ void flow_mag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
                                 const float* __restrict__ intr, const int64_t* __restrict__ ii,
                                 const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, float beta,
                                 float* __restrict__ flow, float* __restrict__ valid, int64_t E, int P) {
-  const int PP = P * P;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = ii[e], j = jj[e], k = kk[e];
-    const Pose Gi = load_pose(poses + 7 * i), Gj = load_pose(poses + 7 * j);
-    const Pose Gi_inv = se3_inv(Gi);
-    const Pose Gij = se3_mul(Gj, Gi_inv);
-    const Pose Gii = se3_mul(Gi, Gi_inv);
-    Pose Gt; Gt.t = Gij.t; Gt.q = {0.f, 0.f, 0.f, 1.f};          // tonly (:62-63)
-    const float* Ki = intr + 4 * i; const float* Kj = intr + 4 * j;
-    const float* pk = patches + k * 3 * PP;
-    float fsum = 0.f, vsum = 0.f;
-    for (int a = 0; a < PP; ++a) {
-      const float X0[4] = {(pk[a] - Ki[2]) / Ki[0], (pk[PP + a] - Ki[3]) / Ki[1], 1.0f, pk[2 * PP + a]};
-      float A0[4], A1[4], A2[4];
-      se3_act4(Gii, X0, A0); se3_act4(Gij, X0, A1); se3_act4(Gt, X0, A2);
-      const float d0 = 1.0f / fmaxf(A0[2], 0.1f), d1 = 1.0f / fmaxf(A1[2], 0.1f), d2 = 1.0f / fmaxf(A2[2], 0.1f);
-      const float c0x = Ki[0] * (d0 * A0[0]) + Ki[2], c0y = Ki[1] * (d0 * A0[1]) + Ki[3];
-      const float c1x = Kj[0] * (d1 * A1[0]) + Kj[2], c1y = Kj[1] * (d1 * A1[1]) + Kj[3];
-      const float c2x = Kj[0] * (d2 * A2[0]) + Kj[2], c2y = Kj[1] * (d2 * A2[1]) + Kj[3];
-      const float f1 = sqrtf((c1x - c0x) * (c1x - c0x) + (c1y - c0y) * (c1y - c0y));
-      const float f2 = sqrtf((c2x - c0x) * (c2x - c0x) + (c2y - c0y) * (c2y - c0y));
-      fsum += beta * f1 + (1.0f - beta) * f2;
-      vsum += (A1[2] > 0.2f) ? 1.0f : 0.0f;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
+    edge_flow(poses, patches, intr, ii[e], jj[e], kk[e], beta, P, flow + e, valid + e);
+}
+
+// DPVO.motionmag(i,j) + motionmag(j,i) (dpvo.py:257-264,269) in one launch: sums and counts of the per-edge
+// pixel-mean flow (pops.flow_mag(...).mean() averages over edges x pixels; every edge has PxP pixels) over the
+// edges (i->j) and (j->i).  One 1024-thread block, fixed-order tree reduction: out = {sum_ij, n_ij, sum_ji, n_ji}.
+__global__ __launch_bounds__(1024) void motionmag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                         const float* __restrict__ intr, const int64_t* __restrict__ ii,
+                                                         const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+                                                         int64_t E, int P, int64_t qi, int64_t qj, float beta,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4][1024];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t e = threadIdx.x; e < E; e += 1024) {
+    const int64_t i = ii[e], j = jj[e];
+    const bool fwd = (i == qi && j == qj), bwd = (i == qj && j == qi);
+    if (fwd || bwd) {
+      float f, v;
+      edge_flow(poses, patches, intr, i, j, kk[e], beta, P, &f, &v);
+      if (fwd) { s[0] += f; s[1] += 1.f; }
+      if (bwd) { s[2] += f; s[3] += 1.f; }
     }
-    flow[e] = fsum / (float)PP;
-    valid[e] = vsum;
   }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) red[a][threadIdx.x] = s[a];
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x][0];
 }
 
 // pops.point_cloud centre pixel, dpvo.py:358-360.
@@ -307,6 +343,17 @@ extern "C" int dpvo_point_cloud(const float* poses, const float* patches, const 
   if (!poses || !patches || !intrinsics || !ix || !points) return DPVO_E_INVALID;
   hipLaunchKernelGGL(point_cloud_kernel, dim3(grid_for(m)), dim3(256), 0, (hipStream_t)stream, poses, patches,
                      intrinsics, ix, points, m, P);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                              const int64_t* jj, const int64_t* kk, int64_t E, int P, int64_t i, int64_t j, float beta,
+                              float* out4, void* stream) {
+  if (E < 0 || P <= 0 || !out4) return DPVO_E_INVALID;
+  if (E > 0 && (!poses || !patches || !intrinsics || !ii || !jj || !kk)) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(motionmag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
+                     kk, E, P, i, j, beta, out4);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

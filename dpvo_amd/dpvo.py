@@ -122,6 +122,12 @@ class DPVO:
         self.network.to(self.device)
         self.network.eval()
         self.network.update.pack()
+        # MIXED_PRECISION: the reference re-casts every conv weight to f16 through autocast on every frame
+        # (dpvo.py:391); the encoders are cast once here and run in f16 directly (same kernels, same arithmetic).
+        self._enc_half = bool(self.cfg.MIXED_PRECISION)
+        if self._enc_half:
+            self.network.patchify.fnet.half()
+            self.network.patchify.inet.half()
 
     def start_viewer(self):
         raise NotImplementedError("DPViewer (Pangolin) is out of scope; run headless")
@@ -239,18 +245,20 @@ class DPVO:
     def remove_factors(self, m, store: bool):
         assert self.pg.ii.numel() == self.pg.weight.shape[1]
         if store:
-            self.pg.ii_inac = torch.cat((self.pg.ii_inac, self.pg.ii[m]))
-            self.pg.jj_inac = torch.cat((self.pg.jj_inac, self.pg.jj[m]))
-            self.pg.kk_inac = torch.cat((self.pg.kk_inac, self.pg.kk[m]))
-            self.pg.weight_inac = torch.cat((self.pg.weight_inac, self.pg.weight[:, m]), dim=1)
-            self.pg.target_inac = torch.cat((self.pg.target_inac, self.pg.target[:, m]), dim=1)
-        self.pg.weight = self.pg.weight[:, ~m]
-        self.pg.target = self.pg.target[:, ~m]
+            rem = m.nonzero().squeeze(1)
+            self.pg.ii_inac = torch.cat((self.pg.ii_inac, self.pg.ii[rem]))
+            self.pg.jj_inac = torch.cat((self.pg.jj_inac, self.pg.jj[rem]))
+            self.pg.kk_inac = torch.cat((self.pg.kk_inac, self.pg.kk[rem]))
+            self.pg.weight_inac = torch.cat((self.pg.weight_inac, self.pg.weight[:, rem]), dim=1)
+            self.pg.target_inac = torch.cat((self.pg.target_inac, self.pg.target[:, rem]), dim=1)
+        keep = (~m).nonzero().squeeze(1)          # x[~m] for six tensors == one nonzero + six gathers
+        self.pg.weight = self.pg.weight[:, keep]
+        self.pg.target = self.pg.target[:, keep]
 
-        self.pg.ii = self.pg.ii[~m]
-        self.pg.jj = self.pg.jj[~m]
-        self.pg.kk = self.pg.kk[~m]
-        self.pg.net = self.pg.net[:, ~m]
+        self.pg.ii = self.pg.ii[keep]
+        self.pg.jj = self.pg.jj[keep]
+        self.pg.kk = self.pg.kk[keep]
+        self.pg.net = self.pg.net[:, keep]
         assert self.pg.ii.numel() == self.pg.weight.shape[1]
         self._plan = None
 
@@ -279,7 +287,10 @@ class DPVO:
     def keyframe(self):
         i = self.n - self.cfg.KEYFRAME_INDEX - 1
         j = self.n - self.cfg.KEYFRAME_INDEX + 1
-        m = self.motionmag(i, j) + self.motionmag(j, i)
+        # m = self.motionmag(i, j) + self.motionmag(j, i): one kernel + one read-back (was 2 x ~12 launches + 2 syncs)
+        m_ij, m_ji = pops.motionmag_pair(self.poses, self.patches, self.intrinsics, self.pg.ii, self.pg.jj, self.pg.kk,
+                                         i, j, beta=0.5)
+        m = m_ij + m_ji
 
         if m / 2 < self.cfg.KEYFRAME_THRESH:
             k = self.n - self.cfg.KEYFRAME_INDEX
@@ -400,12 +411,11 @@ class DPVO:
 
         image = 2 * (image[None, None] / 255.0) - 0.5
 
-        with autocast(device_type="cuda", enabled=self.cfg.MIXED_PRECISION):
-            fmap, gmap, imap, patches, _, clr = \
-                self.network.patchify(image,
-                                      patches_per_image=self.cfg.PATCHES_PER_FRAME,
-                                      centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
-                                      return_color=True, coords=patch_coords)
+        fmap, gmap, imap, patches, _, clr = \
+            self.network.patchify(image,
+                                  patches_per_image=self.cfg.PATCHES_PER_FRAME,
+                                  centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
+                                  return_color=True, coords=patch_coords, half=self._enc_half)
 
         ### update state attributes ###
         self.tlist.append(tstamp)

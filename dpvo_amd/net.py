@@ -228,6 +228,7 @@ class Patchifier(nn.Module):
         self.patch_size = patch_size
         self.fnet = BasicEncoder4(output_dim=128, norm_fn='instance')
         self.inet = BasicEncoder4(output_dim=DIM, norm_fn='none')
+        self._grid_cache = {}
 
     def __image_gradient(self, images):
         gray = ((images + 0.5) * (255.0 / 2)).sum(dim=2)
@@ -238,11 +239,13 @@ class Patchifier(nn.Module):
         return g
 
     def forward(self, images, patches_per_image=80, disps=None, centroid_sel_strat='RANDOM', return_color=False,
-                coords=None):
+                coords=None, half=False):
         """`coords` ([n, patches, 2] float, optional) injects the patch centroids (deterministic tests / oracle
-        replay); otherwise they are drawn exactly like the reference (x then y, net.py:131-133)."""
-        fmap = self.fnet(images) / 4.0
-        imap = self.inet(images) / 4.0
+        replay); otherwise they are drawn exactly like the reference (x then y, net.py:131-133).
+        `half`: the encoders hold f16 weights (DPVO casts them once) and are fed an f16 copy of the image."""
+        enc_in = images.half() if half else images
+        fmap = self.fnet(enc_in) / 4.0
+        imap = self.inet(enc_in) / 4.0
         b, n, c, h, w = fmap.shape
         P = self.patch_size
         dev = fmap.device
@@ -269,8 +272,13 @@ class Patchifier(nn.Module):
         if return_color:
             clr = altcorr.patchify(images[0], 4 * (coords + 0.5), 0).view(b, -1, 3)
         if disps is None:
-            disps = torch.ones(b, n, h, w, device=dev)
-        grid, _ = coords_grid_with_index(disps, device=dev)
+            key = (b, n, h, w, str(dev))
+            grid = self._grid_cache.get(key)
+            if grid is None:                      # (x, y, 1) grid: constant for a given frame size
+                grid, _ = coords_grid_with_index(torch.ones(b, n, h, w, device=dev), device=dev)
+                self._grid_cache = {key: grid}
+        else:
+            grid, _ = coords_grid_with_index(disps, device=dev)
         patches = altcorr.patchify(grid[0], coords, P // 2).view(b, -1, 3, P, P)
         index = torch.arange(n, device=dev).view(n, 1)
         index = index.repeat(1, patches_per_image).reshape(-1)

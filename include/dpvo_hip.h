@@ -81,6 +81,11 @@ int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, const void* f
 int dpvo_patchify_forward(const void* net, const int64_t* sn, const float* coords, void* out, int dtype,
                           int64_t M, int C, int H, int W, int radius, void* stream);
 
+/* altcorr.patchify(net, coords, radius, mode='bilinear') -- dpvo/altcorr/correlation.py:51-68: the gather above
+ * fused with the Python-side bilinear blend (dx,dy of the centroid).  out [M,C,d,d], d = 2R+1. */
+int dpvo_patchify_bilinear(const void* net, const int64_t* sn, const float* coords, void* out, int dtype,
+                           int64_t M, int C, int H, int W, int radius, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * projective ops  (replaces the lietorch + elementwise chain of pops.transform)
  * ---------------------------------------------------------------------------------------------- */
@@ -100,6 +105,12 @@ int dpvo_reproject(const float* poses, const float* patches, const float* intrin
 int dpvo_flow_mag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                   const int64_t* jj, const int64_t* kk, float beta, float* flow, float* valid, int64_t E, int P,
                   void* stream);
+
+/* DPVO.motionmag(i,j) + DPVO.motionmag(j,i) (dpvo/dpvo.py:257-264,269): out4 = {sum_ij, n_ij, sum_ji, n_ji} of
+ * the per-edge pixel-mean flow over the edges i->j and j->i (mean = sum/n; 0/0 = NaN like torch's empty mean). */
+int dpvo_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                   const int64_t* jj, const int64_t* kk, int64_t E, int P, int64_t i, int64_t j, float beta,
+                   float* out4, void* stream);
 
 /* pops.point_cloud centre pixel (projective_ops.py:115-117, dpvo.py:358-360): points[m,3]. */
 int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,

@@ -53,6 +53,15 @@ def test_reproject_flow_points(oracle, dev):
     rf, rv = oracle.flow_mag(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy(), beta=0.5)
     H.assert_close(fl.cpu().numpy(), rf.reshape(3000, -1).mean(1), 2e-3, 1e-4, "flow_mag")
     assert np.array_equal(val.cpu().numpy(), rv.reshape(3000, -1).sum(1))
+    # fused keyframe test (DPVO.motionmag(i,j) + motionmag(j,i))
+    ii_f, jj_f, kk_f = S.replay_graph(40)
+    a, b = pops.motionmag_pair(poses.to(dev), patches.to(dev), intr.to(dev), ii_f.to(dev), jj_f.to(dev), kk_f.to(dev), 35, 37, beta=0.5)
+    for (qi, qj, got) in ((35, 37, a), (37, 35, b)):
+        msk = (ii_f == qi) & (jj_f == qj)
+        rf2, _ = oracle.flow_mag(poses.numpy(), patches.numpy(), intr.numpy(), ii_f[msk].numpy(), jj_f[msk].numpy(), kk_f[msk].numpy(), beta=0.5)
+        assert msk.sum() == 96 and abs(got - rf2.mean()) < 2e-3 * max(1.0, abs(rf2.mean()))
+    a, b = pops.motionmag_pair(poses.to(dev), patches.to(dev), intr.to(dev), ii_f.to(dev), jj_f.to(dev), kk_f.to(dev), 3, 39)
+    assert a != a and b != b          # no such edges: NaN like torch's mean of an empty tensor
     m = 40 * 96
     ix = torch.arange(m) // 96
     pts = pops.point_cloud(poses.to(dev), patches[:m].to(dev), intr.to(dev), ix.to(dev))
