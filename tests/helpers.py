@@ -63,3 +63,25 @@ def assert_close(a, b, atol, rtol, what=""):
     a = np.where(nan_a, 0, a); b = np.where(nan_b, 0, b)
     err = np.abs(a - b) - (atol + rtol * np.abs(b))
     assert (err <= 0).all(), f"{what}: max abs err {np.abs(a - b).max():.3e} (atol {atol}, rtol {rtol}), worst excess {err.max():.3e}"
+
+
+def golden_update_case(UpdateCls):
+    """Seeded weights + inputs of tests/golden/update.npz (shared by make_golden.py, which instantiates the
+    REFERENCE's Update class, and by the tests, which instantiate dpvo_amd.net.Update: same construction order,
+    same RNG stream -> identical parameters; the fixture stores checksums to prove it)."""
+    torch.manual_seed(1234)
+    upd = UpdateCls(3).double()
+    with torch.no_grad():
+        for p in upd.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    ii, jj, kk = S.replay_graph(9, S.GraphCfg(M=4, REMOVAL_WINDOW=10, PATCH_LIFETIME=5))
+    E = ii.numel()
+    g = torch.Generator().manual_seed(5)
+    net = torch.randn(1, E, 384, generator=g).double(); inp = torch.randn(1, E, 384, generator=g).double()
+    corr = torch.randn(1, E, 882, generator=g).double()
+    return upd, net, inp, corr, ii, jj, kk
+
+
+def state_checksums(sd):
+    return {k: float(v.double().abs().sum()) for k, v in sd.items()}

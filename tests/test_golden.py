@@ -1,0 +1,88 @@
+"""Oracle (and, on the GPU box, the HIP kernels) against the golden fixtures under tests/golden/, which were produced
+by importing the REFERENCE'S OWN PYTHON (tests/golden/make_golden.py): Update.forward / SoftAgg / GatedResidual,
+pops.transform / flow_mag / point_cloud, altcorr.patchify's bilinear glue and reduce_edges.  The fixtures are f64
+reference outputs, so the oracle must match them to ~1e-9 (f32 storage: 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def test_pops_golden(oracle):
+    d = _load("pops")
+    co = oracle.reproject(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"])
+    assert np.allclose(co, d["coords"], atol=1e-8, rtol=1e-10)
+    fl, val = oracle.flow_mag(d["poses"], d["patches"], d["intr"], d["ii"], d["jj"], d["kk"], beta=0.5)
+    assert np.allclose(fl, d["flow"], atol=1e-8) and np.array_equal(val, d["valid"])
+    pts = oracle.point_cloud(d["poses"], d["patches"], d["intr"], np.arange(14 * 8) // 8)
+    assert np.allclose(pts, d["points"], atol=1e-8)
+
+
+def test_patchify_golden(oracle):
+    d = _load("patchify")
+    assert np.allclose(oracle.patchify(d["net"], d["coords"], 1), d["out"], atol=1e-12)
+
+
+def test_reduce_edges_golden(oracle):
+    from dpvo_amd.patchgraph import reduce_edges
+    d = _load("reduce_edges")
+    for cap, key in ((1000, "edges"), (5, "edges_cap5")):
+        assert np.array_equal(oracle.reduce_edges(d["flow"], d["ii"], d["jj"], cap, 1), d[key])
+        assert np.array_equal(reduce_edges(d["flow"], d["ii"], d["jj"], cap, 1), d[key])      # product host code
+
+
+def _update_case():
+    from dpvo_amd.net import Update
+    d = _load("update")
+    upd, net, inp, corr, ii, jj, kk = H.golden_update_case(Update)
+    cs = H.state_checksums(upd.state_dict())
+    assert list(d["ck_names"]) == sorted(cs)
+    assert np.allclose([cs[k] for k in sorted(cs)], d["ck_vals"], rtol=1e-12), "weights differ from the fixture's"
+    assert np.allclose([float(net.abs().sum()), float(inp.abs().sum()), float(corr.abs().sum())], d["in_ck"], rtol=1e-12)
+    return d, upd, net, inp, corr, ii, jj, kk
+
+
+def test_update_golden(oracle):
+    """oracle/update_ref.py == the reference's Update.forward (f64, no autocast) on the fixture"""
+    from oracle import update_ref
+    d, upd, net, inp, corr, ii, jj, kk = _update_case()
+    saved = (update_ref._h, update_ref._f)
+    update_ref._h = lambda x: x.double(); update_ref._f = lambda x: x.double()
+    try:
+        rn, rd, rw = update_ref.update_forward(upd.state_dict(), net[0], inp[0], corr[0], ii, jj, kk, half_scatter=False)
+    finally:
+        update_ref._h, update_ref._f = saved
+    assert np.allclose(rn.numpy(), d["net_out"], atol=2e-5) and np.allclose(rd.numpy(), d["delta"], atol=2e-5)
+    assert np.allclose(rw.numpy(), d["weight"], atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_against_golden(dev):
+    """the HIP kernels against the reference-generated fixtures directly (f16/f32 tolerances of the op tests)"""
+    from dpvo_amd import altcorr
+    from dpvo_amd import projective_ops as pops
+    d = _load("pops")
+    t = lambda k: torch.from_numpy(d[k]).to(dev)
+    co = pops.transform_coords(t("poses"), t("patches"), t("intr"), t("ii"), t("jj"), t("kk"))
+    H.assert_close(co[0].cpu().numpy(), d["coords"], 2e-3, 1e-5, "reproject vs reference golden")
+    fl, val = pops.flow_mag(t("poses"), t("patches"), t("intr"), t("ii"), t("jj"), t("kk"), beta=0.5)
+    H.assert_close(fl.cpu().numpy(), d["flow"].reshape(len(d["ii"]), -1).mean(1), 2e-3, 1e-4, "flow_mag vs golden")
+    p = _load("patchify")
+    out = altcorr.patchify(torch.from_numpy(p["net"]).float()[None].to(dev), torch.from_numpy(p["coords"]).float()[None].to(dev), 1)
+    H.assert_close(out[0].cpu().numpy(), p["out"], 1e-5, 1e-5, "patchify vs golden")
+    # update operator: f16 GEMM operands vs the reference's f64 run -> tolerance of the update tests
+    d2, upd, net, inp, corr, ii, jj, kk = _update_case()
+    upd = upd.float().to(dev)
+    out, (dl, w, _) = upd(net.float().to(dev), inp.half().to(dev), corr.half().to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
+    H.assert_close(out[0].cpu().numpy(), d2["net_out"], 3e-2, 2e-2, "update net vs reference golden")
+    H.assert_close(dl[0].cpu().numpy(), d2["delta"], 2e-2, 2e-2, "update delta vs reference golden")
+    H.assert_close(w[0].cpu().numpy(), d2["weight"], 1e-2, 1e-2, "update weight vs reference golden")

@@ -1,0 +1,212 @@
+"""CPU tests of the oracle itself (the checker must be right before it checks anything).
+
+* lietorch's own algebraic identities (reference dpvo/lietorch/run_tests.py:16-52) on the SE3 restatement, f64 atol 1e-8
+  exactly as the reference states them;
+* cross-checks: Schur-complement BA step == dense normal-equation solve; neighbours vs brute force; unique vs numpy;
+  correlation of a map with itself at integer coordinates = squared norm; out-of-bounds = 0; convergence of BA on a
+  noise-free scene;
+* the update-operator restatement against plain torch modules (f32, no rounding emulation)."""
+import numpy as np
+import pytest
+import torch
+
+from dpvo_amd import synthetic as S
+from tests import helpers as H
+
+
+def test_se3_identities_run_tests_py(oracle):
+    rng = np.random.default_rng(0)
+    a = .2 * rng.standard_normal((2, 3, 4, 5, 6))
+    b = oracle.se3_log(oracle.se3_exp(a))
+    assert np.allclose(a, b, atol=1e-8)                                   # test_exp_log (:16-21)
+    X = oracle.se3_exp(.1 * rng.standard_normal((2, 3, 4, 5, 6)))
+    c = oracle.se3_log(oracle.se3_mul(X, oracle.se3_inv(X)))
+    assert np.allclose(c, 0, atol=1e-8)                                   # test_inv (:23-28)
+    # test_act (:44-52): act vs the 4x4 matrix built from the quaternion
+    X = oracle.se3_exp(rng.standard_normal((50, 6)))
+    p = rng.standard_normal((50, 3))
+    p4 = np.concatenate([p, np.ones((50, 1))], -1)
+    q = X[:, 3:]
+    x, y, z, w = q.T
+    Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                   2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                   2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(50, 3, 3)
+    ref = np.einsum('nij,nj->ni', Rm, p) + X[:, :3]
+    assert np.allclose(oracle.se3_act4(X, p4)[:, :3], ref, atol=1e-8)
+    # test_adj (:30-41) restated without an adjoint op: X * Exp(a) * X^-1 == Exp(Ad_X a); check via group law only
+    A = oracle.se3_exp(.3 * rng.standard_normal((50, 6)))
+    lhs = oracle.se3_mul(oracle.se3_mul(X, A), oracle.se3_inv(X))
+    assert np.allclose(oracle.se3_mul(lhs, X), oracle.se3_mul(X, A), atol=1e-8)
+    # small-angle branches
+    tiny = np.zeros((3, 6)); tiny[1, 3] = 1e-9; tiny[2, :3] = 1.0
+    assert np.allclose(oracle.se3_log(oracle.se3_exp(tiny)), tiny, atol=1e-12)
+    # f32 variant agrees with f64
+    assert np.allclose(oracle.se3_exp(a.reshape(-1, 6), dtype=np.float32), oracle.se3_exp(a.reshape(-1, 6)), atol=1e-6)
+
+
+def test_neighbors_unique_bruteforce(oracle):
+    ii, jj, kk = S.replay_graph(20, S.GraphCfg(M=8, REMOVAL_WINDOW=10, PATCH_LIFETIME=6))
+    g = torch.Generator().manual_seed(0)
+    p = torch.randperm(ii.numel(), generator=g)
+    kk, jj = kk[p].numpy(), jj[p].numpy()
+    kk = np.concatenate([kk, kk[:50]]); jj = np.concatenate([jj, jj[:50]])           # duplicates -> stability matters
+    ix, jx = oracle.neighbors(kk, jj)
+    for e in range(0, kk.size, 7):
+        same = np.where(kk == kk[e])[0]
+        order = same[np.argsort(jj[same], kind="stable")]
+        pos = int(np.where(order == e)[0][0])
+        assert ix[e] == (order[pos - 1] if pos > 0 else -1)
+        assert jx[e] == (order[pos + 1] if pos < order.size - 1 else -1)
+    u, inv = oracle.unique(kk)
+    u2, inv2 = np.unique(kk, return_inverse=True)
+    assert np.array_equal(u, u2) and np.array_equal(inv, inv2)
+    assert oracle.unique(np.zeros(0, np.int64))[0].size == 0
+
+
+def test_reduce_edges_matches_python_restatement(oracle):
+    from dpvo_amd.patchgraph import reduce_edges
+    rng = np.random.default_rng(1)
+    for n in (0, 5, 400):
+        ii = rng.integers(0, 60, n); jj = rng.integers(20, 120, n)
+        fm = rng.random(n) * 100
+        fm[::9] = np.inf
+        a = oracle.reduce_edges(fm, ii, jj, 1000, 1)
+        b = reduce_edges(fm, ii.astype(np.int64), jj.astype(np.int64), 1000, 1)
+        assert np.array_equal(a, b)
+        if n:
+            assert ((a[:, 1] - a[:, 0]) >= 30).all()
+    ii = np.arange(40); jj = ii + 40
+    assert len(oracle.reduce_edges(np.ones(40), ii, jj, 5, 0)) == 5          # max_num_edges cap
+
+
+def test_corr_properties(oracle):
+    g = torch.Generator().manual_seed(0)
+    C, Hh, W, P = 16, 12, 14, 3
+    f2 = torch.randn(2, C, Hh, W, generator=g).numpy()
+    # fmap1 = the 3x3 patch of frame 0 around (6,5): at integer coords the centre of the window is |f|^2
+    cx, cy = 6, 5
+    f1 = f2[0][:, cy - 1:cy + 2, cx - 1:cx + 2][None].copy()
+    off = np.arange(3) - 1
+    coords = np.stack([np.broadcast_to(cx + off[None, :], (3, 3)), np.broadcast_to(cy + off[:, None], (3, 3))], 0)[None].astype(np.float64)
+    out = oracle.corr_forward(f1, f2, coords, np.array([0]), np.array([0]), 3)      # [1, x, y, P, P]
+    for i0 in range(3):
+        for j0 in range(3):
+            v = f2[0][:, cy - 1 + i0, cx - 1 + j0]
+            assert np.isclose(out[0, 3, 3, i0, j0], (v * v).sum())
+    # axis convention: out[e, x, y]: moving +1 in x looks at the pixel to the right
+    v0 = f2[0][:, cy, cx]; vr = f2[0][:, cy, cx + 1]; vd = f2[0][:, cy + 1, cx]
+    assert np.isclose(out[0, 4, 3, 1, 1], (v0 * vr).sum()) and np.isclose(out[0, 3, 4, 1, 1], (v0 * vd).sum())
+    # out of bounds -> exactly 0; bilinear: half-pixel shift = mean of neighbours
+    far = coords + 1000
+    assert (oracle.corr_forward(f1, f2, far, np.array([0]), np.array([0]), 3) == 0).all()
+    half = coords + np.array([0.5, 0.0]).reshape(1, 2, 1, 1)
+    oh = oracle.corr_forward(f1, f2, half, np.array([0]), np.array([0]), 3)
+    assert np.isclose(oh[0, 3, 3, 1, 1], 0.5 * ((v0 * v0).sum() + (v0 * vr).sum()))
+    # pyramid stacking order (dpvo.py:207): feature index ((x*7+y)*3+i0)*3+j0)*2+level
+    f2b = torch.randn(2, C, 3, 4, generator=g).numpy()
+    pyr = oracle.corr_pyramid(f1, [f2, f2b], coords[0][None], np.array([0]), np.array([0]))
+    assert pyr.shape == (1, 882)
+    assert np.isclose(pyr[0, (((3 * 7 + 3) * 3 + 1) * 3 + 1) * 2 + 0], (v0 * v0).sum())
+    # patchify: integer coords reproduce the window, OOB zeros
+    net = torch.randn(5, 9, 11, generator=g).numpy()
+    pt = oracle.patchify(net, np.array([[4.0, 3.0], [0.0, 0.0], [4.5, 3.0]]), 1)
+    assert np.allclose(pt[0], net[:, 2:5, 3:6])
+    assert (pt[1][:, 0, :] == 0).all() and (pt[1][:, :, 0] == 0).all() and np.allclose(pt[1][:, 1:, 1:], net[:, :2, :2])
+    assert np.allclose(pt[2], 0.5 * (net[:, 2:5, 3:6] + net[:, 2:5, 4:7]))
+
+
+def test_ba_schur_equals_full_solve_and_converges(oracle):
+    ii, jj, kk, cfg = H.small_graph(14, 8)
+    poses, patches, intr = S.make_scene(14, M=8, ht=48, wd=64)
+    iin, jjn, kkn = ii.numpy(), jj.numpy(), kk.numpy()
+    co = oracle.reproject(poses.numpy(), patches.numpy(), intr.numpy(), iin, jjn, kkn)
+    rng = np.random.default_rng(0)
+    target = co[:, :, 1, 1] + 0.5 * rng.standard_normal((iin.size, 2))
+    weight = rng.random((iin.size, 2))
+    p0 = poses.numpy().astype(np.float64)
+    # one iteration of the reference's Schur form == solving the full damped normal equations
+    p1, pat1, info, _ = oracle.ba(p0, patches.numpy(), intr.numpy(), target, weight, 1e-4, iin, jjn, kkn, 9, 14, iterations=1)
+    dX, dZ, kx, info2 = oracle.ba_full_solve(p0, patches.numpy(), intr.numpy(), target, weight, 1e-4, iin, jjn, kkn, 9, 14)
+    assert info == 0 and info2 == 0
+    d_ref = np.maximum(np.where(patches.numpy()[kx, 2, 1, 1] + dZ > 20, 1.0, patches.numpy()[kx, 2, 1, 1] + dZ), 1e-4)
+    assert np.allclose(pat1[kx, 2, 1, 1], d_ref, atol=1e-9)
+    # retraction: left multiplication by Exp(dX) (ba_cuda.cu:157-174); compare through the SE3 oracle
+    for a in range(5):
+        expd = oracle.se3_exp(dX[6 * a:6 * a + 6][None])
+        ref = oracle.se3_mul(expd, p0[9 + a][None])[0]
+        assert np.allclose(p1[9 + a], ref, atol=1e-7)
+    assert np.array_equal(p1[:9], p0[:9])
+    # convergence on a noise-free scene from perturbed poses
+    tgt = co[:, :, 1, 1]
+    p2 = p0.copy(); p2[10:, :3] += 0.01 * rng.standard_normal((4, 3))
+    pn, _, _, rt = oracle.ba(p2, patches.numpy(), intr.numpy(), tgt, np.ones_like(tgt), 1e-4, iin, jjn, kkn, 9, 14, iterations=4)
+    assert rt[-1] < 1e-6 * rt[0] and np.abs(pn - p0)[:, :3].max() < 1e-6
+    # f32 mode tracks f64
+    pf, patf, _, _ = oracle.ba(p0, patches.numpy(), intr.numpy(), target, weight, 1e-4, iin, jjn, kkn, 9, 14, iterations=2, dtype=np.float32)
+    pd_, patd, _, _ = oracle.ba(p0, patches.numpy(), intr.numpy(), target, weight, 1e-4, iin, jjn, kkn, 9, 14, iterations=2)
+    assert np.allclose(pf, pd_, atol=2e-4) and np.allclose(patf[:, 2], patd[:, 2], atol=2e-4, rtol=2e-3)
+
+
+def test_reproject_matches_matrix_formulation(oracle):
+    poses, patches, intr = S.make_scene(12, M=8, ht=48, wd=64)
+    ii, jj, kk, _ = H.small_graph(12, 8)
+    co = oracle.reproject(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy())
+    # independent formulation with 4x4 matrices in numpy
+    def mat(p):
+        x, y, z, w = p[3:] / np.linalg.norm(p[3:])
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = p[:3]
+        return T
+    P = poses.numpy().astype(np.float64); K = intr.numpy().astype(np.float64); pt = patches.numpy().astype(np.float64)
+    for e in range(0, ii.numel(), 37):
+        i, j, k = int(ii[e]), int(jj[e]), int(kk[e])
+        G = mat(P[j]) @ np.linalg.inv(mat(P[i]))
+        X0 = np.stack([(pt[k, 0] - K[i, 2]) / K[i, 0], (pt[k, 1] - K[i, 3]) / K[i, 1], np.ones((3, 3)), pt[k, 2]], -1)
+        X1 = X0 @ G.T
+        d = 1.0 / np.maximum(X1[..., 2], 0.1)
+        assert np.allclose(co[e, 0], K[j, 0] * d * X1[..., 0] + K[j, 2], atol=1e-8)
+        assert np.allclose(co[e, 1], K[j, 1] * d * X1[..., 1] + K[j, 3], atol=1e-8)
+
+
+def test_update_ref_against_plain_torch_modules():
+    """oracle/update_ref.py with all f16 rounding disabled must equal a straightforward f64 torch implementation
+    of net.py:74-92 built from nn modules (scatter ops written with index_add / scatter_reduce)."""
+    from oracle import update_ref
+    from dpvo_amd.net import Update
+    torch.manual_seed(0)
+    upd = Update(3).double()
+    sd = {k: v.clone() for k, v in upd.state_dict().items()}
+    ii, jj, kk, _ = H.small_graph(10, 4)
+    E = ii.numel()
+    g = torch.Generator().manual_seed(1)
+    net = torch.randn(E, 384, generator=g).double(); inp = torch.randn(E, 384, generator=g).double()
+    corr = torch.randn(E, 882, generator=g).double()
+    saved = (update_ref._h, update_ref._f)
+    update_ref._h = lambda x: x.double(); update_ref._f = lambda x: x.double()
+    try:
+        rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
+    finally:
+        update_ref._h, update_ref._f = saved
+    import oracle
+    with torch.no_grad():
+        x = net + inp + upd.corr(corr)
+        x = upd.norm(x)
+        ix, jx = oracle.neighbors(kk.numpy(), jj.numpy())
+        ix = torch.from_numpy(ix); jx = torch.from_numpy(jx)
+        x = x + upd.c1((ix >= 0).double()[:, None] * x[ix])
+        x = x + upd.c2((jx >= 0).double()[:, None] * x[jx])
+        for agg, keys in ((upd.agg_kk, kk), (upd.agg_ij, ii * 12345 + jj)):
+            _, inv = torch.unique(keys, return_inverse=True)
+            n = int(inv.max()) + 1
+            gx = agg.g(x); fx = agg.f(x)
+            mx = torch.full((n, 384), -float("inf"), dtype=torch.double).scatter_reduce(0, inv[:, None].expand(-1, 384), gx, "amax")
+            ex = torch.exp(gx - mx[inv]); sm = torch.zeros(n, 384, dtype=torch.double).index_add(0, inv, ex)
+            y = torch.zeros(n, 384, dtype=torch.double).index_add(0, inv, fx * ex / sm[inv])
+            x = x + agg.h(y)[inv]
+        for ln, gr in ((upd.gru[0], upd.gru[1]), (upd.gru[2], upd.gru[3])):
+            x = ln(x)
+            x = x + gr.gate(x) * gr.res(x)
+        d = upd.d(x); w = upd.w(x)
+    assert torch.allclose(rn, x, atol=1e-9) and torch.allclose(rd, d, atol=1e-9) and torch.allclose(rw, w, atol=1e-9)
