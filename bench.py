@@ -59,8 +59,13 @@ def cpu_baseline():
     from dpvo_amd import synthetic as S
     from dpvo_amd.net import Update
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)     # the oracle's OpenMP loop and torch-CPU both capped at 16 threads
     torch.set_num_threads(cores)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     ii, jj, kk = S.replay_graph(40)
     E = ii.numel()
     gmap, f0, f1, imap = S.make_features()
@@ -131,29 +136,21 @@ def main():
     def step(t):
         slam(float(t), frames[t % n_img], intr)
 
+    from dpvo_amd import multiseq
+    clock = multiseq.Clock(dist=dist, device=device)
     with torch.no_grad():
         for t in range(args.warmup):
             step(t)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
         corr_mod.PROFILE = []
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        clock.start()                                 # barrier + torch.cuda.synchronize()
         for t in range(args.warmup, total):
             step(t)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+        local = clock.stop()                          # torch.cuda.synchronize() + barrier
     prof = corr_mod.PROFILE
     corr_mod.PROFILE = None
     E_now = int(slam.pg.ii.numel())
-
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    res = multiseq.gather_results(args.steps, local, dist=dist, device=device)
+    elapsed = res["seconds"]                          # max over ranks
 
     corr_ms = [s.elapsed_time(e) for s, e, _ in prof]
     corr_edges = [n for _, _, n in prof]
