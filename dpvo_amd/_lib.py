@@ -25,6 +25,7 @@ SYMBOLS = [
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
     "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
+    "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
 ]
 
 
@@ -52,7 +53,8 @@ def lib():
         for s in SYMBOLS:
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
-        for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes"):
+        for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
+                  "dpvo_gba_workspace_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
         _lib = L
     return _lib

@@ -54,7 +54,7 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M,
     N = t1 - t0
     if eff_impl or 6 * N > 120:
         from .global_ba import global_BA
-        return global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations)
+        return global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, plan=plan)
     ii = ii.long().contiguous(); jj = jj.long().contiguous(); kk = kk.long().contiguous()
     target = target.reshape(-1, 2).float().contiguous()
     weight = weight.reshape(-1, 2).float().contiguous()

@@ -1,14 +1,54 @@
-"""Global bundle adjustment (reference: eff_impl=True, dpvo/fastba/block_e.cu:43-300, dpvo.py:312-326).
+"""Global bundle adjustment (reference: eff_impl=True, dpvo/fastba/block_e.cu:43-300, ba_cuda.cu:538-550; caller
+DPVO.__run_global_BA, dpvo/dpvo.py:312-326).
 
-Routed here when `eff_impl=True` or when more than 20 poses are free (6N > 120, beyond the dense in-LDS Schur path
-of dpvo_amd/csrc/ba.hip).  The block-sparse device path (E_lookup blocks + rocSOLVER potrf/potrs for 6N up to ~6000)
-is the next SURVEY.md section-8 row to build (BASELINE config 5, LOOP_CLOSURE=True); it is NOT implemented yet and
-fails loudly instead of falling back to anything else.
-"""
+Routed here when `eff_impl=True` or when more than 20 poses are free (beyond the in-LDS dense Schur path).
+Linearisation, block-sparse Schur complement and the retractions are HIP kernels (dpvo_amd/csrc/ba_global.hip);
+the 6N x 6N damped system is factorised by rocSOLVER through ATen (`torch.linalg.cholesky_ex` + `cholesky_solve`),
+exactly the division of labour of the reference (ba_cuda.cu:546-548)."""
+import ctypes
+
+import torch
+
 from .. import _lib as L
+from .. import workspace
+from ..graph import GraphPlan
 
 
-def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations):
-    raise L.DPVOHipError(
-        f"global BA with {t1 - t0} free poses (eff_impl) is not implemented yet in dpvo_amd "
-        "(dense Schur path covers t1 - t0 <= 20); LOOP_CLOSURE=True configurations are the next scope row")
+def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, plan=None):
+    P = patches.shape[-1]
+    E = ii.numel()
+    N = t1 - t0
+    if E == 0 or N <= 0:
+        raise L.DPVOHipError("global BA needs edges and at least one free pose")
+    ii = ii.long().contiguous(); jj = jj.long().contiguous(); kk = kk.long().contiguous()
+    target = target.reshape(-1, 2).float().contiguous()
+    weight = weight.reshape(-1, 2).float().contiguous()
+    if plan is None:
+        plan = GraphPlan(ii, jj, kk)
+    kmin, kmax = int(kk.min().item()), int(kk.max().item())
+    f0 = kmin // M
+    n_frames = kmax // M - f0 + 1
+    lm = float(lmbda) if not torch.is_tensor(lmbda) else float(lmbda.reshape(-1)[0].item())
+    nbytes = L.lib().dpvo_gba_workspace_bytes(L.i64(E), L.i64(plan.n_pairs_host), L.i64(n_frames), L.i32(M))
+    ws = workspace.get(nbytes, poses.device, "gba")
+    n6 = 6 * N
+    dev = poses.device
+    infos = []
+    for _ in range(iterations):
+        S = torch.zeros(n6, n6, dtype=torch.float32, device=dev)
+        y = torch.zeros(n6, dtype=torch.float32, device=dev)
+        L.check(L.lib().dpvo_gba_linearize(
+            L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight), L.f32(lm), L.ptr(ii), L.ptr(jj),
+            L.ptr(kk), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(E), L.i32(P), L.i32(M),
+            L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(S), L.ptr(y), L.ptr(ws), ctypes.c_size_t(ws.numel()),
+            L.stream()), "dpvo_gba_linearize")
+        d = S.diagonal()
+        d.add_(1e-4 * d + 1.0)                                    # S += I * (1e-4 * S + 1.0)   (ba_cuda.cu:546)
+        U, info = torch.linalg.cholesky_ex(S)                      # info ignored by the reference (:547)
+        dX = torch.cholesky_solve(y[:, None], U)[:, 0].contiguous()
+        infos.append(info)
+        L.check(L.lib().dpvo_gba_retract(
+            L.ptr(poses), L.ptr(patches), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(E),
+            L.i32(P), L.i32(M), L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(dX), L.ptr(ws),
+            ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_gba_retract")
+    return []

@@ -223,6 +223,23 @@ int dpvo_ba(float* poses, float* patches, const float* intrinsics, const float* 
             int64_t n_patches_hint, int64_t n_pairs_hint, int64_t E, int P, int t0, int t1, int iterations,
             int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
+/* Global BA == cuda_ba.forward(..., eff_impl=True) (ba_cuda.cu:475-478,538-550 with EfficentE, block_e.cu:43-300),
+ * used by DPVO.__run_global_BA (dpvo/dpvo.py:312-326).  One Gauss-Newton iteration is
+ *     zero S[6N,6N], y[6N];  dpvo_gba_linearize -> S = B - E Q E^T, y = v - E Q u  (block-sparse E, device plan);
+ *     host: S += I*(1e-4*S + 1), dX = cholesky_solve(y, cholesky(S))   (rocSOLVER via ATen, as the reference);
+ *     dpvo_gba_retract(dX) -> dZ = Q (u - E^T dX), depth and pose retraction in place.
+ * f0 / n_frames: first source frame that owns a patch in kk and the number of frames up to the last one
+ * (patch p belongs to frame p / M); M = patches per frame (PPF); plan from dpvo_plan_build(ii,jj,kk);
+ * the same `ws` (dpvo_gba_workspace_bytes) must be passed to both calls of one iteration. */
+size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n_frames, int M);
+int dpvo_gba_linearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
+                       const float* weight, float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk,
+                       const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E, int P, int M, int f0,
+                       int n_frames, int t0, int t1, float* S, float* y, void* ws, size_t ws_bytes, void* stream);
+int dpvo_gba_retract(float* poses, float* patches, const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E,
+                     int P, int M, int f0, int n_frames, int t0, int t1, const float* dX, void* ws, size_t ws_bytes,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

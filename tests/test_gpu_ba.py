@@ -87,3 +87,38 @@ def test_ba_converges_full_size(oracle, dev):
               M=96, iterations=4)
     assert (pd.cpu() - poses)[:, :3].abs().max() < 2e-4
     assert ((ptd.cpu() - patches)[:, 2].abs() / patches[:, 2]).max() < 5e-3
+
+
+@pytest.mark.parametrize("case", ["eff_small", "many_free", "loop_edges"])
+def test_global_ba_vs_oracle(oracle, dev, case):
+    """eff_impl=True / N > 20 free poses: block-sparse Schur + rocSOLVER Cholesky vs the oracle's dense algebra (f64).
+    (block_e.cu is a sparse storage of the same E, so the dense oracle is the restatement for both paths.)"""
+    M = 8
+    cfg = S.GraphCfg(M=M, REMOVAL_WINDOW=30, PATCH_LIFETIME=6)
+    n = 40
+    ii, jj, kk = S.replay_graph(n, cfg)
+    if case == "loop_edges":
+        # long-range edges: patches of frames 2..5 observed in frames 33..36, plus duplicates of existing edges
+        ks = torch.arange(2 * M, 6 * M).repeat_interleave(4)
+        js = torch.arange(33, 37).repeat(4 * M)
+        ii = torch.cat([ii, ks // M, ii[:40]]); jj = torch.cat([jj, js, jj[:40]]); kk = torch.cat([kk, ks, kk[:40]])
+    t0, t1 = {"eff_small": (30, 40), "many_free": (5, 40), "loop_edges": (1, 40)}[case]
+    poses, patches, intr, target, weight = _problem(ii, jj, kk, n, M, oracle, seed=3)
+    rp, rpat, info, _ = oracle.ba(poses.numpy(), patches.numpy(), intr.numpy(), target.numpy(), weight.numpy(), 1e-4,
+                                  ii.numpy(), jj.numpy(), kk.numpy(), t0, t1, iterations=2)
+    assert info == 0
+    pd, ptd = poses.clone().to(dev), patches.clone().to(dev)
+    ret = fastba.BA(pd.view(1, -1, 7), ptd.view(1, -1, 3, 3, 3), intr.to(dev).view(1, -1, 4), target.to(dev)[None],
+                    weight.to(dev)[None], 1e-4, ii.to(dev), jj.to(dev), kk.to(dev), t0, t1, M=M, iterations=2,
+                    eff_impl=True)
+    assert ret == []
+    assert torch.equal(pd[:t0].cpu(), poses[:t0])
+    H.assert_close(pd.cpu().numpy(), rp, 3e-4, 1e-4, f"global BA poses [{case}]")
+    H.assert_close(ptd.cpu().numpy()[:, 2], rpat[:, 2], 3e-4, 3e-3, f"global BA depths [{case}]")
+    if case == "eff_small":
+        # the dense in-LDS path and the block-sparse path solve the same system
+        pd2, ptd2 = poses.clone().to(dev), patches.clone().to(dev)
+        fastba.BA(pd2, ptd2, intr.to(dev), target.to(dev), weight.to(dev), 1e-4, ii.to(dev), jj.to(dev), kk.to(dev), t0, t1,
+                  M=M, iterations=2, eff_impl=False)
+        H.assert_close(pd.cpu().numpy(), pd2.cpu().numpy(), 1e-4, 1e-4, "dense vs block-sparse poses")
+        H.assert_close(ptd.cpu().numpy()[:, 2], ptd2.cpu().numpy()[:, 2], 1e-4, 1e-3, "dense vs block-sparse depths")
