@@ -80,3 +80,33 @@ def test_run_to_run_determinism(dev):
     assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n])
     assert torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
     assert torch.equal(a.pg.net, b.pg.net)
+
+
+def test_loop_closure_global_ba_path(dev):
+    """BASELINE config 5 plumbing (LOOP_CLOSURE=True): edges_loop -> reduce_edges -> append, normalize(), global BA."""
+    from oracle.graph_ref import GraphRef  # noqa: F401  (import check only)
+    cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
+    cfg.PATCHES_PER_FRAME = 16
+    cfg.BUFFER_SIZE = 256
+    cfg.LOOP_CLOSURE = True
+    cfg.MAX_EDGE_AGE = 100
+    cfg.KEYFRAME_THRESH = -1.0
+    torch.manual_seed(0)
+    ht, wd = 96, 128
+    slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev)
+    slam.motion_probe = lambda: 1e9
+    g = torch.Generator().manual_seed(0)
+    intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
+    saw_loop = False
+    for t in range(75):
+        img = torch.randint(0, 255, (3, ht, wd), generator=g, dtype=torch.uint8).to(dev)
+        slam(float(t), img, intr)
+        if slam.pg.ii.numel():
+            saw_loop = saw_loop or bool(((slam.pg.jj - slam.pg.ii) > 30).any())
+    assert saw_loop, "no loop-closure edges were created"
+    assert slam.ran_global_ba.any(), "global BA never ran"
+    n = slam.n
+    assert torch.isfinite(slam.pg.poses_[:n]).all() and torch.isfinite(slam.pg.patches_[:n]).all()
+    assert (slam.pg.patches_[:n, :, 2] > 0).all()
+    poses, tstamps = slam.terminate()
+    assert poses.shape == (75, 7) and np.isfinite(poses).all()
