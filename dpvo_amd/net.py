@@ -21,7 +21,7 @@ EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 
 
 # ------------------------------------------------------------------------------------------ kernels' Python face
-def linear(A, W, bias, out=None, epilogue=EPI_NONE, rows=None, gate=None, n_split=0, K=None):
+def linear(A, W, bias, out=None, epilogue=EPI_NONE, rows=None, gate=None, n_split=0, K=None, out16=None):
     """dpvo_linear: A [M,>=K] f16/f32 (row stride = A.stride(0)), W [N,K] f16, bias [N] f16."""
     M = A.shape[0]
     N = W.shape[0]
@@ -33,7 +33,8 @@ def linear(A, W, bias, out=None, epilogue=EPI_NONE, rows=None, gate=None, n_spli
         out = torch.empty(M, N, dtype=torch.float16, device=A.device)
     L.check(L.lib().dpvo_linear(L.ptr(A), L.i32(L.dtype_code(A.dtype)), L.i64(A.stride(0)), L.ptr(rows), L.ptr(W),
                                 L.i64(W.stride(0)), L.ptr(bias), L.ptr(out), L.i64(out.stride(0)), L.ptr(gate),
-                                L.i64(gate.stride(0) if gate is not None else 0), L.i32(epilogue), L.i32(n_split),
+                                L.i64(gate.stride(0) if gate is not None else 0), L.ptr(out16),
+                                L.i64(out16.stride(0) if out16 is not None else 0), L.i32(epilogue), L.i32(n_split),
                                 L.i64(M), L.i32(N), L.i32(K), L.stream()), "dpvo_linear")
     return out
 
@@ -55,9 +56,9 @@ def softagg(fg, perm, off, n_groups_dev, n_groups):
     return y
 
 
-def gather_add(net, hy, group):
-    L.check(L.lib().dpvo_gather_add(L.ptr(net), L.ptr(hy), L.ptr(group), L.i64(net.shape[0]), L.i32(DIM), L.stream()),
-            "dpvo_gather_add")
+def gather_add(net, hy, group, net16=None):
+    L.check(L.lib().dpvo_gather_add(L.ptr(net), L.ptr(hy), L.ptr(group), L.ptr(net16), L.i64(net.shape[0]), L.i32(DIM),
+                                    L.stream()), "dpvo_gather_add")
 
 
 def heads(net, Wd, bd, Ww, bw):
@@ -190,24 +191,26 @@ class Update(nn.Module):
         layernorm(h2, P["cln"][0], P["cln"][1], y_f16=h1, relu_f16=True)
         c = linear(h1, P["c5"][0], P["c5"][1], out=h2)
         x = torch.empty(E, DIM, dtype=torch.float32, device=dev)
-        layernorm(net2, P["norm"][0], P["norm"][1], add1=inp2, add1_rows=inp_rows, add1_mod=inp_mod, add2=c, y_f32=x)
+        x16 = torch.empty(E, DIM, dtype=torch.float16, device=dev)      # f16 operand image of `net`, kept in step
+        layernorm(net2, P["norm"][0], P["norm"][1], add1=inp2, add1_rows=inp_rows, add1_mod=inp_mod, add2=c, y_f32=x,
+                  y_f16=x16)
 
         # net = net + c1(mask_ix * net[:,ix]); net = net + c2(mask_jx * net[:,jx])              (net.py:80-85)
         for name, rows in (("c1", plan.ix), ("c2n", plan.jx)):
             W0, b0, W2, b2 = P[name]
-            t = linear(x, W0, b0, out=h1, epilogue=EPI_RELU, rows=rows)
-            linear(t, W2, b2, out=x, epilogue=EPI_RESADD)
+            t = linear(x16, W0, b0, out=h1, epilogue=EPI_RELU, rows=rows)
+            linear(t, W2, b2, out=x, epilogue=EPI_RESADD, out16=x16)
 
         # net = net + agg_kk(net, kk); net = net + agg_ij(net, ii*12345 + jj)                    (net.py:87-88)
         fg = torch.empty(E, 2 * DIM, dtype=torch.float16, device=dev)
-        for name, perm, off, cnt_dev, cnt, grp in (
-                ("akk", plan.perm_k, plan.patch_off, plan.counts[0:1], plan.n_patches_host, plan.ku),
-                ("aij", plan.perm_p, plan.pair_off, plan.counts[1:2], plan.n_pairs_host, plan.pu)):
+        for name, perm, off, cnt_dev, cnt, grp, want16 in (
+                ("akk", plan.perm_k, plan.patch_off, plan.counts[0:1], plan.n_patches_host, plan.ku, True),
+                ("aij", plan.perm_p, plan.pair_off, plan.counts[1:2], plan.n_pairs_host, plan.pu, False)):
             Wfg, bfg, Wh, bh = P[name]
-            linear(x, Wfg, bfg, out=fg)
+            linear(x16, Wfg, bfg, out=fg)
             y = softagg(fg, perm, off, cnt_dev, cnt)
             hy = linear(y, Wh, bh)
-            gather_add(x, hy, grp)
+            gather_add(x, hy, grp, net16=x16 if want16 else None)
 
         # net = self.gru(net): 2 x (LayerNorm, x + gate(x) * res(x))                            (net.py:90)
         for name in ("g0", "g1"):

@@ -172,10 +172,13 @@ int dpvo_neighbors(const int64_t* kk, const int64_t* jj, int64_t* ix, int64_t* j
  * (v_mfma_f32_16x16x32_f16).  A [M,K] f16 or f32 (converted to f16 on load, as autocast does) with
  * leading dimension lda; optional row gather `rows` (int32, -1 -> zero row: the mask_ix * net[:,ix]
  * of net.py:81-85); W [N,K] f16 row-major (torch Linear weight layout) with leading dimension ldw;
- * bias [N] f16; out f16 [M,ldo] or the f32 residual target, see DPVO_EPI_*; K % 32 == 0, N % 16 == 0. */
+ * bias [N] f16; out f16 [M,ldo] or the f32 residual target, see DPVO_EPI_*; K % 32 == 0, N % 16 == 0.
+ * out16 (optional, RESADD / GATED with f16 A only): also store the updated residual row as f16 [M,ld16], the
+ * operand image of the next Linear (autocast would cast it on the fly).
+ * f16 A runs the LDS-DMA kernel (global_load_lds_dwordx4, 3-stage ring); f32 A the register-staged one. */
 int dpvo_linear(const void* A, int a_dtype, int64_t lda, const int32_t* rows, const void* W, int64_t ldw,
-                const void* bias, void* out, int64_t ldo, const void* gate, int64_t ldg, int epilogue, int n_split,
-                int64_t M, int N, int K, void* stream);
+                const void* bias, void* out, int64_t ldo, const void* gate, int64_t ldg, void* out16, int64_t ld16,
+                int epilogue, int n_split, int64_t M, int N, int K, void* stream);
 
 /* Fused "net = LayerNorm(net + inp[inp_rows] + corr)" (net.py:77-78) and plain LayerNorm (eps 1e-3):
  *   x [M,384] f32 or f16 (x_dtype), optional add1 f16 [.,384] gathered by add1_rows (int64 indices
@@ -193,8 +196,8 @@ int dpvo_layernorm(const void* x, int x_dtype, const void* add1, const int64_t* 
 int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, const int32_t* off, const int32_t* n_groups,
                  int64_t max_groups, void* y, int D, void* stream);
 
-/* net[e] += float(hy[group[e]])  -- the `self.h(y)[:,jx]` expand + residual of net.py:87-88. */
-int dpvo_gather_add(float* net, const void* hy, const int32_t* group, int64_t E, int D, void* stream);
+/* net[e] += float(hy[group[e]])  -- the `self.h(y)[:,jx]` expand + residual of net.py:87-88; optional f16 image. */
+int dpvo_gather_add(float* net, const void* hy, const int32_t* group, void* net16, int64_t E, int D, void* stream);
 
 /* Heads: delta = d(net), weight = sigmoid(w(net)) (net.py:61-71,92) as one row-dot kernel;
  * Wd,Ww [2,D] f16, bd,bw [2] f16; outputs f32 [E,2] (the .float() of dpvo.py:339-340 folded in). */
