@@ -1,0 +1,313 @@
+// frontend.hip -- small fused kernels of the per-frame front-end (the callers either side of the hot path:
+// SURVEY.md section 8f "next #2", dpvo/dpvo.py:377-473).  Each replaces a chain of 4..25 tiny torch launches; the
+// frame is launch-bound at > 200 fps, so every launch removed is ~8 us of wall time.
+#include "common.h"
+
+namespace {
+
+// ---- image normalisation (dpvo.py:389) + f16 copy for the encoders: out = 2*(u8/255) - 0.5, same op order -------
+__global__ void normalize_image_kernel(const uint8_t* __restrict__ img, float* __restrict__ f32, _Float16* __restrict__ f16,
+                                       int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // torch divides by a scalar as a multiplication by its f32 reciprocal (BinaryDivTrueKernel): match it bit for bit
+    const float v = 2.0f * ((float)img[i] * (1.0f / 255.0f)) - 0.5f;
+    if (f32) f32[i] = v;
+    if (f16) f16[i] = (_Float16)v;
+  }
+}
+
+// ---- patch colours (dpvo.py:404-405 with net.py:143): colours_[n][m] = uint8((img_norm[c', y, x] + 0.5) * 127.5),
+//      c' = (2,1,0), (x,y) = 4*(centroid + 0.5), zero when out of bounds; same float op order as the reference ------
+__global__ void patch_colors_kernel(const uint8_t* __restrict__ img, const float* __restrict__ coords,
+                                    uint8_t* __restrict__ out, int M, int H, int W) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * M) return;
+  const int m = t / 3, c = t - 3 * m;
+  const float x = 4.0f * (coords[2 * m + 0] + 0.5f), y = 4.0f * (coords[2 * m + 1] + 0.5f);
+  const float fx = floorf(x), fy = floorf(y);
+  const float dx = x - fx, dy = y - fy;
+  const int j0 = (int)fx, i0 = (int)fy;
+  const int cs = 2 - c;                                            // clr[0,:,[2,1,0]]
+  float v[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = i0 + a, j = j0 + b;
+      v[a][b] = (i >= 0 && i < H && j >= 0 && j < W) ? 2.0f * ((float)img[((int64_t)cs * H + i) * W + j] * (1.0f / 255.0f)) - 0.5f : 0.f;
+    }
+  float o = (1.f - dy) * (1.f - dx) * v[0][0];
+  o += (1.f - dy) * dx * v[0][1];
+  o += dy * (1.f - dx) * v[1][0];
+  o += dy * dx * v[1][1];
+  const float f = (o + 0.5f) * (255.0f / 2.0f);
+  out[t] = (uint8_t)(int)f;                                        // tensor.to(torch.uint8): truncation toward zero
+}
+
+// ---- feature ring-buffer store: fmap [C,h,w] (NCHW f16, the encoder output) -> channels-last slot [h,w,C] and the
+//      4x4 average pool [h/4,w/4,C] (dpvo.py:437-438: F.avg_pool2d(fmap,1,1), F.avg_pool2d(fmap,4,4)) ------------
+//      block = one 4x4-pooled row segment: 4 rows x 64 columns x all channels, transposed through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void store_features_kernel(const T* __restrict__ fmap, T* __restrict__ f1,
+                                                             T* __restrict__ f2, int C, int h, int w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);                        // [C][4][65]
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+  const int tid = threadIdx.x;
+  const int nx = min(64, w - x0), ny = min(4, h - y0);
+  for (int idx = tid; idx < C * 4 * 64; idx += 256) {
+    const int x = idx & 63, y = (idx >> 6) & 3, c = idx >> 8;
+    T v = (T)0.f;
+    if (x < nx && y < ny) v = fmap[((int64_t)c * h + y0 + y) * w + x0 + x];
+    tile[(c * 4 + y) * 65 + x] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 4 * 64 * C; idx += 256) {
+    const int c = idx % C, x = (idx / C) & 63, y = idx / (C * 64);
+    if (x < nx && y < ny) f1[(((int64_t)(y0 + y)) * w + x0 + x) * C + c] = tile[(c * 4 + y) * 65 + x];
+  }
+  if (ny == 4) {
+    const int h4 = h / 4, w4 = w / 4;
+    for (int idx = tid; idx < 16 * C; idx += 256) {
+      const int c = idx % C, px = idx / C;
+      if (x0 / 4 + px < w4 && px * 4 + 3 < nx && blockIdx.y < h4) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) s += (float)tile[(c * 4 + a) * 65 + px * 4 + b];
+        f2[(((int64_t)blockIdx.y) * w4 + x0 / 4 + px) * C + c] = (T)(s / 16.0f);
+      }
+    }
+  }
+}
+
+// ---- new edges of a frame (append_factors(edges_forw) + append_factors(edges_back), dpvo.py:215-221,362-375,458-459):
+//      writes kk, jj, ii = ix[kk] for the n_forw + n_back new edges and zeroes their hidden state rows ---------------
+__global__ void append_edges_kernel(int64_t* __restrict__ ii, int64_t* __restrict__ jj, int64_t* __restrict__ kk,
+                                    float* __restrict__ net, const int64_t* __restrict__ ix, int64_t E0, int n, int M,
+                                    int r, int D) {
+  // forw: kk in [M*max(n-r,0), M*max(n-1,0)), jj = n-1 (kk-major);  back: kk in [M*(n-1), M*n) x jj in [max(n-r,0), n)
+  const int64_t f0 = (int64_t)M * max(n - r, 0), f1 = (int64_t)M * max(n - 1, 0);
+  const int64_t nf = f1 - f0;
+  const int jlo = max(n - r, 0), nj = n - jlo;
+  const int64_t nb = (int64_t)M * nj;
+  const int64_t total = nf + nb;
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (int64_t e = gt; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k, j;
+    if (e < nf) { k = f0 + e; j = n - 1; }
+    else { const int64_t q = e - nf; k = (int64_t)M * max(n - 1, 0) + q / nj; j = jlo + q % nj; }
+    kk[E0 + e] = k; jj[E0 + e] = j; ii[E0 + e] = ix[k];
+  }
+  const int64_t nn = total * (D / 4);
+  f4* np = reinterpret_cast<f4*>(net + E0 * D);
+  for (int64_t q = gt; q < nn; q += (int64_t)gridDim.x * blockDim.x) np[q] = (f4)0.f;
+}
+
+// ---- edge compaction: dst[t] = src[idx[t]] for the six per-edge arrays (remove_factors, dpvo.py:223-238) ----------
+__global__ void gather_edges_kernel(const int64_t* __restrict__ idx, int64_t n, const int64_t* __restrict__ ii,
+                                    const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+                                    const float* __restrict__ net, const float* __restrict__ target,
+                                    const float* __restrict__ weight, int64_t* __restrict__ oii, int64_t* __restrict__ ojj,
+                                    int64_t* __restrict__ okk, float* __restrict__ onet, float* __restrict__ otarget,
+                                    float* __restrict__ oweight, int D) {
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = gt; t < n; t += gs) {
+    const int64_t s = idx[t];
+    oii[t] = ii[s]; ojj[t] = jj[s]; okk[t] = kk[s];
+    if (otarget) { otarget[2 * t] = target[2 * s]; otarget[2 * t + 1] = target[2 * s + 1]; }
+    if (oweight) { oweight[2 * t] = weight[2 * s]; oweight[2 * t + 1] = weight[2 * s + 1]; }
+  }
+  if (onet) {
+    const int dq = D / 4;
+    for (int64_t q = gt; q < n * dq; q += gs) {
+      const int64_t t = q / dq;
+      const int c = (int)(q - t * dq);
+      reinterpret_cast<f4*>(onet)[t * dq + c] = reinterpret_cast<const f4*>(net)[idx[t] * dq + c];
+    }
+  }
+}
+
+// ---- motion model (dpvo.py:410-421): poses[n] = Exp(damping*fac * Log(P1 * P2^-1)) * P1 --------------------------
+struct Q4 { float x, y, z, w; };
+__device__ __forceinline__ Q4 qn(Q4 q) { const float n = sqrtf(q.x*q.x+q.y*q.y+q.z*q.z+q.w*q.w); return {q.x/n,q.y/n,q.z/n,q.w/n}; }
+__device__ __forceinline__ Q4 qm(Q4 a, Q4 b) {
+  return {a.w*b.x+a.x*b.w+a.y*b.z-a.z*b.y, a.w*b.y+a.y*b.w+a.z*b.x-a.x*b.z, a.w*b.z+a.z*b.w+a.x*b.y-a.y*b.x,
+          a.w*b.w-a.x*b.x-a.y*b.y-a.z*b.z};
+}
+__device__ __forceinline__ void qr(Q4 q, const float* p, float* o) {
+  float ux = q.y*p[2]-q.z*p[1], uy = q.z*p[0]-q.x*p[2], uz = q.x*p[1]-q.y*p[0];
+  ux += ux; uy += uy; uz += uz;
+  o[0] = p[0]+q.w*ux+(q.y*uz-q.z*uy); o[1] = p[1]+q.w*uy+(q.z*ux-q.x*uz); o[2] = p[2]+q.w*uz+(q.x*uy-q.y*ux);
+}
+__device__ __forceinline__ void hat3(const float* p, float* M) {
+  M[0]=0; M[1]=-p[2]; M[2]=p[1]; M[3]=p[2]; M[4]=0; M[5]=-p[0]; M[6]=-p[1]; M[7]=p[0]; M[8]=0;
+}
+__device__ __forceinline__ void mm3(const float* A, const float* B, float* C) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += A[3*i+k]*B[3*k+j]; C[3*i+j] = s; }
+}
+__global__ void motion_model_kernel(float* __restrict__ poses, int n, float scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  constexpr float kEps = 1e-6f;
+  const float* p1 = poses + 7 * (int64_t)(n - 1);
+  const float* p2 = poses + 7 * (int64_t)(n - 2);
+  // SE3 constructors normalise (so3.h:35-37); same sequence as lietorch: P2.inv(), P1 * inv, .log(), * scale, exp, * P1
+  const Q4 q1 = qn({p1[3], p1[4], p1[5], p1[6]}), q2 = qn({p2[3], p2[4], p2[5], p2[6]});
+  const Q4 q2i = qn({-q2.x, -q2.y, -q2.z, q2.w});
+  float t2i[3]; qr(q2i, p2, t2i); t2i[0] = -t2i[0]; t2i[1] = -t2i[1]; t2i[2] = -t2i[2];
+  const Q4 qd = qn(qm(q1, q2i));
+  float td[3]; qr(q1, t2i, td); td[0] += p1[0]; td[1] += p1[1]; td[2] += p1[2];
+  // log (se3.h:124-131, so3.h:115-150,192-208)
+  const float sn = qd.x*qd.x+qd.y*qd.y+qd.z*qd.z, w = qd.w;
+  float f;
+  if (sn < kEps*kEps) f = 2.0f/w - (2.0f/3.0f)*sn/(w*w*w);
+  else { const float nn = sqrtf(sn); f = (fabsf(w) < kEps) ? ((w > 0) ? 3.14159265358979323846f/nn : -3.14159265358979323846f/nn) : 2.0f*atanf(nn/w)/nn; }
+  float phi[3] = {f*qd.x, f*qd.y, f*qd.z};
+  float Phi[9], Phi2[9]; hat3(phi, Phi); mm3(Phi, Phi, Phi2);
+  float th2 = phi[0]*phi[0]+phi[1]*phi[1]+phi[2]*phi[2], th = sqrtf(th2), ht = 0.5f*th;
+  const float c2l = (th < kEps) ? (1.0f/12.0f) : (1.0f - th*cosf(ht)/(2.0f*sinf(ht)))/(th*th);
+  float xi[6];
+  for (int r = 0; r < 3; r++) { float s = 0; for (int c = 0; c < 3; c++) s += (((r==c)?1.0f:0.0f) - 0.5f*Phi[3*r+c] + c2l*Phi2[3*r+c])*td[c]; xi[r] = s; }
+  xi[3] = phi[0]; xi[4] = phi[1]; xi[5] = phi[2];
+  for (int r = 0; r < 6; r++) xi[r] = scale * xi[r];
+  // exp (se3.h:133-142, so3.h:152-190)
+  phi[0] = xi[3]; phi[1] = xi[4]; phi[2] = xi[5];
+  th2 = phi[0]*phi[0]+phi[1]*phi[1]+phi[2]*phi[2]; th = sqrtf(th2);
+  float imag, real;
+  if (th < kEps) { const float t4 = th2*th2; imag = 0.5f-(1.0f/48.0f)*th2+(1.0f/3840.0f)*t4; real = 1.0f-(1.0f/8.0f)*th2+(1.0f/384.0f)*t4; }
+  else { imag = sinf(.5f*th)/th; real = cosf(.5f*th); }
+  const Q4 qe = qn({imag*phi[0], imag*phi[1], imag*phi[2], real});
+  hat3(phi, Phi); mm3(Phi, Phi, Phi2);
+  const float c1 = (th < kEps) ? 0.5f-(1.0f/24.0f)*th2 : (1.0f-cosf(th))/th2;
+  const float c2 = (th < kEps) ? (1.0f/6.0f)-(1.0f/120.0f)*th2 : (th-sinf(th))/(th2*th);
+  float te[3];
+  for (int r = 0; r < 3; r++) { float s = 0; for (int c = 0; c < 3; c++) s += (((r==c)?1.0f:0.0f) + c1*Phi[3*r+c] + c2*Phi2[3*r+c])*xi[c]; te[r] = s; }
+  // exp(xi) * P1
+  const Q4 qo = qn(qm(qe, q1));
+  float to[3]; qr(qe, p1, to);
+  float* o = poses + 7 * (int64_t)n;
+  o[0] = te[0]+to[0]; o[1] = te[1]+to[1]; o[2] = te[2]+to[2]; o[3] = qo.x; o[4] = qo.y; o[5] = qo.z; o[6] = qo.w;
+}
+
+// ---- depth initialisation (dpvo.py:427-432): patches[n][:, 2] = median(patches[n-3:n, :, 2]) (torch.median = lower
+//      median of the flattened values).  One block, bitonic sort in LDS (count <= 4096). ------------------------------
+__global__ __launch_bounds__(1024) void median_depth_kernel(float* __restrict__ patches, int n, int M, int PP) {
+  __shared__ float v[4096];
+  const int per = M * PP, cnt = 3 * per;
+  const float* src = patches + (int64_t)(n - 3) * M * 3 * PP;
+  for (int i = threadIdx.x; i < 4096; i += 1024) {
+    float x = INFINITY;
+    if (i < cnt) { const int f = i / per, r = i - f * per, m = r / PP, p = r - m * PP; x = src[((int64_t)(f * M + m) * 3 + 2) * PP + p]; }
+    v[i] = x;
+  }
+  __syncthreads();
+  for (int k = 2; k <= 4096; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < 4096; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = ((i & k) == 0);
+          const float a = v[i], b = v[l];
+          if ((a > b) == up) { v[i] = b; v[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const float med = v[(cnt - 1) / 2];
+  float* dst = patches + (int64_t)n * M * 3 * PP;
+  for (int i = threadIdx.x; i < per; i += 1024) { const int m = i / PP, p = i - m * PP; dst[((int64_t)m * 3 + 2) * PP + p] = med; }
+}
+
+inline unsigned grid_for(int64_t n, int cap = 4096) {
+  int64_t g = cdiv64(n, 256);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dpvo_normalize_image(const void* img_u8, float* out_f32, void* out_f16, int64_t n, void* stream) {
+  if (n < 0 || (!out_f32 && !out_f16)) return DPVO_E_INVALID;
+  if (n == 0) return DPVO_OK;
+  if (!img_u8) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(normalize_image_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img_u8,
+                     out_f32, (_Float16*)out_f16, n);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_patch_colors(const void* img_u8, const float* coords, void* out_u8, int M, int H, int W, void* stream) {
+  if (M < 0 || H <= 0 || W <= 0) return DPVO_E_INVALID;
+  if (M == 0) return DPVO_OK;
+  if (!img_u8 || !coords || !out_u8) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(patch_colors_kernel, dim3((3 * M + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)img_u8, coords, (uint8_t*)out_u8, M, H, W);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_store_features(const void* fmap, void* f1_slot, void* f2_slot, int dtype, int C, int h, int w,
+                                   void* stream) {
+  if (C <= 0 || h <= 0 || w <= 0 || (h % 4) || (w % 4)) return DPVO_E_INVALID;
+  if (!fmap || !f1_slot || !f2_slot) return DPVO_E_INVALID;
+  const dim3 grid((w + 63) / 64, h / 4);
+  if (dtype == DPVO_F16) {
+    const size_t sh = (size_t)C * 4 * 65 * 2;
+    if (sh > 160 * 1024) return DPVO_E_UNSUPPORTED;
+    (void)hipFuncSetAttribute((const void*)store_features_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(store_features_kernel<_Float16>, grid, dim3(256), sh, (hipStream_t)stream, (const _Float16*)fmap,
+                       (_Float16*)f1_slot, (_Float16*)f2_slot, C, h, w);
+  } else if (dtype == DPVO_F32) {
+    const size_t sh = (size_t)C * 4 * 65 * 4;
+    if (sh > 160 * 1024) return DPVO_E_UNSUPPORTED;
+    (void)hipFuncSetAttribute((const void*)store_features_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(store_features_kernel<float>, grid, dim3(256), sh, (hipStream_t)stream, (const float*)fmap,
+                       (float*)f1_slot, (float*)f2_slot, C, h, w);
+  } else {
+    return DPVO_E_UNSUPPORTED;
+  }
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_append_edges(int64_t* ii, int64_t* jj, int64_t* kk, float* net, const int64_t* ix, int64_t E0, int n,
+                                 int M, int r, int D, int64_t* n_new, void* stream) {
+  if (E0 < 0 || n < 1 || M <= 0 || r < 0 || D <= 0 || (D % 4)) return DPVO_E_INVALID;
+  const int64_t nf = (int64_t)M * ((n - 1 > 0 ? n - 1 : 0) - (n - r > 0 ? n - r : 0));
+  const int jlo = n - r > 0 ? n - r : 0;
+  const int64_t total = nf + (int64_t)M * (n - jlo);
+  if (n_new) *n_new = total;
+  if (total == 0) return DPVO_OK;
+  if (!ii || !jj || !kk || !net || !ix) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(append_edges_kernel, dim3(grid_for(total * (D / 4), 2048)), dim3(256), 0, (hipStream_t)stream, ii, jj,
+                     kk, net, ix, E0, n, M, r, D);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* ii, const int64_t* jj, const int64_t* kk,
+                                 const float* net, const float* target, const float* weight, int64_t* oii, int64_t* ojj,
+                                 int64_t* okk, float* onet, float* otarget, float* oweight, int D, void* stream) {
+  if (n < 0 || D <= 0 || (D % 4)) return DPVO_E_INVALID;
+  if (n == 0) return DPVO_OK;
+  if (!idx || !ii || !jj || !kk || !oii || !ojj || !okk) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(gather_edges_kernel, dim3(grid_for(onet ? n * (D / 4) : n, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     idx, n, ii, jj, kk, net, target, weight, oii, ojj, okk, onet, otarget, oweight, D);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_motion_model(float* poses, int n, float scale, void* stream) {
+  if (!poses || n < 2) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(motion_model_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, poses, n, scale);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_median_depth(float* patches, int n, int M, int P, void* stream) {
+  if (!patches || n < 3 || M <= 0 || P <= 0) return DPVO_E_INVALID;
+  if (3 * M * P * P > 4096) return DPVO_E_UNSUPPORTED;
+  hipLaunchKernelGGL(median_depth_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, patches, n, M, P * P);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}

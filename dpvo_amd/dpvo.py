@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import altcorr, fastba, lietorch
 from . import projective_ops as pops
 from .graph import GraphPlan
@@ -234,32 +235,26 @@ class DPVO:
         return pops.transform_coords(self.poses, self.patches, self.intrinsics, ii, jj, kk)
 
     def append_factors(self, ii, jj):
-        self.pg.jj = torch.cat([self.pg.jj, jj])
-        self.pg.kk = torch.cat([self.pg.kk, ii])
-        self.pg.ii = torch.cat([self.pg.ii, self.ix[ii]])
+        """generic append (loop-closure edges): ii = patch ids, jj = target frames (dpvo.py:215-221)"""
+        self.pg.edges.append(self.ix[ii], jj, ii)
+        self._plan = None
 
-        net = torch.zeros(1, len(ii), self.DIM, dtype=torch.float, device=self.device)
-        self.pg.net = torch.cat([self.pg.net, net], dim=1)
+    def append_frame_factors(self):
+        """append_factors(*edges_forw) + append_factors(*edges_back) (dpvo.py:458-459) as one kernel"""
+        self.pg.edges.append_frame(self.ix, self.n, self.M, self.cfg.PATCH_LIFETIME)
         self._plan = None
 
     def remove_factors(self, m, store: bool):
-        assert self.pg.ii.numel() == self.pg.weight.shape[1]
+        """dpvo.py:223-238.  m: bool mask over the active edges."""
         if store:
             rem = m.nonzero().squeeze(1)
-            self.pg.ii_inac = torch.cat((self.pg.ii_inac, self.pg.ii[rem]))
-            self.pg.jj_inac = torch.cat((self.pg.jj_inac, self.pg.jj[rem]))
-            self.pg.kk_inac = torch.cat((self.pg.kk_inac, self.pg.kk[rem]))
-            self.pg.weight_inac = torch.cat((self.pg.weight_inac, self.pg.weight[:, rem]), dim=1)
-            self.pg.target_inac = torch.cat((self.pg.target_inac, self.pg.target[:, rem]), dim=1)
-        keep = (~m).nonzero().squeeze(1)          # x[~m] for six tensors == one nonzero + six gathers
-        self.pg.weight = self.pg.weight[:, keep]
-        self.pg.target = self.pg.target[:, keep]
-
-        self.pg.ii = self.pg.ii[keep]
-        self.pg.jj = self.pg.jj[keep]
-        self.pg.kk = self.pg.kk[keep]
-        self.pg.net = self.pg.net[:, keep]
-        assert self.pg.ii.numel() == self.pg.weight.shape[1]
+            if rem.numel():
+                dst = self.pg.edges_inac
+                dst.reserve(rem.numel())
+                self.pg.edges.gather_into(rem, dst.a, dst.E)
+                dst.E += rem.numel()
+        keep = (~m).nonzero().squeeze(1)
+        self.pg.edges.keep(keep)
         self._plan = None
 
     def motion_probe(self):
@@ -358,9 +353,10 @@ class DPVO:
             plan = self.plan()
             coords = self.reproject()
             corr = self.corr(coords)
-            self.pg.net, (delta, weight, _) = self.network.update(
-                self.pg.net, self.imap, corr, None, self.pg.ii, self.pg.jj, self.pg.kk, plan=plan,
-                inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896))
+            netbuf = self.pg.edges.view("net")          # updated in place (the reference reassigns pg.net)
+            _, (delta, weight, _) = self.network.update(
+                netbuf[None], self.imap, corr, None, self.pg.ii, self.pg.jj, self.pg.kk, plan=plan,
+                inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896), out=netbuf)
 
             lmbda = 1e-4
             weight = weight.float()
@@ -409,38 +405,40 @@ class DPVO:
         if (self.n + 1) >= self.N:
             raise Exception(f'The buffer size is too small. You can increase it using "--opts BUFFER_SIZE={self.N*2}"')
 
-        image = 2 * (image[None, None] / 255.0) - 0.5
+        # image = 2 * (image[None,None] / 255.0) - 0.5, plus the f16 copy the encoders eat: one kernel
+        image_u8 = image.contiguous()
+        H, W = image_u8.shape[-2:]
+        img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
+        img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
+        L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),
+                                             L.stream()), "dpvo_normalize_image")
 
-        fmap, gmap, imap, patches, _, clr = \
-            self.network.patchify(image,
+        fmap, gmap, imap, patches, _, coords = \
+            self.network.patchify(img32 if img32 is not None else img16,
                                   patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                   centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
-                                  return_color=True, coords=patch_coords, half=self._enc_half)
+                                  coords=patch_coords, half=self._enc_half, images_f16=img16, return_coords=True)
 
         ### update state attributes ###
         self.tlist.append(tstamp)
         self.pg.tstamps_[self.n] = self.counter
         self.pg.intrinsics_[self.n] = intrinsics / self.RES
 
-        # color info for visualization
-        clr = (clr[0, :, [2, 1, 0]] + 0.5) * (255.0 / 2)
-        self.pg.colors_[self.n] = clr.to(torch.uint8)
+        # color info for visualization (clr = (clr[0,:,[2,1,0]] + 0.5) * (255.0 / 2) -> uint8): one kernel on the u8 image
+        L.check(L.lib().dpvo_patch_colors(L.ptr(image_u8), L.ptr(coords[0].contiguous()), L.ptr(self.pg.colors_[self.n]),
+                                          L.i32(self.M), L.i32(H), L.i32(W), L.stream()), "dpvo_patch_colors")
 
         self.pg.index_[self.n + 1] = self.n + 1
         self.pg.index_map_[self.n + 1] = self.m + self.M
 
         if self.n > 1:
             if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                P1 = SE3(self.pg.poses_[self.n - 1])
-                P2 = SE3(self.pg.poses_[self.n - 2])
-
                 # To deal with varying camera hz
                 *_, a, b, c = [1] * 3 + self.tlist
                 fac = (c - b) / (b - a)
-
-                xi = self.cfg.MOTION_DAMPING * fac * (P1 * P2.inv()).log()
-                tvec_qvec = (SE3.exp(xi) * P1).data
-                self.pg.poses_[self.n] = tvec_qvec
+                # poses_[n] = Exp(MOTION_DAMPING * fac * Log(P1 * P2^-1)) * P1: one kernel (was ~8 lietorch launches)
+                L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
+                                                  L.f32(self.cfg.MOTION_DAMPING * fac), L.stream()), "dpvo_motion_model")
             else:
                 tvec_qvec = self.poses[self.n - 1]
                 self.pg.poses_[self.n] = tvec_qvec
@@ -451,17 +449,24 @@ class DPVO:
             patches[:, :, 2] = torch.rand_like(patches[:, :, 2, 0, 0, None, None])
         else:
             patches[:, :, 2] = depth_init.view(1, -1, 1, 1).to(patches)
-        if self.is_initialized:
-            s = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
-            patches[:, :, 2] = s
-
         self.pg.patches_[self.n] = patches
+        if self.is_initialized:
+            # s = torch.median(patches_[n-3:n,:,2]); patches[:,:,2] = s: one kernel (was sort + gather + fills)
+            if 3 * self.M * self.P * self.P <= 4096:
+                L.check(L.lib().dpvo_median_depth(L.ptr(self.pg.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.P),
+                                                  L.stream()), "dpvo_median_depth")
+            else:
+                self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
 
         ### update network attributes ###
         self.imap_[self.n % self.pmem] = imap.squeeze()
         self.gmap_[self.n % self.pmem] = gmap.squeeze()
-        self.fmap1_[:, self.n % self.mem] = F.avg_pool2d(fmap[0], 1, 1)
-        self.fmap2_[:, self.n % self.mem] = F.avg_pool2d(fmap[0], 4, 4)
+        # fmap1_[:, n % mem] = avg_pool2d(fmap, 1, 1); fmap2_[:, n % mem] = avg_pool2d(fmap, 4, 4): one transposing kernel
+        fm = fmap[0, 0].contiguous()
+        L.check(L.lib().dpvo_store_features(L.ptr(fm), L.ptr(self._fmap1_cl[self.n % self.mem]),
+                                            L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(L.dtype_code(fm.dtype)),
+                                            L.i32(fm.shape[0]), L.i32(fm.shape[1]), L.i32(fm.shape[2]), L.stream()),
+                "dpvo_store_features")
 
         self.counter += 1
         if self.n > 0 and not self.is_initialized:
@@ -481,8 +486,7 @@ class DPVO:
                     self.append_factors(lii, ljj)
 
         # Add forward and backward factors
-        self.append_factors(*self._edges_forw())
-        self.append_factors(*self._edges_back())
+        self.append_frame_factors()
 
         if self.n == 8 and not self.is_initialized:
             self.is_initialized = True

@@ -154,9 +154,11 @@ class Update(nn.Module):
 
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
-    def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False):
+    def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
+                out=None):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
+        `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
         Returns net f32 [1,E,384], (delta f32 [1,E,2], weight f32 [1,E,2], None)."""
         P = self._packed or self.pack()
         L.require_cuda(net, inp, corr, ii, jj, kk)
@@ -190,7 +192,8 @@ class Update(nn.Module):
         h2 = linear(h1, P["c2"][0], P["c2"][1])
         layernorm(h2, P["cln"][0], P["cln"][1], y_f16=h1, relu_f16=True)
         c = linear(h1, P["c5"][0], P["c5"][1], out=h2)
-        x = torch.empty(E, DIM, dtype=torch.float32, device=dev)
+        x = out.reshape(E, DIM) if out is not None else torch.empty(E, DIM, dtype=torch.float32, device=dev)
+        assert x.dtype == torch.float32 and x.is_contiguous()
         x16 = torch.empty(E, DIM, dtype=torch.float16, device=dev)      # f16 operand image of `net`, kept in step
         layernorm(net2, P["norm"][0], P["norm"][1], add1=inp2, add1_rows=inp_rows, add1_mod=inp_mod, add2=c, y_f32=x,
                   y_f16=x16)
@@ -242,11 +245,11 @@ class Patchifier(nn.Module):
         return g
 
     def forward(self, images, patches_per_image=80, disps=None, centroid_sel_strat='RANDOM', return_color=False,
-                coords=None, half=False):
+                coords=None, half=False, images_f16=None, return_coords=False):
         """`coords` ([n, patches, 2] float, optional) injects the patch centroids (deterministic tests / oracle
         replay); otherwise they are drawn exactly like the reference (x then y, net.py:131-133).
         `half`: the encoders hold f16 weights (DPVO casts them once) and are fed an f16 copy of the image."""
-        enc_in = images.half() if half else images
+        enc_in = images_f16 if images_f16 is not None else (images.half() if half else images)
         fmap = self.fnet(enc_in) / 4.0
         imap = self.inet(enc_in) / 4.0
         b, n, c, h, w = fmap.shape
@@ -283,8 +286,12 @@ class Patchifier(nn.Module):
         else:
             grid, _ = coords_grid_with_index(disps, device=dev)
         patches = altcorr.patchify(grid[0], coords, P // 2).view(b, -1, 3, P, P)
-        index = torch.arange(n, device=dev).view(n, 1)
-        index = index.repeat(1, patches_per_image).reshape(-1)
+        index = None
+        if not return_coords:
+            index = torch.arange(n, device=dev).view(n, 1)
+            index = index.repeat(1, patches_per_image).reshape(-1)
+        if return_coords:
+            return fmap, gmap, imap, patches, index, coords
         if return_color:
             return fmap, gmap, imap, patches, index, clr
         return fmap, gmap, imap, patches, index

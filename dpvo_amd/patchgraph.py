@@ -6,9 +6,100 @@ float32 after the first update anyway, dpvo.py:220 + net.py:78); index tensors s
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import projective_ops as pops
 from .lietorch import SE3
 from .utils import flatmeshgrid
+
+
+class EdgeStore:
+    """Preallocated per-edge arrays (ii, jj, kk int64; net f32 [.,D]; target, weight f32 [.,2]) with an element count.
+
+    The reference rebuilds these tensors with torch.cat / boolean-mask indexing on every frame (dpvo.py:215-238):
+    ~45 small launches and ~150 MB of copies.  Here appends write into the tail of capacity buffers (one kernel) and
+    removals compact into a second buffer set (one nonzero + one gather kernel), then the sets swap."""
+
+    def __init__(self, D, device, with_state=True, cap=65536):
+        self.D, self.dev, self.with_state = D, device, with_state
+        self.E = 0
+        self._alloc(cap)
+
+    def _new(self, cap):
+        d = {k: torch.empty(cap, dtype=torch.long, device=self.dev) for k in ("ii", "jj", "kk")}
+        d["target"] = torch.zeros(cap, 2, dtype=torch.float, device=self.dev)
+        d["weight"] = torch.zeros(cap, 2, dtype=torch.float, device=self.dev)
+        if self.with_state:
+            d["net"] = torch.empty(cap, self.D, dtype=torch.float, device=self.dev)
+        return d
+
+    def _alloc(self, cap):
+        self.cap = cap
+        self.a, self.b = self._new(cap), self._new(cap)
+
+    def reserve(self, n):
+        if self.E + n <= self.cap:
+            return
+        old, E = self.a, self.E
+        self._alloc(max(2 * self.cap, self.E + n))
+        for k, v in old.items():
+            self.a[k][:E] = v[:E]
+
+    def view(self, name):
+        return self.a[name][:self.E]
+
+    def assign(self, name, value):
+        value = value.reshape((-1,) + tuple(self.a[name].shape[1:]))
+        n = value.shape[0]
+        if name in ("ii", "jj", "kk") and n != self.E:
+            raise ValueError("edge arrays must be resized through EdgeStore.append / keep")
+        self.a[name][:n] = value
+
+    def append_frame(self, ix, n, M, r):
+        """append_factors(edges_forw) + append_factors(edges_back) for frame count n: one kernel"""
+        import ctypes
+        nf = M * (max(n - 1, 0) - max(n - r, 0))
+        total = nf + M * (n - max(n - r, 0))
+        self.reserve(total)
+        cnt = ctypes.c_int64(0)
+        L.check(L.lib().dpvo_append_edges(L.ptr(self.a["ii"]), L.ptr(self.a["jj"]), L.ptr(self.a["kk"]),
+                                          L.ptr(self.a["net"]), L.ptr(ix), L.i64(self.E), L.i32(n), L.i32(M), L.i32(r),
+                                          L.i32(self.D), ctypes.byref(cnt), L.stream()), "dpvo_append_edges")
+        assert cnt.value == total
+        self.E += total
+
+    def append(self, ii, jj, kk, net=None, target=None, weight=None):
+        n = ii.numel()
+        self.reserve(n)
+        E = self.E
+        self.a["ii"][E:E + n] = ii; self.a["jj"][E:E + n] = jj; self.a["kk"][E:E + n] = kk
+        if self.with_state:
+            if net is None:
+                self.a["net"][E:E + n].zero_()
+            else:
+                self.a["net"][E:E + n] = net.reshape(n, self.D)
+        for name, val in (("target", target), ("weight", weight)):
+            if val is None:
+                self.a[name][E:E + n].zero_()
+            else:
+                self.a[name][E:E + n] = val.reshape(n, 2)
+        self.E += n
+
+    def gather_into(self, idx, dst, dst_off):
+        """dst arrays [dst_off : dst_off+len(idx)] = self arrays[idx] (one kernel)"""
+        n = idx.numel()
+        o = lambda t: None if t is None else t[dst_off:]
+        L.check(L.lib().dpvo_gather_edges(
+            L.ptr(idx), L.i64(n), L.ptr(self.a["ii"]), L.ptr(self.a["jj"]), L.ptr(self.a["kk"]),
+            L.ptr(self.a.get("net")) if dst.get("net") is not None else L.ptr(None), L.ptr(self.a["target"]),
+            L.ptr(self.a["weight"]), L.ptr(o(dst["ii"])), L.ptr(o(dst["jj"])), L.ptr(o(dst["kk"])),
+            L.ptr(o(dst.get("net"))), L.ptr(o(dst["target"])), L.ptr(o(dst["weight"])), L.i32(self.D), L.stream()),
+            "dpvo_gather_edges")
+
+    def keep(self, idx):
+        """compact to the edges listed in idx (sorted ascending), ping-pong buffers"""
+        self.gather_into(idx, self.b, 0)
+        self.a, self.b = self.b, self.a
+        self.E = idx.numel()
 
 
 def reduce_edges(flow_mag, ii, jj, max_num_edges, nms):
@@ -70,20 +161,23 @@ class PatchGraph:
         # store relative poses for removed frames
         self.delta = {}
 
-        ### edge information ###
-        self.net = torch.zeros(1, 0, DIM, dtype=torch.float, device=dev)
-        self.ii = torch.as_tensor([], dtype=torch.long, device=dev)
-        self.jj = torch.as_tensor([], dtype=torch.long, device=dev)
-        self.kk = torch.as_tensor([], dtype=torch.long, device=dev)
-        self.weight = torch.zeros(1, 0, 2, dtype=torch.float, device=dev)
-        self.target = torch.zeros(1, 0, 2, dtype=torch.float, device=dev)
-
+        ### edge information: preallocated stores, exposed under the reference's attribute names ###
+        self.edges = EdgeStore(DIM, dev, with_state=True)
         ### inactive edge information (i.e., no longer updated, but useful for BA) ###
-        self.ii_inac = torch.as_tensor([], dtype=torch.long, device=dev)
-        self.jj_inac = torch.as_tensor([], dtype=torch.long, device=dev)
-        self.kk_inac = torch.as_tensor([], dtype=torch.long, device=dev)
-        self.weight_inac = torch.zeros(1, 0, 2, dtype=torch.float, device=dev)
-        self.target_inac = torch.zeros(1, 0, 2, dtype=torch.float, device=dev)
+        self.edges_inac = EdgeStore(DIM, dev, with_state=False, cap=1 << 17)
+
+    # active edges (views of the store; assignment copies into it, in-place ops on the views work as in the reference)
+    ii = property(lambda self: self.edges.view("ii"), lambda self, v: self.edges.assign("ii", v))
+    jj = property(lambda self: self.edges.view("jj"), lambda self, v: self.edges.assign("jj", v))
+    kk = property(lambda self: self.edges.view("kk"), lambda self, v: self.edges.assign("kk", v))
+    net = property(lambda self: self.edges.view("net")[None], lambda self, v: self.edges.assign("net", v))
+    target = property(lambda self: self.edges.view("target")[None], lambda self, v: self.edges.assign("target", v))
+    weight = property(lambda self: self.edges.view("weight")[None], lambda self, v: self.edges.assign("weight", v))
+    ii_inac = property(lambda self: self.edges_inac.view("ii"))
+    jj_inac = property(lambda self: self.edges_inac.view("jj"))
+    kk_inac = property(lambda self: self.edges_inac.view("kk"))
+    target_inac = property(lambda self: self.edges_inac.view("target")[None])
+    weight_inac = property(lambda self: self.edges_inac.view("weight")[None])
 
     def edges_loop(self):
         """Adding edges from old patches to new frames (patchgraph.py:56-82)"""

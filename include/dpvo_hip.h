@@ -226,6 +226,30 @@ int dpvo_ba(float* poses, float* patches, const float* intrinsics, const float* 
             int64_t n_patches_hint, int64_t n_pairs_hint, int64_t E, int P, int t0, int t1, int iterations,
             int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * front-end helpers  (callers either side of the hot path, dpvo/dpvo.py:377-473; each replaces a chain of
+ * small torch launches -- the frame is launch-bound above ~200 fps)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* image = 2*(image/255) - 0.5 (dpvo.py:389): f32 and/or f16 output, n elements. */
+int dpvo_normalize_image(const void* img_u8, float* out_f32, void* out_f16, int64_t n, void* stream);
+/* colours of the new patches (dpvo.py:404-405 + net.py:143): out_u8 [M,3] (BGR->RGB swap, uint8 truncation). */
+int dpvo_patch_colors(const void* img_u8, const float* coords, void* out_u8, int M, int H, int W, void* stream);
+/* ring-buffer store (dpvo.py:437-438): fmap [C,h,w] -> channels-last slot [h,w,C] + 4x4 avg-pooled [h/4,w/4,C]. */
+int dpvo_store_features(const void* fmap, void* f1_slot, void* f2_slot, int dtype, int C, int h, int w, void* stream);
+/* append_factors(edges_forw) + append_factors(edges_back) (dpvo.py:215-221,362-375,458-459) for frame count n:
+ * writes kk, jj, ii = ix[kk] at [E0, E0+n_new) and zeroes the new rows of net [.,D]; *n_new (host) = count. */
+int dpvo_append_edges(int64_t* ii, int64_t* jj, int64_t* kk, float* net, const int64_t* ix, int64_t E0, int n, int M,
+                      int r, int D, int64_t* n_new, void* stream);
+/* remove_factors compaction (dpvo.py:223-238): out[t] = in[idx[t]] for ii,jj,kk and (optional) net,target,weight. */
+int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* ii, const int64_t* jj, const int64_t* kk,
+                      const float* net, const float* target, const float* weight, int64_t* oii, int64_t* ojj,
+                      int64_t* okk, float* onet, float* otarget, float* oweight, int D, void* stream);
+/* damped-linear motion model (dpvo.py:410-421): poses[n] = Exp(scale * Log(P[n-1] * P[n-2]^-1)) * P[n-1]. */
+int dpvo_motion_model(float* poses, int n, float scale, void* stream);
+/* depth initialisation (dpvo.py:430-432): patches[n][:,2] = torch.median(patches[n-3:n,:,2]) (lower median). */
+int dpvo_median_depth(float* patches, int n, int M, int P, void* stream);
+
 /* Global BA == cuda_ba.forward(..., eff_impl=True) (ba_cuda.cu:475-478,538-550 with EfficentE, block_e.cu:43-300),
  * used by DPVO.__run_global_BA (dpvo/dpvo.py:312-326).  One Gauss-Newton iteration is
  *     zero S[6N,6N], y[6N];  dpvo_gba_linearize -> S = B - E Q E^T, y = v - E Q u  (block-sparse E, device plan);

@@ -1,0 +1,88 @@
+"""Front-end helper kernels (dpvo_amd/csrc/frontend.hip) against the torch / lietorch formulation the reference uses."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dpvo_amd import _lib as L
+from dpvo_amd import altcorr, lietorch
+from dpvo_amd.patchgraph import EdgeStore
+from dpvo_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_normalize_colors_features(dev):
+    g = torch.Generator().manual_seed(0)
+    H, W, M = 96, 128, 40
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)
+    f32 = torch.empty(3, H, W, device=dev); f16 = torch.empty(3, H, W, dtype=torch.float16, device=dev)
+    L.check(L.lib().dpvo_normalize_image(L.ptr(img), L.ptr(f32), L.ptr(f16), L.i64(img.numel()), L.stream()), "norm")
+    ref = 2 * (img[None, None] / 255.0) - 0.5                          # dpvo.py:389
+    assert torch.equal(f32, ref[0, 0]) and torch.equal(f16, ref[0, 0].half())
+    # colours: clr = patchify(images[0], 4*(coords+0.5), 0); clr = (clr[0,:,[2,1,0]] + 0.5) * (255/2) -> uint8
+    coords = torch.stack([torch.randint(1, W // 4 - 1, (M,), generator=g), torch.randint(1, H // 4 - 1, (M,), generator=g)], -1).float().to(dev)
+    coords[0] = torch.tensor([W / 4 - 0.3, 2.0], device=dev)           # partly out of bounds
+    clr = altcorr.patchify(ref[0], 4 * (coords[None] + 0.5), 0).view(1, -1, 3)
+    clr = ((clr[0, :, [2, 1, 0]] + 0.5) * (255.0 / 2)).to(torch.uint8)
+    out = torch.zeros(M, 3, dtype=torch.uint8, device=dev)
+    L.check(L.lib().dpvo_patch_colors(L.ptr(img), L.ptr(coords.contiguous()), L.ptr(out), L.i32(M), L.i32(H), L.i32(W), L.stream()), "clr")
+    assert torch.equal(out, clr)
+    # feature store: channels-last copy + 4x4 average pool
+    for dt in (torch.float16, torch.float32):
+        C, h, w = 128, 24, 72
+        fm = torch.randn(C, h, w, generator=g).to(dt).to(dev)
+        f1 = torch.zeros(h, w, C, dtype=dt, device=dev); f2 = torch.zeros(h // 4, w // 4, C, dtype=dt, device=dev)
+        L.check(L.lib().dpvo_store_features(L.ptr(fm), L.ptr(f1), L.ptr(f2), L.i32(L.dtype_code(dt)), L.i32(C), L.i32(h), L.i32(w), L.stream()), "feat")
+        assert torch.equal(f1, fm.permute(1, 2, 0))
+        ref2 = F.avg_pool2d(fm[None].float(), 4, 4)[0].permute(1, 2, 0)
+        assert torch.allclose(f2.float(), ref2, atol=2e-3 if dt == torch.float16 else 1e-6)
+
+
+def test_motion_model_and_median(dev):
+    g = torch.Generator().manual_seed(1)
+    poses = lietorch.SE3.exp(0.3 * torch.randn(10, 6, generator=g).to(dev)).data.contiguous()
+    poses[:, 3:] *= 1.3                                                # constructors normalise
+    ref = poses.clone()
+    n, scale = 7, 0.5 * 1.25
+    P1, P2 = lietorch.SE3(ref[n - 1]), lietorch.SE3(ref[n - 2])        # dpvo.py:412-421
+    xi = scale * (P1 * P2.inv()).log()
+    ref[n] = (lietorch.SE3.exp(xi) * P1).data
+    L.check(L.lib().dpvo_motion_model(L.ptr(poses), L.i32(n), L.f32(scale), L.stream()), "motion")
+    assert torch.allclose(poses[n], ref[n], atol=2e-6) and torch.equal(poses[:n], ref[:n]) and torch.equal(poses[n + 1:], ref[n + 1:])
+    for M in (16, 96):
+        patches = torch.rand(12, M, 3, 3, 3, generator=g).to(dev)
+        ref = patches.clone()
+        n = 9
+        ref[n, :, 2] = torch.median(ref[n - 3:n, :, 2])                # dpvo.py:430-432
+        L.check(L.lib().dpvo_median_depth(L.ptr(patches), L.i32(n), L.i32(M), L.i32(3), L.stream()), "median")
+        assert torch.equal(patches, ref)
+
+
+def test_edge_store_matches_replay(dev):
+    """append_frame + keep reproduce dpvo.py:215-238,362-375 exactly (compare with the CPU replay of the same rules)"""
+    cfg = S.GraphCfg(M=8, REMOVAL_WINDOW=10, PATCH_LIFETIME=6)
+    N = 64
+    index_ = torch.zeros(N, cfg.M, dtype=torch.long, device=dev)
+    st = EdgeStore(384, dev, cap=256)                                  # small capacity: exercises growth
+    inac = EdgeStore(384, dev, with_state=False, cap=64)
+    for n in range(1, 25):
+        index_[n] = n
+        E0 = st.E
+        st.append_frame(index_.view(-1), n, cfg.M, cfg.PATCH_LIFETIME)
+        assert (st.view("net")[E0:] == 0).all()
+        st.view("net")[E0:] += n                                       # tag rows to check the gather moves them along
+        st.view("target")[E0:] = float(n)
+        m = st.view("ii") < n - cfg.REMOVAL_WINDOW
+        rem = m.nonzero().squeeze(1)
+        if rem.numel():
+            inac.reserve(rem.numel()); st.gather_into(rem, inac.a, inac.E); inac.E += rem.numel()
+        st.keep((~m).nonzero().squeeze(1))
+        ii, jj, kk = S.replay_graph(n, cfg)
+        assert torch.equal(st.view("ii").cpu(), ii) and torch.equal(st.view("jj").cpu(), jj) and torch.equal(st.view("kk").cpu(), kk)
+        # the row tag equals the frame count at which the edge was created = jj + 1 for forward edges, kk//M + 1 for back
+        born = torch.maximum(st.view("jj"), st.view("kk") // cfg.M) + 1
+        assert torch.equal(st.view("net")[:, 0], born.float()) and torch.equal(st.view("target")[:, 1], born.float())
+    assert inac.E > 0 and (inac.view("ii") < 24 - cfg.REMOVAL_WINDOW).all()
