@@ -198,35 +198,163 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
     }
   }
   __syncthreads();
-  // Schur complement (ba_cuda.cu:557-558) + damping (:560): entry = 6 x n6 of S, then 6 of y; 4 lanes per entry
+  // Schur complement (ba_cuda.cu:557-558) + damping (:560): entries = 6 x n6 of S, then 6 of y; 4 lanes per entry, the
+  // partial sums of up to 8 entries per lane are accumulated in one pass so that their loads overlap.
   const int nrow = 6 * n6 + 6;
-  for (int base = 0; base < nrow; base += 64) {
-    const int e4 = base + (tid >> 2), sub = tid & 3;
-    float sc = 0.f;
-    int gent = 0;
-    if (e4 < nrow) {
-      gent = (e4 < 6 * n6) ? (6 * p + e4 / n6) * n6 + (e4 % n6) : n6 * n6 + 6 * p + (e4 - 6 * n6);
-      for (int b = sub; b < n_spart; b += 4) sc += spart[(int64_t)b * kSEntries + gent];
-    }
-    sc += __shfl_xor(sc, 1);
-    sc += __shfl_xor(sc, 2);
+  constexpr int kIt = (6 * kMaxDim + 6 + 63) / 64;      // 12
+  const int sub = tid & 3;
+  float sc[kIt];
+  int gent[kIt];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int e4 = it * 64 + (tid >> 2);
+    sc[it] = 0.f;
+    gent[it] = (e4 < 6 * n6) ? (6 * p + e4 / n6) * n6 + (e4 % n6) : n6 * n6 + 6 * p + (e4 - 6 * n6);
+    if (e4 >= nrow) gent[it] = -1;
+  }
+  for (int b = sub; b < n_spart; b += 4) {
+    const float* sp = spart + (int64_t)b * kSEntries;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it)
+      if (gent[it] >= 0) sc[it] += sp[gent[it]];
+  }
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    float v = sc[it];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    const int e4 = it * 64 + (tid >> 2);
     if (e4 < nrow && sub == 0) {
       if (e4 < 6 * n6) {
         const int ra = e4 / n6, rb = e4 - ra * n6;
-        float s = rowS[ra][rb] - sc;
-        if (6 * p + ra == rb) s += 1e-4f * s + 1.0f;              // S += I * (1e-4 * S + 1.0)
-        Sg[gent] = s;
+        float sv = rowS[ra][rb] - v;
+        if (6 * p + ra == rb) sv += 1e-4f * sv + 1.0f;              // S += I * (1e-4 * S + 1.0)
+        Sg[gent[it]] = sv;
       } else {
-        yg[6 * p + (e4 - 6 * n6)] = rowy[e4 - 6 * n6] - sc;
+        yg[6 * p + (e4 - 6 * n6)] = rowy[e4 - 6 * n6] - v;
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 4a. solve kernel for n6 <= 60 (the default window: N <= 10 free poses): ONE wave, lane t owns row t of the system
+//     IN REGISTERS.  Right-looking block Cholesky with 6x6 pose blocks: the diagonal block travels by v_readlane and
+//     is factorised redundantly by every lane, the 6-wide panel is published through LDS once per block step and the
+//     trailing update runs on registers -- 10 short dependent steps instead of 60 LDS round trips.  The system is
+//     padded with identity rows up to 60, so every loop bound is a compile-time constant.
+// ---------------------------------------------------------------------------------------------------
+#define RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+
+template <int B>
+__device__ __forceinline__ void chol_block_step(float (&row)[60], float (*Lp)[8], int t, int& bad) {
+  constexpr int o = 6 * B;
+  // 1. diagonal block (lower) from the lanes that own it
+  float D[6][6], Lb[6][6], inv[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) D[r][c] = RL(row[o + c], o + r);
+  // 2. its Cholesky factor, redundantly in every lane
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float d = D[c][c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) d -= Lb[c][k] * Lb[c][k];
+    if (!(d > 0.f) && bad == 0) bad = o + c + 1;
+    Lb[c][c] = sqrtf(d);
+    inv[c] = 1.0f / Lb[c][c];
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      float v = D[r][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) v -= Lb[r][k] * Lb[c][k];
+      Lb[r][c] = v * inv[c];
+    }
+  }
+  // 3. panel: rows at / below the block solve  x L_bb^T = row[o..o+5]
+  float x[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float v = row[o + c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) v -= x[k] * Lb[c][k];
+    x[c] = v * inv[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    if (t == o + c) x[c] = Lb[c][c];          // exact pivot on the diagonal lanes
+    row[o + c] = x[c];
+  }
+  if constexpr (B < 9) {
+    // 4. publish the panel, 5. trailing update of the columns to the right
+    *reinterpret_cast<f4*>(&Lp[t][0]) = (f4){x[0], x[1], x[2], x[3]};
+    Lp[t][4] = x[4]; Lp[t][5] = x[5];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int c2 = o + 6; c2 < 60; ++c2) {
+      const f4 l0 = *reinterpret_cast<const f4*>(&Lp[c2][0]);
+      const float l4 = Lp[c2][4], l5 = Lp[c2][5];
+      row[c2] -= x[0] * l0[0] + x[1] * l0[1] + x[2] * l0[2] + x[3] * l0[3] + x[4] * l4 + x[5] * l5;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(64) void ba_solve60_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
+                                                        float* __restrict__ dX, int32_t* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) float Lp[64][8];
+  __shared__ float Lf[60][61];
+  const int n6 = 6 * N;
+  const int t = threadIdx.x;
+  float row[60];
+#pragma unroll
+  for (int c = 0; c < 60; ++c) row[c] = (t < n6 && c < n6) ? Sg[t * n6 + c] : ((t == c) ? 1.0f : 0.0f);
+  float bv = (t < n6) ? yg[t] : 0.0f;
+  int bad = 0;
+  chol_block_step<0>(row, Lp, t, bad); chol_block_step<1>(row, Lp, t, bad); chol_block_step<2>(row, Lp, t, bad);
+  chol_block_step<3>(row, Lp, t, bad); chol_block_step<4>(row, Lp, t, bad); chol_block_step<5>(row, Lp, t, bad);
+  chol_block_step<6>(row, Lp, t, bad); chol_block_step<7>(row, Lp, t, bad); chol_block_step<8>(row, Lp, t, bad);
+  chol_block_step<9>(row, Lp, t, bad);
+  // L[t][c] = row[c] (c <= t).  Forward substitution L z = y on registers.
+  float dinv = 1.0f;
+#pragma unroll
+  for (int c = 0; c < 60; ++c) dinv = (t == c) ? 1.0f / row[c] : dinv;
+#pragma unroll
+  for (int k = 0; k < 60; ++k) {
+    const float zk = RL(bv, k) * RL(dinv, k);
+    if (t == k) bv = zk;
+    if (t > k) bv -= row[k] * zk;
+  }
+  // transpose through LDS for the backward substitution L^T x = z
+  if (t < 60) {
+#pragma unroll
+    for (int c = 0; c < 60; ++c) Lf[t][c] = row[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (t < 60) {
+#pragma unroll
+    for (int k = 0; k < 60; ++k) row[k] = Lf[k][t];       // row[k] := L[k][t]
+  }
+#pragma unroll
+  for (int k = 59; k >= 0; --k) {
+    const float xk = RL(bv, k) * RL(dinv, k);
+    if (t == k) bv = xk;
+    if (t < k) bv -= row[k] * xk;
+  }
+  if (t < n6) dX[t] = bv;
+  if (t == 0 && info) *info = bad;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 4. solve kernel: one workgroup, thread r owns row r.  n6 <= 64: a single wave, no barriers at all
 //    (LDS traffic of one wave is program-ordered; pivots travel by v_readlane); n6 <= 120: two waves.
 // ---------------------------------------------------------------------------------------------------
+// 4b. generic solve kernel (n6 <= 120)
 constexpr int kLdS = kMaxDim + 4;       // 124: 16-byte aligned rows, conflict-free for ds_read_b128
 
 template <bool ONE_WAVE>
@@ -320,18 +448,29 @@ __global__ void ba_retr_kernel(float* __restrict__ poses, float* __restrict__ pa
                                const int32_t* __restrict__ n_patches, const float* __restrict__ Qbuf,
                                const float* __restrict__ ubuf, const float* __restrict__ Ecol, int64_t ldE,
                                const float* __restrict__ dX, int t0, int N, int P) {
+  __shared__ float sdx[kMaxDim];
   const int np = *n_patches;
   const int PP = P * P, n6 = 6 * N;
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int a = threadIdx.x; a < n6; a += blockDim.x) sdx[a] = dX[a];
+  __syncthreads();
   for (int k = gt; k < np; k += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int a = 0; a < n6; ++a) s += Ecol[(int64_t)a * ldE + k] * dX[a];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // four independent chains: the loads overlap
+    int a = 0;
+    for (; a + 4 <= n6; a += 4) {
+      s0 += Ecol[(int64_t)(a + 0) * ldE + k] * sdx[a + 0];
+      s1 += Ecol[(int64_t)(a + 1) * ldE + k] * sdx[a + 1];
+      s2 += Ecol[(int64_t)(a + 2) * ldE + k] * sdx[a + 2];
+      s3 += Ecol[(int64_t)(a + 3) * ldE + k] * sdx[a + 3];
+    }
+    for (; a < n6; ++a) s0 += Ecol[(int64_t)a * ldE + k] * sdx[a];
+    const float s = (s0 + s1) + (s2 + s3);
     const float dZ = Qbuf[k] * (ubuf[k] - s);
     float* pk = patches + (int64_t)kx[k] * 3 * PP + 2 * PP;
     float d = pk[0] + dZ;
     d = (d > 20.0f) ? 1.0f : d;
     d = fmaxf(d, 1e-4f);
-    for (int a = 0; a < PP; ++a) pk[a] = d;
+    for (int a2 = 0; a2 < PP; ++a2) pk[a2] = d;
   }
   if (gt < N) {
     float* p = poses + 7 * (int64_t)(t0 + gt);
@@ -416,7 +555,9 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
     if (N > 0) {
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, spart,
                          (int)patch_blocks, t0, N, Sg, yg);
-      if (6 * N <= 64)
+      if (6 * N <= 60)
+        hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(64), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
+      else if (6 * N <= 64)
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(64), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
       else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(128), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);

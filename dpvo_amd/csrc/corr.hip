@@ -164,8 +164,17 @@ __global__ __launch_bounds__(64) void corr_pyramid_kernel(
   __shared__ int meta_i[32];
   __shared__ float meta_f[32];
   const int lane = threadIdx.x;
-  for (int64_t blk = blockIdx.x; blk < E; blk += gridDim.x) {
-    const int64_t e = order ? (int64_t)order[blk] : blk;
+  const int64_t nblk = order ? ((E + 7) >> 3) << 3 : E;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int64_t e = blk;
+    if (order) {
+      // XCD-aware walk of the hinted order: workgroup b runs on XCD b % 8 (observed, a speed hint only), so XCD x
+      // is handed the contiguous slice [x*per, (x+1)*per) of `order` and its L2 sees one target frame at a time.
+      const int64_t per = (E + 7) >> 3;
+      const int64_t v = (blk & 7) * per + (blk >> 3);
+      if (v >= E) continue;
+      e = order[v];
+    }
     const int64_t u = us[e], v = vs[e];
     // A fragments: template pixel m = lane&15 (<9), channels [(4s+kg)*8, +8)
     h8 a[4];
@@ -311,7 +320,8 @@ extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, co
   if (E == 0) return DPVO_OK;
   if (!gmap || !fmap0 || !fmap1 || !coords || !us || !vs || !out) return DPVO_E_INVALID;
   (void)N1; (void)N2;
-  const int64_t grid = E < (int64_t)1 << 20 ? E : (int64_t)1 << 20;
+  // with an order hint the grid is padded to 8 slices of ceil(E/8) so that the XCD remap is a bijection onto [0,E)
+  const int64_t grid = order ? ((E + 7) >> 3) << 3 : E;
   hipLaunchKernelGGL(corr_pyramid_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
                      (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
                      (_Float16*)out, ld_out, E, H0, W0, H1, W1);

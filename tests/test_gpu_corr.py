@@ -50,6 +50,10 @@ def test_pyramid_empty_and_order(oracle, dev):
     order = torch.randperm(64).int().to(dev)
     out2 = altcorr.corr_pyramid(g, a, b, coords.to(dev), us.to(dev), vs.to(dev), order=order)
     assert torch.equal(out, out2)        # processing order is a locality hint only: bit-identical results
+    for n in (1, 7, 61):                 # edge counts that are not a multiple of the 8 XCD slices
+        o = torch.randperm(n).int().to(dev)
+        r1 = altcorr.corr_pyramid(g, a, b, coords[:n].to(dev), us[:n].to(dev), vs[:n].to(dev), order=o)
+        assert torch.equal(r1, out[:n])
 
 
 @pytest.mark.parametrize("dtype,radius,P", [(torch.float16, 3, 3), (torch.float32, 3, 3), (torch.float16, 1, 1),

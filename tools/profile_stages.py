@@ -42,8 +42,9 @@ def main():
     res["reproject"] = timeit(lambda: pops.transform_coords(poses, patches, intr, ii, jj, kk))
     coords = pops.transform_coords(poses, patches, intr, ii, jj, kk)
     res["corr_pyramid"] = timeit(lambda: altcorr.corr_pyramid(g, a, b, coords, us, vs))
-    order = plan.perm_p
-    res["corr_pyramid(order=by pair)"] = timeit(lambda: altcorr.corr_pyramid(g, a, b, coords, us, vs, order=order))
+    res["corr_pyramid(order=by pair)"] = timeit(lambda: altcorr.corr_pyramid(g, a, b, coords, us, vs, order=plan.perm_p))
+    oj = torch.argsort(vs, stable=True).int()
+    res["corr_pyramid(order=by target frame)"] = timeit(lambda: altcorr.corr_pyramid(g, a, b, coords, us, vs, order=oj))
     corr = altcorr.corr_pyramid(g, a, b, coords, us, vs)
     net = torch.randn(1, E, 384, device=dev)
     res["update_total"] = timeit(lambda: upd(net, imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk,
