@@ -28,6 +28,7 @@ SYMBOLS = [
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges",
     "dpvo_motion_model", "dpvo_median_depth",
+    "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_pool4_nhwc",
 ]
 
 
@@ -56,7 +57,7 @@ def lib():
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
         for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
-                  "dpvo_gba_workspace_bytes"):
+                  "dpvo_gba_workspace_bytes", "dpvo_encoders_workspace_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
         _lib = L
     return _lib

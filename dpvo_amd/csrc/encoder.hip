@@ -1,0 +1,444 @@
+// encoder.hip -- the two feature encoders of the Patchifier (reference dpvo/extractor.py:200-264 BasicEncoder4,
+// ResidualBlock :6-55; called from dpvo/net.py:110-127) as hand-written MFMA implicit-GEMM convolutions for gfx950.
+//
+// SURVEY.md section 8(f) "next #1": the step right before the hot path, every frame, ~24 GFLOP.  MIOpen runs these
+// small-channel (32/64) convolutions on dot2 VALU kernels (0.9 ms) plus ~56 elementwise launches for bias / norm /
+// ReLU / residual; here
+//   * activations live in NHWC f16, so one pixel's channels are 64 / 128 contiguous bytes = MFMA fragments;
+//   * a workgroup computes an 8x32 output tile for 64 (or all) output channels: the input halo is staged ONCE in LDS
+//     (with the producer's InstanceNorm + ReLU applied on the way in, so normalised tensors are never materialised),
+//     then 9 taps x Cin/32 chunks of v_mfma_f32_16x16x32_f16 run from LDS; weights stream from L1/L2;
+//   * the epilogue adds the bias, rounds to f16 exactly where autocast rounds, stores NHWC and emits per-workgroup
+//     (sum, sum^2) partials per channel; the CONSUMER reduces them in a fixed order (deterministic InstanceNorm);
+//   * fnet (InstanceNorm) and inet (no norm) share every launch (grid.z = encoder).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;           // output tile (pixels)
+constexpr float kInEps = 1e-5f;          // nn.InstanceNorm2d default eps
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+struct EncPtrs {                         // one per encoder (z = 0 fnet, z = 1 inet)
+  const _Float16* in;                    // input activation NHWC (raw conv output of the producer, or materialised)
+  const float* in_part;                  // producer's (sum,sumsq) partials [n_part][2][Cin] or null
+  const _Float16* w;                     // weights [Cout][K]
+  const _Float16* bias;                  // [Cout]
+  _Float16* out;                         // NHWC raw conv output (bias added, f16)
+  float* out_part;                       // this conv's partials [gridDim.x*gridDim.y(tiles)][2][Cout] or null
+  int in_mode;                           // 0 identity, 1 relu, 2 instance-norm + relu
+  int cout;                              // number of output channels of THIS encoder for this layer
+  float out_scale;                       // multiplies the rounded f16 output (the "/ 4.0" of net.py:116-117)
+};
+struct EncArgs { EncPtrs e[2]; };
+
+__device__ __forceinline__ int swz4(int px) { return (0x78 >> (2 * ((px >> 2) & 3))) & 3; }   // 64 B pixels (Cin 32)
+
+// mean / rstd of the producer's channels from its per-workgroup partials, fixed summation order, f64 accumulate
+template <int CIN>
+__device__ __forceinline__ void reduce_stats(const float* part, int n_part, float inv_n, float* s_mean, float* s_rstd) {
+  for (int c = threadIdx.x; c < CIN; c += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < n_part; ++p) { s += (double)part[(p * 2 + 0) * CIN + c]; q += (double)part[(p * 2 + 1) * CIN + c]; }
+    const double mean = s * (double)inv_n;
+    const double var = q * (double)inv_n - mean * mean;
+    s_mean[c] = (float)mean;
+    s_rstd[c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)kInEps));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv KSxKS (KS = 3 pad 1, or KS = 1 pad 0), stride S, Cin in {32,64}, 64 output channels per workgroup (blockIdx.y)
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, int KS, int S, int NT>
+__global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Win, int Hout, int Wout, int n_part_in) {
+  constexpr int PAD = KS / 2;
+  constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+  constexpr int CPP = CIN / 8;                              // 16-byte chunks per pixel
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* halo = reinterpret_cast<_Float16*>(smem_raw);   // [IH][IW][CIN] swizzled
+  float* s_mean = reinterpret_cast<float*>(smem_raw + (size_t)IH * IW * CIN * 2);
+  float* s_rstd = s_mean + CIN;
+  float* s_red = s_rstd + CIN;                              // [4 waves][2][64]
+
+  const EncPtrs P = args.e[blockIdx.z];
+  const int n0 = blockIdx.y * (16 * NT);
+  if (n0 >= P.cout) return;
+  const int tiles_x = (Wout + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  if (P.in_mode == 2) reduce_stats<CIN>(P.in_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean, s_rstd);
+  __syncthreads();
+
+  // ---- stage the input halo (producer's norm + relu applied here; zero padding applies to the transformed tensor)
+  const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+  for (int q = tid; q < IH * IW * CPP; q += 256) {
+    const int ch = q % CPP, pix = q / CPP;
+    const int ly = pix / IW, lx = pix - ly * IW;
+    const int y = iy0 + ly, x = ix0 + lx;
+    h8 v = (h8)(_Float16)0;
+    if (y >= 0 && y < Hin && x >= 0 && x < Win) {
+      v = *reinterpret_cast<const h8*>(P.in + ((int64_t)y * Win + x) * CIN + ch * 8);
+      if (P.in_mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const _Float16 nv = (_Float16)(((float)v[k] - s_mean[ch * 8 + k]) * s_rstd[ch * 8 + k]);   // IN output is f16
+          v[k] = nv > (_Float16)0 ? nv : (_Float16)0;
+        }
+      } else if (P.in_mode == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] > (_Float16)0 ? v[k] : (_Float16)0;
+      }
+    }
+    const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+    *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
+  }
+  __syncthreads();
+
+  // ---- implicit GEMM: wave w owns output rows 2w, 2w+1 (4 M-tiles of 16 pixels), 4 N-tiles (64 channels)
+  f4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f4)0.f;
+  const int m = lane & 15, kg = lane >> 4;
+  const int ncout = P.cout;
+  constexpr int K = KS * KS * CIN;
+#pragma unroll
+  for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+      for (int kc = 0; kc < CIN / 32; ++kc) {
+        h8 fw[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + m;
+          fw[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w + (int64_t)n * K + ((kh * KS + kw) * CIN + kc * 32 + kg * 8))
+                              : (h8)(_Float16)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ly = (2 * wave + (i >> 1)) * S + kh, lx = ((i & 1) * 16 + m) * S + kw;
+          const int ch = kc * 4 + kg;
+          const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+          const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa, acc[i][j], 0, 0, 0);
+        }
+      }
+
+  // ---- epilogue: bias, f16 rounding, NHWC store, per-channel partial statistics of the ROUNDED values
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oy = oy0 + 2 * wave + (i >> 1), ox = ox0 + (i & 1) * 16 + m;
+    const bool inb = oy < Hout && ox < Wout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + kg * 4;
+      if (n >= ncout) continue;
+      const h4 bv = *reinterpret_cast<const h4*>(P.bias + n);
+      h4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hv[r] = (_Float16)(acc[i][j][r] + (float)bv[r]);
+        if (inb) { const float f = (float)hv[r]; ssum[j][r] += f; ssq[j][r] += f * f; }
+        hv[r] = (_Float16)((float)hv[r] * P.out_scale);
+      }
+      if (inb) *reinterpret_cast<h4*>(P.out + ((int64_t)oy * Wout + ox) * ncout + n) = hv;
+    }
+  }
+  if (P.out_part) {
+    // reduce over the 16 pixel lanes (xor 1,2,4,8 keeps kg), then over the 4 waves through LDS, fixed order
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = ssum[j][r], b = ssq[j][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (m == 0) { s_red[(wave * 2 + 0) * 64 + j * 16 + kg * 4 + r] = a; s_red[(wave * 2 + 1) * 64 + j * 16 + kg * 4 + r] = b; }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      if (c < 16 * NT && n0 + c < ncout) {
+        const float v = ((s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c]) +
+                         (s_red[(2 * 2 + which) * 64 + c] + s_red[(3 * 2 + which) * 64 + c]));
+        P.out_part[((int64_t)blockIdx.x * 2 + which) * ncout + n0 + c] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv1: 7x7 stride 2 pad 3, 3 -> 32 channels, planar f16 input image [3][H][W] (shared by both encoders).
+// K is ordered (kh, c, kw) with kw padded 7 -> 8 so that one k-group of 8 = one input row segment of 8 contiguous
+// pixels (stride-1 in x for a fixed output pixel): K = 21 groups -> padded to 24 groups = 6 chunks of 32.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__ img, EncArgs args, int H, int W, int Hout,
+                                                    int Wout) {
+  constexpr int IH = (TH - 1) * 2 + 7, IW = (TW - 1) * 2 + 7 + 1, IWP = 72;     // 21 x 70 (+pad) per channel
+  __shared__ __attribute__((aligned(16))) _Float16 halo[3 * IH * IWP];
+  __shared__ float s_red[4 * 2 * 32];
+  const EncPtrs P = args.e[blockIdx.z];
+  const int tiles_x = (Wout + TW - 1) / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  for (int q = tid; q < 3 * IH * IWP; q += 256) {
+    const int lx = q % IWP, ly = (q / IWP) % IH, c = q / (IWP * IH);
+    const int y = iy0 + ly, x = ix0 + lx;
+    _Float16 v = (_Float16)0;
+    if (lx < IW && y >= 0 && y < H && x >= 0 && x < W) v = img[((int64_t)c * H + y) * W + x];
+    halo[q] = v;
+  }
+  __syncthreads();
+  f4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = (f4)0.f; acc[i][1] = (f4)0.f; }
+  const int m = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int g = q * 4 + kg;                         // k-group: (kh, c) = (g / 3, g % 3), valid for g < 21
+    const int kh = g / 3, c = g - 3 * kh;
+    h8 fw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const h8*>(P.w + (int64_t)(j * 16 + m) * 192 + g * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h8 fa = (h8)(_Float16)0;
+      if (g < 21) {
+        const int ly = (2 * wave + (i >> 1)) * 2 + kh, lx = ((i & 1) * 16 + m) * 2;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(halo + (c * IH + ly) * IWP + lx);   // 4-byte aligned
+        const u4v u = {p[0], p[1], p[2], p[3]};
+        fa = __builtin_bit_cast(h8, u);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa, acc[i][j], 0, 0, 0);
+    }
+  }
+  float ssum[2][4], ssq[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int oy = oy0 + 2 * wave + (i >> 1), ox = ox0 + (i & 1) * 16 + m;
+    const bool inb = oy < Hout && ox < Wout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = j * 16 + kg * 4;
+      const h4 bv = *reinterpret_cast<const h4*>(P.bias + n);
+      h4 hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hv[r] = (_Float16)(acc[i][j][r] + (float)bv[r]);
+        if (inb) { const float f = (float)hv[r]; ssum[j][r] += f; ssq[j][r] += f * f; }
+      }
+      if (inb) *reinterpret_cast<h4*>(P.out + ((int64_t)oy * Wout + ox) * 32 + n) = hv;
+    }
+  }
+  if (P.out_part) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = ssum[j][r], b = ssq[j][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (m == 0) { s_red[(wave * 2 + 0) * 32 + j * 16 + kg * 4 + r] = a; s_red[(wave * 2 + 1) * 32 + j * 16 + kg * 4 + r] = b; }
+      }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      P.out_part[((int64_t)blockIdx.x * 2 + which) * 32 + c] =
+          (s_red[(0 * 2 + which) * 32 + c] + s_red[(1 * 2 + which) * 32 + c]) +
+          (s_red[(2 * 2 + which) * 32 + c] + s_red[(3 * 2 + which) * 32 + c]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// residual-block output (extractor.py:44-55): out = relu(fx(x) + relu(fy(y))), f = InstanceNorm (from partials) or id;
+// all intermediate roundings to f16 at the points the reference (f16 tensors) has them.
+// ---------------------------------------------------------------------------------------------------
+struct ResPtrs {
+  const _Float16* x; const float* x_part; int x_mode;      // 0 identity, 1 relu, 2 instance-norm, 3 instance-norm + relu
+  const _Float16* y; const float* y_part; int y_mode;      // 1 relu, 3 instance-norm + relu
+  _Float16* out;
+};
+struct ResArgs { ResPtrs e[2]; };
+
+template <int C>
+__global__ __launch_bounds__(256) void resout_kernel(ResArgs args, int64_t npix, int n_part_x, int n_part_y) {
+  __shared__ float mx[C], rx[C], my[C], ry[C];
+  const ResPtrs P = args.e[blockIdx.y];
+  if (P.x_mode >= 2) reduce_stats<C>(P.x_part, n_part_x, 1.0f / (float)npix, mx, rx);
+  if (P.y_mode >= 2) reduce_stats<C>(P.y_part, n_part_y, 1.0f / (float)npix, my, ry);
+  __syncthreads();
+  const int64_t nchunk = npix * (C / 8);
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nchunk; q += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(q % (C / 8));
+    h8 xv = *reinterpret_cast<const h8*>(P.x + q * 8);
+    h8 yv = *reinterpret_cast<const h8*>(P.y + q * 8);
+    h8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = ch * 8 + k;
+      _Float16 a = xv[k], b = yv[k];
+      if (P.x_mode >= 2) a = (_Float16)(((float)a - mx[c]) * rx[c]);
+      if (P.x_mode & 1) a = a > (_Float16)0 ? a : (_Float16)0;
+      if (P.y_mode >= 2) b = (_Float16)(((float)b - my[c]) * ry[c]);
+      b = b > (_Float16)0 ? b : (_Float16)0;
+      const _Float16 s = a + b;                               // f16 add (x + y on f16 tensors)
+      o[k] = s > (_Float16)0 ? s : (_Float16)0;
+    }
+    *reinterpret_cast<h8*>(P.out + q * 8) = o;
+  }
+}
+
+template <int CIN, int KS, int S, int NT>
+int launch_conv(const EncArgs& a, int Hin, int Win, int Hout, int Wout, int n_part_in, int cout_max, hipStream_t st) {
+  constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+  const size_t sh = (size_t)IH * IW * CIN * 2 + (2 * CIN + 4 * 2 * 64) * 4;
+  (void)hipFuncSetAttribute((const void*)conv_kernel<CIN, KS, S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  const int tiles = ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW);
+  hipLaunchKernelGGL((conv_kernel<CIN, KS, S, NT>), dim3(tiles, (cout_max + 16 * NT - 1) / (16 * NT), 2), dim3(256), sh, st, a, Hin, Win, Hout,
+                     Wout, n_part_in);
+  return (int)hipGetLastError();
+}
+
+// 4x4 average pooling of an NHWC map (dpvo.py:438: fmap2_ = F.avg_pool2d(fmap, 4, 4)), f32 accumulate, one rounding
+__global__ void pool4_nhwc_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int h, int w, int C) {
+  const int h4 = h / 4, w4 = w / 4, c8 = C / 8;
+  const int64_t total = (int64_t)h4 * w4 * c8;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(q % c8);
+    const int64_t pix = q / c8;
+    const int px = (int)(pix % w4), py = (int)(pix / w4);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const h8 v = *reinterpret_cast<const h8*>(in + ((int64_t)(py * 4 + a) * w + px * 4 + b) * C + ch * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+      }
+    h8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] / 16.0f);
+    *reinterpret_cast<h8*>(out + pix * C + ch * 8) = o;
+  }
+}
+
+}  // namespace
+
+// Weight / bias pointer table, per encoder (fnet then inet), in this order (all f16, repacked by the host):
+//   0 conv1 w[32][192]  1 conv1 b     (K = (kh, c, kw padded to 8), zero padded to 192)
+//   then for each 3x3 / 1x1 conv  w[Cout][KS*KS*Cin] with K = (kh, kw, cin), b[Cout]:
+//   2,3   layer1.0.conv1 (32->32)     4,5   layer1.0.conv2      6,7   layer1.1.conv1     8,9   layer1.1.conv2
+//   10,11 layer2.0.conv1 (32->64 s2)  12,13 layer2.0.conv2 (64) 14,15 layer2.0.downsample.0 (1x1 s2 32->64)
+//   16,17 layer2.1.conv1 (64->64)     18,19 layer2.1.conv2      20,21 conv2 (1x1, 64 -> 128 | 384)
+static inline size_t enc_al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t dpvo_encoders_workspace_bytes(int H, int W) {
+  if (H <= 0 || W <= 0 || (H % 16) || (W % 16)) return 0;
+  const size_t h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4;
+  const size_t a32 = enc_al(h2 * w2 * 32 * 2), a64 = enc_al(h4 * w4 * 64 * 2);
+  const size_t t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW);
+  const size_t part = enc_al(t2 * 2 * 64 * 4);
+  return 2 * (3 * a32 + 3 * a64 + 4 * part) + 4096;
+}
+
+// fmap_out [H/4][W/4][128], imap_out [H/4][W/4][384] f16 NHWC, both already divided by 4 (net.py:116-117).
+extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out,
+                                     int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  if (!image_f16 || !weights || !fmap_out || !imap_out || !ws) return DPVO_E_INVALID;
+  if (H <= 0 || W <= 0 || (H % 16) || (W % 16)) return DPVO_E_UNSUPPORTED;
+  if (ws_bytes < dpvo_encoders_workspace_bytes(H, W)) return DPVO_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4;
+  const size_t a32 = enc_al((size_t)h2 * w2 * 32 * 2), a64 = enc_al((size_t)h4 * w4 * 64 * 2);
+  const int t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW), t4 = ((h4 + TH - 1) / TH) * ((w4 + TW - 1) / TW);
+  const size_t part = enc_al((size_t)t2 * 2 * 64 * 4);
+  char* base = (char*)ws;
+  _Float16 *A[2][3], *B[2][3];
+  float* Pt[2][4];
+  for (int z = 0; z < 2; ++z) {
+    for (int i = 0; i < 3; ++i) { A[z][i] = (_Float16*)base; base += a32; }
+    for (int i = 0; i < 3; ++i) { B[z][i] = (_Float16*)base; base += a64; }
+    for (int i = 0; i < 4; ++i) { Pt[z][i] = (float*)base; base += part; }
+  }
+  auto Wp = [&](int z, int i) { return (const _Float16*)weights[z * 22 + i]; };
+  const bool nm[2] = {true, false};                       // fnet: instance norm, inet: none (net.py:98-99)
+  const int64_t np2 = (int64_t)h2 * w2, np4 = (int64_t)h4 * w4;
+  int rc;
+  EncArgs a;
+  ResArgs r;
+  const int cin_mode[2] = {2, 1};                         // consumer-side transform of a raw conv output: IN+relu | relu
+  const unsigned rgrid2 = (unsigned)((np2 * 4 + 255) / 256 < 2048 ? (np2 * 4 + 255) / 256 : 2048);
+  const unsigned rgrid4 = (unsigned)((np4 * 8 + 255) / 256 < 2048 ? (np4 * 8 + 255) / 256 : 2048);
+#define STATS(z, i) (nm[z] ? Pt[z][i] : nullptr)
+
+  // conv1 (7x7 s2) -> A0 raw, stats P0; x0 = relu(norm1(A0)) is applied on the fly by its consumers      :252-254
+  for (int z = 0; z < 2; ++z) a.e[z] = {nullptr, nullptr, Wp(z, 0), Wp(z, 1), A[z][0], STATS(z, 0), 0, 32, 1.0f};
+  hipLaunchKernelGGL(conv1_kernel, dim3(t2, 1, 2), dim3(256), 0, st, (const _Float16*)image_f16, a, H, W, h2, w2);
+
+  // ---- layer1.0 (ResidualBlock 32->32, :44-55): c1 -> A1 (P1), c2 -> A2 (P2), out -> A1
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], STATS(z, 0), Wp(z, 2), Wp(z, 3), A[z][1], STATS(z, 1), cin_mode[z], 32, 1.0f};
+  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][1], STATS(z, 1), Wp(z, 4), Wp(z, 5), A[z][2], STATS(z, 2), cin_mode[z], 32, 1.0f};
+  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  for (int z = 0; z < 2; ++z) r.e[z] = {A[z][0], STATS(z, 0), nm[z] ? 3 : 1, A[z][2], STATS(z, 2), nm[z] ? 3 : 1, A[z][1]};
+  hipLaunchKernelGGL(resout_kernel<32>, dim3(rgrid2, 2), dim3(256), 0, st, r, np2, t2, t2);
+  // ---- layer1.1: input X1 = A1; c1 -> A0 (P0), c2 -> A2 (P1), out -> A0
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][1], nullptr, Wp(z, 6), Wp(z, 7), A[z][0], STATS(z, 0), 0, 32, 1.0f};
+  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], STATS(z, 0), Wp(z, 8), Wp(z, 9), A[z][2], STATS(z, 1), cin_mode[z], 32, 1.0f};
+  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  for (int z = 0; z < 2; ++z) r.e[z] = {A[z][1], nullptr, 0, A[z][2], STATS(z, 1), nm[z] ? 3 : 1, A[z][0]};
+  hipLaunchKernelGGL(resout_kernel<32>, dim3(rgrid2, 2), dim3(256), 0, st, r, np2, t2, t2);
+  // ---- layer2.0 (32->64, stride 2): input X2 = A0; c1 -> B0 (P0), c2 -> B1 (P2), downsample -> B2 (P3), out -> B0
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 10), Wp(z, 11), B[z][0], STATS(z, 0), 0, 64, 1.0f};
+  if ((rc = launch_conv<32, 3, 2, 4>(a, h2, w2, h4, w4, 0, 64, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], STATS(z, 0), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 2), cin_mode[z], 64, 1.0f};
+  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 14), Wp(z, 15), B[z][2], STATS(z, 3), 0, 64, 1.0f};
+  if ((rc = launch_conv<32, 1, 2, 4>(a, h2, w2, h4, w4, 0, 64, st))) return rc;
+  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][2], STATS(z, 3), nm[z] ? 2 : 0, B[z][1], STATS(z, 2), nm[z] ? 3 : 1, B[z][0]};
+  hipLaunchKernelGGL(resout_kernel<64>, dim3(rgrid4, 2), dim3(256), 0, st, r, np4, t4, t4);
+  // ---- layer2.1: input X3 = B0; c1 -> B1 (P0), c2 -> B2 (P1), out -> B1
+  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], nullptr, Wp(z, 16), Wp(z, 17), B[z][1], STATS(z, 0), 0, 64, 1.0f};
+  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, 0, 64, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][1], STATS(z, 0), Wp(z, 18), Wp(z, 19), B[z][2], STATS(z, 1), cin_mode[z], 64, 1.0f};
+  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
+  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][0], nullptr, 0, B[z][2], STATS(z, 1), nm[z] ? 3 : 1, B[z][1]};
+  hipLaunchKernelGGL(resout_kernel<64>, dim3(rgrid4, 2), dim3(256), 0, st, r, np4, t4, t4);
+  // ---- conv2 (1x1, 64 -> 128 | 384), output / 4.0                                                     :259, net.py:116-117
+  a.e[0] = {B[0][1], nullptr, Wp(0, 20), Wp(0, 21), (_Float16*)fmap_out, nullptr, 0, 128, 0.25f};
+  a.e[1] = {B[1][1], nullptr, Wp(1, 20), Wp(1, 21), (_Float16*)imap_out, nullptr, 0, 384, 0.25f};
+  if ((rc = launch_conv<64, 1, 1, 4>(a, h4, w4, h4, w4, 0, 384, st))) return rc;
+#undef STATS
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_pool4_nhwc(const void* in, void* out, int h, int w, int C, void* stream) {
+  if (!in || !out || h <= 0 || w <= 0 || (h % 4) || (w % 4) || (C % 8)) return DPVO_E_INVALID;
+  const int64_t total = (int64_t)(h / 4) * (w / 4) * (C / 8);
+  hipLaunchKernelGGL(pool4_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)in, (_Float16*)out, h, w, C);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}

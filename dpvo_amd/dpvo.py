@@ -90,6 +90,7 @@ class DPVO:
         self.pyramid = (self.fmap1_, self.fmap2_)
 
         self._plan = None          # GraphPlan of the active edge list (rebuilt when edges change)
+        self._imap_full = None
         self._corr_buf = None
 
         self.viewer = None
@@ -126,9 +127,12 @@ class DPVO:
         # MIXED_PRECISION: the reference re-casts every conv weight to f16 through autocast on every frame
         # (dpvo.py:391); the encoders are cast once here and run in f16 directly (same kernels, same arithmetic).
         self._enc_half = bool(self.cfg.MIXED_PRECISION)
+        self._hip_enc = None
         if self._enc_half:
             self.network.patchify.fnet.half()
             self.network.patchify.inet.half()
+            from .encoders import HipEncoders
+            self._hip_enc = HipEncoders(self.network.patchify.fnet, self.network.patchify.inet)
 
     def start_viewer(self):
         raise NotImplementedError("DPViewer (Pangolin) is out of scope; run headless")
@@ -413,11 +417,22 @@ class DPVO:
         L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),
                                              L.stream()), "dpvo_normalize_image")
 
+        maps = None
+        if self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM':
+            # both encoders as 15 MFMA launches, fmap written straight into its channels-last ring slot
+            # (the reference also writes fmap1_[n % mem] before the motion probe may reject the frame, dpvo.py:437)
+            slot = self._fmap1_cl[self.n % self.mem]
+            if self._imap_full is None:
+                self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
+            self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
+            maps = (slot, self._imap_full)
+
         fmap, gmap, imap, patches, _, coords = \
             self.network.patchify(img32 if img32 is not None else img16,
                                   patches_per_image=self.cfg.PATCHES_PER_FRAME,
                                   centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
-                                  coords=patch_coords, half=self._enc_half, images_f16=img16, return_coords=True)
+                                  coords=patch_coords, half=self._enc_half, images_f16=img16, return_coords=True,
+                                  maps=maps)
 
         ### update state attributes ###
         self.tlist.append(tstamp)
@@ -462,11 +477,16 @@ class DPVO:
         self.imap_[self.n % self.pmem] = imap.squeeze()
         self.gmap_[self.n % self.pmem] = gmap.squeeze()
         # fmap1_[:, n % mem] = avg_pool2d(fmap, 1, 1); fmap2_[:, n % mem] = avg_pool2d(fmap, 4, 4): one transposing kernel
-        fm = fmap[0, 0].contiguous()
-        L.check(L.lib().dpvo_store_features(L.ptr(fm), L.ptr(self._fmap1_cl[self.n % self.mem]),
-                                            L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(L.dtype_code(fm.dtype)),
-                                            L.i32(fm.shape[0]), L.i32(fm.shape[1]), L.i32(fm.shape[2]), L.stream()),
-                "dpvo_store_features")
+        if maps is not None:
+            hh, ww = maps[0].shape[:2]
+            L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(hh), L.i32(ww),
+                                            L.i32(128), L.stream()), "dpvo_pool4_nhwc")
+        else:
+            fm = fmap[0, 0].contiguous()
+            L.check(L.lib().dpvo_store_features(L.ptr(fm), L.ptr(self._fmap1_cl[self.n % self.mem]),
+                                                L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(L.dtype_code(fm.dtype)),
+                                                L.i32(fm.shape[0]), L.i32(fm.shape[1]), L.i32(fm.shape[2]), L.stream()),
+                    "dpvo_store_features")
 
         self.counter += 1
         if self.n > 0 and not self.is_initialized:

@@ -245,13 +245,18 @@ class Patchifier(nn.Module):
         return g
 
     def forward(self, images, patches_per_image=80, disps=None, centroid_sel_strat='RANDOM', return_color=False,
-                coords=None, half=False, images_f16=None, return_coords=False):
+                coords=None, half=False, images_f16=None, return_coords=False, maps=None):
         """`coords` ([n, patches, 2] float, optional) injects the patch centroids (deterministic tests / oracle
         replay); otherwise they are drawn exactly like the reference (x then y, net.py:131-133).
         `half`: the encoders hold f16 weights (DPVO casts them once) and are fed an f16 copy of the image."""
-        enc_in = images_f16 if images_f16 is not None else (images.half() if half else images)
-        fmap = self.fnet(enc_in) / 4.0
-        imap = self.inet(enc_in) / 4.0
+        if maps is not None:
+            # (fmap, imap) already computed by the HIP encoders as NHWC f16 maps, "/ 4" included: expose NCHW views
+            fmap = maps[0].permute(2, 0, 1)[None, None]
+            imap = maps[1].permute(2, 0, 1)[None, None]
+        else:
+            enc_in = images_f16 if images_f16 is not None else (images.half() if half else images)
+            fmap = self.fnet(enc_in) / 4.0
+            imap = self.inet(enc_in) / 4.0
         b, n, c, h, w = fmap.shape
         P = self.patch_size
         dev = fmap.device

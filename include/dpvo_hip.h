@@ -250,6 +250,24 @@ int dpvo_motion_model(float* poses, int n, float scale, void* stream);
 /* depth initialisation (dpvo.py:430-432): patches[n][:,2] = torch.median(patches[n-3:n,:,2]) (lower median). */
 int dpvo_median_depth(float* patches, int n, int M, int P, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * feature encoders  (Patchifier.fnet / .inet: dpvo/extractor.py:200-264, called at dpvo/net.py:116-117)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Both BasicEncoder4 towers on one normalised f16 image [3,H,W] (planar), H, W multiples of 16:
+ *   fmap_out [H/4][W/4][128] = fnet(image) / 4   (InstanceNorm tower)      -- NHWC f16
+ *   imap_out [H/4][W/4][384] = inet(image) / 4   (no normalisation)        -- NHWC f16
+ * weights: 44 device pointers (22 per tower, fnet first) to f16 tensors repacked by the host:
+ *   [0] conv1.weight as [32][192]: K ordered (kh, c, kw) with kw padded 7->8 and K padded 168->192; [1] conv1.bias;
+ *   then weight [Cout][kh][kw][Cin] / bias pairs of layer1.0.conv1, layer1.0.conv2, layer1.1.conv1, layer1.1.conv2,
+ *   layer2.0.conv1 (stride 2), layer2.0.conv2, layer2.0.downsample.0 (1x1 stride 2), layer2.1.conv1, layer2.1.conv2,
+ *   conv2 (1x1).  15 launches for both towers (MIOpen path: ~114). */
+size_t dpvo_encoders_workspace_bytes(int H, int W);
+int dpvo_encoders_forward(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out, int H, int W,
+                          void* ws, size_t ws_bytes, void* stream);
+/* F.avg_pool2d(fmap, 4, 4) on an NHWC f16 map (dpvo/dpvo.py:438). */
+int dpvo_pool4_nhwc(const void* in, void* out, int h, int w, int C, void* stream);
+
 /* Global BA == cuda_ba.forward(..., eff_impl=True) (ba_cuda.cu:475-478,538-550 with EfficentE, block_e.cu:43-300),
  * used by DPVO.__run_global_BA (dpvo/dpvo.py:312-326).  One Gauss-Newton iteration is
  *     zero S[6N,6N], y[6N];  dpvo_gba_linearize -> S = B - E Q E^T, y = v - E Q u  (block-sparse E, device plan);
