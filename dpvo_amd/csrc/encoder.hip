@@ -21,11 +21,11 @@ typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 
 struct EncPtrs {                         // one per encoder (z = 0 fnet, z = 1 inet)
   const _Float16* in;                    // input activation NHWC (raw conv output of the producer, or materialised)
-  const float* in_part;                  // producer's (sum,sumsq) partials [n_part][2][Cin] or null
+  const double* in_part;                 // producer's per-channel (sum, sum^2) accumulators [2][64] or null
   const _Float16* w;                     // weights [Cout][K]
   const _Float16* bias;                  // [Cout]
   _Float16* out;                         // NHWC raw conv output (bias added, f16)
-  float* out_part;                       // this conv's partials [gridDim.x*gridDim.y(tiles)][2][Cout] or null
+  double* out_part;                      // this conv's (sum, sum^2) accumulators [2][64] (zeroed by the host) or null
   int in_mode;                           // 0 identity, 1 relu, 2 instance-norm + relu
   int cout;                              // number of output channels of THIS encoder for this layer
   float out_scale;                       // multiplies the rounded f16 output (the "/ 4.0" of net.py:116-117)
@@ -34,14 +34,14 @@ struct EncArgs { EncPtrs e[2]; };
 
 __device__ __forceinline__ int swz4(int px) { return (0x78 >> (2 * ((px >> 2) & 3))) & 3; }   // 64 B pixels (Cin 32)
 
-// mean / rstd of the producer's channels from its per-workgroup partials, fixed summation order, f64 accumulate
+// mean / rstd of the producer's channels from its f64 (sum, sum^2) accumulators.  Producers add one f64 atomic per
+// channel per workgroup (hardware global_atomic_add_f64); summation order effects are ~1e-16 relative, far below the
+// f32 statistics derived here.
 template <int CIN>
-__device__ __forceinline__ void reduce_stats(const float* part, int n_part, float inv_n, float* s_mean, float* s_rstd) {
+__device__ __forceinline__ void reduce_stats(const double* acc, int /*unused*/, float inv_n, float* s_mean, float* s_rstd) {
   for (int c = threadIdx.x; c < CIN; c += blockDim.x) {
-    double s = 0.0, q = 0.0;
-    for (int p = 0; p < n_part; ++p) { s += (double)part[(p * 2 + 0) * CIN + c]; q += (double)part[(p * 2 + 1) * CIN + c]; }
-    const double mean = s * (double)inv_n;
-    const double var = q * (double)inv_n - mean * mean;
+    const double mean = acc[c] * (double)inv_n;
+    const double var = acc[64 + c] * (double)inv_n - mean * mean;
     s_mean[c] = (float)mean;
     s_rstd[c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)kInEps));
   }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       if (c < 16 * NT && n0 + c < ncout) {
         const float v = ((s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c]) +
                          (s_red[(2 * 2 + which) * 64 + c] + s_red[(3 * 2 + which) * 64 + c]));
-        P.out_part[((int64_t)blockIdx.x * 2 + which) * ncout + n0 + c] = v;
+        unsafeAtomicAdd(&P.out_part[which * 64 + n0 + c], (double)v);
       }
     }
   }
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
     __syncthreads();
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
-      P.out_part[((int64_t)blockIdx.x * 2 + which) * 32 + c] =
-          (s_red[(0 * 2 + which) * 32 + c] + s_red[(1 * 2 + which) * 32 + c]) +
-          (s_red[(2 * 2 + which) * 32 + c] + s_red[(3 * 2 + which) * 32 + c]);
+      unsafeAtomicAdd(&P.out_part[which * 64 + c],
+                      (double)((s_red[(0 * 2 + which) * 32 + c] + s_red[(1 * 2 + which) * 32 + c]) +
+                               (s_red[(2 * 2 + which) * 32 + c] + s_red[(3 * 2 + which) * 32 + c])));
     }
   }
 }
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
 // all intermediate roundings to f16 at the points the reference (f16 tensors) has them.
 // ---------------------------------------------------------------------------------------------------
 struct ResPtrs {
-  const _Float16* x; const float* x_part; int x_mode;      // 0 identity, 1 relu, 2 instance-norm, 3 instance-norm + relu
-  const _Float16* y; const float* y_part; int y_mode;      // 1 relu, 3 instance-norm + relu
+  const _Float16* x; const double* x_part; int x_mode;      // 0 identity, 1 relu, 2 instance-norm, 3 instance-norm + relu
+  const _Float16* y; const double* y_part; int y_mode;      // 1 relu, 3 instance-norm + relu
   _Float16* out;
 };
 struct ResArgs { ResPtrs e[2]; };
@@ -357,8 +357,7 @@ extern "C" size_t dpvo_encoders_workspace_bytes(int H, int W) {
   const size_t h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4;
   const size_t a32 = enc_al(h2 * w2 * 32 * 2), a64 = enc_al(h4 * w4 * 64 * 2);
   const size_t t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW);
-  const size_t part = enc_al(t2 * 2 * 64 * 4);
-  return 2 * (3 * a32 + 3 * a64 + 4 * part) + 4096;
+  return 2 * (3 * a32 + 3 * a64) + enc_al(2 * 10 * 128 * 8) + 4096;
 }
 
 // fmap_out [H/4][W/4][128], imap_out [H/4][W/4][384] f16 NHWC, both already divided by 4 (net.py:116-117).
@@ -371,18 +370,25 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
   const int h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4;
   const size_t a32 = enc_al((size_t)h2 * w2 * 32 * 2), a64 = enc_al((size_t)h4 * w4 * 64 * 2);
   const int t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW), t4 = ((h4 + TH - 1) / TH) * ((w4 + TW - 1) / TW);
-  const size_t part = enc_al((size_t)t2 * 2 * 64 * 4);
   char* base = (char*)ws;
   _Float16 *A[2][3], *B[2][3];
-  float* Pt[2][4];
   for (int z = 0; z < 2; ++z) {
     for (int i = 0; i < 3; ++i) { A[z][i] = (_Float16*)base; base += a32; }
     for (int i = 0; i < 3; ++i) { B[z][i] = (_Float16*)base; base += a64; }
-    for (int i = 0; i < 4; ++i) { Pt[z][i] = (float*)base; base += part; }
   }
+  // ten (sum, sum^2) accumulator sets per tower, one per statistics-producing conv, zeroed once per forward
+  double* Sacc = (double*)base;
+  {
+    hipError_t e = hipMemsetAsync(Sacc, 0, (size_t)2 * 10 * 128 * 8, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  double* Pt[2][10];
+  for (int z = 0; z < 2; ++z)
+    for (int i = 0; i < 10; ++i) Pt[z][i] = Sacc + ((size_t)z * 10 + i) * 128;
   auto Wp = [&](int z, int i) { return (const _Float16*)weights[z * 22 + i]; };
   const bool nm[2] = {true, false};                       // fnet: instance norm, inet: none (net.py:98-99)
   const int64_t np2 = (int64_t)h2 * w2, np4 = (int64_t)h4 * w4;
+  (void)t4;
   int rc;
   EncArgs a;
   ResArgs r;
@@ -403,27 +409,27 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
   for (int z = 0; z < 2; ++z) r.e[z] = {A[z][0], STATS(z, 0), nm[z] ? 3 : 1, A[z][2], STATS(z, 2), nm[z] ? 3 : 1, A[z][1]};
   hipLaunchKernelGGL(resout_kernel<32>, dim3(rgrid2, 2), dim3(256), 0, st, r, np2, t2, t2);
   // ---- layer1.1: input X1 = A1; c1 -> A0 (P0), c2 -> A2 (P1), out -> A0
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][1], nullptr, Wp(z, 6), Wp(z, 7), A[z][0], STATS(z, 0), 0, 32, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][1], nullptr, Wp(z, 6), Wp(z, 7), A[z][0], STATS(z, 3), 0, 32, 1.0f};
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], STATS(z, 0), Wp(z, 8), Wp(z, 9), A[z][2], STATS(z, 1), cin_mode[z], 32, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], STATS(z, 3), Wp(z, 8), Wp(z, 9), A[z][2], STATS(z, 4), cin_mode[z], 32, 1.0f};
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {A[z][1], nullptr, 0, A[z][2], STATS(z, 1), nm[z] ? 3 : 1, A[z][0]};
+  for (int z = 0; z < 2; ++z) r.e[z] = {A[z][1], nullptr, 0, A[z][2], STATS(z, 4), nm[z] ? 3 : 1, A[z][0]};
   hipLaunchKernelGGL(resout_kernel<32>, dim3(rgrid2, 2), dim3(256), 0, st, r, np2, t2, t2);
   // ---- layer2.0 (32->64, stride 2): input X2 = A0; c1 -> B0 (P0), c2 -> B1 (P2), downsample -> B2 (P3), out -> B0
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 10), Wp(z, 11), B[z][0], STATS(z, 0), 0, 64, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 10), Wp(z, 11), B[z][0], STATS(z, 5), 0, 64, 1.0f};
   if ((rc = launch_conv<32, 3, 2, 4>(a, h2, w2, h4, w4, 0, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], STATS(z, 0), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 2), cin_mode[z], 64, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], STATS(z, 5), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 6), cin_mode[z], 64, 1.0f};
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 14), Wp(z, 15), B[z][2], STATS(z, 3), 0, 64, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 14), Wp(z, 15), B[z][2], STATS(z, 7), 0, 64, 1.0f};
   if ((rc = launch_conv<32, 1, 2, 4>(a, h2, w2, h4, w4, 0, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][2], STATS(z, 3), nm[z] ? 2 : 0, B[z][1], STATS(z, 2), nm[z] ? 3 : 1, B[z][0]};
+  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][2], STATS(z, 7), nm[z] ? 2 : 0, B[z][1], STATS(z, 6), nm[z] ? 3 : 1, B[z][0]};
   hipLaunchKernelGGL(resout_kernel<64>, dim3(rgrid4, 2), dim3(256), 0, st, r, np4, t4, t4);
   // ---- layer2.1: input X3 = B0; c1 -> B1 (P0), c2 -> B2 (P1), out -> B1
-  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], nullptr, Wp(z, 16), Wp(z, 17), B[z][1], STATS(z, 0), 0, 64, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], nullptr, Wp(z, 16), Wp(z, 17), B[z][1], STATS(z, 8), 0, 64, 1.0f};
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, 0, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][1], STATS(z, 0), Wp(z, 18), Wp(z, 19), B[z][2], STATS(z, 1), cin_mode[z], 64, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][1], STATS(z, 8), Wp(z, 18), Wp(z, 19), B[z][2], STATS(z, 9), cin_mode[z], 64, 1.0f};
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][0], nullptr, 0, B[z][2], STATS(z, 1), nm[z] ? 3 : 1, B[z][1]};
+  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][0], nullptr, 0, B[z][2], STATS(z, 9), nm[z] ? 3 : 1, B[z][1]};
   hipLaunchKernelGGL(resout_kernel<64>, dim3(rgrid4, 2), dim3(256), 0, st, r, np4, t4, t4);
   // ---- conv2 (1x1, 64 -> 128 | 384), output / 4.0                                                     :259, net.py:116-117
   a.e[0] = {B[0][1], nullptr, Wp(0, 20), Wp(0, 21), (_Float16*)fmap_out, nullptr, 0, 128, 0.25f};
