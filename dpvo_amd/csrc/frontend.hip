@@ -193,28 +193,26 @@ __global__ void motion_model_kernel(float* __restrict__ poses, int n, float scal
 // ---- depth initialisation (dpvo.py:427-432): patches[n][:, 2] = median(patches[n-3:n, :, 2]) (torch.median = lower
 //      median of the flattened values).  One block, bitonic sort in LDS (count <= 4096). ------------------------------
 __global__ __launch_bounds__(1024) void median_depth_kernel(float* __restrict__ patches, int n, int M, int PP) {
+  // rank counting instead of a sort: element i is the lower median iff exactly (cnt-1)/2 elements precede it in the
+  // total order (value, index).  All lanes read the same v[j] (LDS broadcast), ~cnt^2/1024 compares per thread.
   __shared__ float v[4096];
+  __shared__ float med_s;
   const int per = M * PP, cnt = 3 * per;
   const float* src = patches + (int64_t)(n - 3) * M * 3 * PP;
-  for (int i = threadIdx.x; i < 4096; i += 1024) {
-    float x = INFINITY;
-    if (i < cnt) { const int f = i / per, r = i - f * per, m = r / PP, p = r - m * PP; x = src[((int64_t)(f * M + m) * 3 + 2) * PP + p]; }
-    v[i] = x;
+  for (int i = threadIdx.x; i < cnt; i += 1024) {
+    const int f = i / per, r = i - f * per, m = r / PP, p = r - m * PP;
+    v[i] = src[((int64_t)(f * M + m) * 3 + 2) * PP + p];
   }
   __syncthreads();
-  for (int k = 2; k <= 4096; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < 4096; i += 1024) {
-        const int l = i ^ j;
-        if (l > i) {
-          const bool up = ((i & k) == 0);
-          const float a = v[i], b = v[l];
-          if ((a > b) == up) { v[i] = b; v[l] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  const float med = v[(cnt - 1) / 2];
+  const int target = (cnt - 1) / 2;
+  for (int i = threadIdx.x; i < cnt; i += 1024) {
+    const float x = v[i];
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) { const float y = v[j]; rank += (y < x) || (y == x && j < i); }
+    if (rank == target) med_s = x;
+  }
+  __syncthreads();
+  const float med = med_s;
   float* dst = patches + (int64_t)n * M * 3 * PP;
   for (int i = threadIdx.x; i < per; i += 1024) { const int m = i / PP, p = i - m * PP; dst[((int64_t)m * 3 + 2) * PP + p] = med; }
 }

@@ -288,7 +288,7 @@ class DPVO:
         j = self.n - self.cfg.KEYFRAME_INDEX + 1
         # m = self.motionmag(i, j) + self.motionmag(j, i): one kernel + one read-back (was 2 x ~12 launches + 2 syncs)
         m_ij, m_ji = pops.motionmag_pair(self.poses, self.patches, self.intrinsics, self.pg.ii, self.pg.jj, self.pg.kk,
-                                         i, j, beta=0.5)
+                                         i, j, beta=0.5, plan=self._plan)
         m = m_ij + m_ji
 
         if m / 2 < self.cfg.KEYFRAME_THRESH:

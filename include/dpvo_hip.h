@@ -109,8 +109,8 @@ int dpvo_flow_mag(const float* poses, const float* patches, const float* intrins
 /* DPVO.motionmag(i,j) + DPVO.motionmag(j,i) (dpvo/dpvo.py:257-264,269): out4 = {sum_ij, n_ij, sum_ji, n_ji} of
  * the per-edge pixel-mean flow over the edges i->j and j->i (mean = sum/n; 0/0 = NaN like torch's empty mean). */
 int dpvo_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
-                   const int64_t* jj, const int64_t* kk, int64_t E, int P, int64_t i, int64_t j, float beta,
-                   float* out4, void* stream);
+                   const int64_t* jj, const int64_t* kk, const int32_t* plan /* of (ii,jj,kk), or NULL: full scan */,
+                   int64_t E, int P, int64_t i, int64_t j, float beta, float* out4, void* stream);
 
 /* pops.point_cloud centre pixel (projective_ops.py:115-117, dpvo.py:358-360): points[m,3]. */
 int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,

@@ -56,6 +56,11 @@ def test_reproject_flow_points(oracle, dev):
     # fused keyframe test (DPVO.motionmag(i,j) + motionmag(j,i))
     ii_f, jj_f, kk_f = S.replay_graph(40)
     a, b = pops.motionmag_pair(poses.to(dev), patches.to(dev), intr.to(dev), ii_f.to(dev), jj_f.to(dev), kk_f.to(dev), 35, 37, beta=0.5)
+    plan_f = GraphPlan(ii_f.to(dev), jj_f.to(dev), kk_f.to(dev))
+    a2, b2 = pops.motionmag_pair(poses.to(dev), patches.to(dev), intr.to(dev), ii_f.to(dev), jj_f.to(dev), kk_f.to(dev), 35, 37, beta=0.5, plan=plan_f)
+    assert abs(a - a2) < 1e-4 * max(1, abs(a)) and abs(b - b2) < 1e-4 * max(1, abs(b))
+    a3, b3 = pops.motionmag_pair(poses.to(dev), patches.to(dev), intr.to(dev), ii_f.to(dev), jj_f.to(dev), kk_f.to(dev), 3, 39, plan=plan_f)
+    assert a3 != a3 and b3 != b3
     for (qi, qj, got) in ((35, 37, a), (37, 35, b)):
         msk = (ii_f == qi) & (jj_f == qj)
         rf2, _ = oracle.flow_mag(poses.numpy(), patches.numpy(), intr.numpy(), ii_f[msk].numpy(), jj_f[msk].numpy(), kk_f[msk].numpy(), beta=0.5)
