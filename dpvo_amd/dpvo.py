@@ -23,6 +23,7 @@ from .patchgraph import PatchGraph
 from .utils import Timer, flatmeshgrid
 
 autocast = torch.autocast
+_PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 
 
 class DPVO:
@@ -349,7 +350,14 @@ class DPVO:
 
     def plan(self):
         if self._plan is None or self._plan.E != self.pg.ii.numel():
-            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk)
+            ub_p = ub_g = None
+            if not self.cfg.LOOP_CLOSURE and not _PLAN_SYNC:
+                # every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
+                # PATCH_LIFETIME frames of the source: bounds on #patches / #frame pairs, no device read-back needed
+                nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
+                ub_p = nf * self.M
+                ub_g = nf * (2 * self.cfg.PATCH_LIFETIME + 2)
+            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g)
         return self._plan
 
     def update(self):

@@ -14,7 +14,7 @@ class GraphPlan:
     """All views are int32 device tensors into one buffer; `counts` = [n_patches, n_pairs, 0, 0] stays on the
     device (no synchronisation); `n_patches()` / `n_pairs()` synchronise and are for tests / host logic only."""
 
-    def __init__(self, ii, jj, kk):
+    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None):
         L.require_cuda(ii, jj, kk)
         assert ii.dtype == jj.dtype == kk.dtype == torch.long
         E = ii.numel()
@@ -38,13 +38,20 @@ class GraphPlan:
         L.check(L.lib().dpvo_plan_build(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
                                         ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_plan_build")
 
-        # one host read-back per plan (= per frame): exact grid sizes for the group-level launches.  The
-        # reference synchronises ~10x per update for the same information.
-        c = self.counts[:2].tolist()
-        self.n_patches_host, self.n_pairs_host = int(c[0]), int(c[1])
+        # Launch sizes of the group-level kernels.  Callers that can bound the group counts from their own bookkeeping
+        # (DPVO: patches / frame pairs inside the removal window) pass upper bounds and NO host synchronisation happens:
+        # the kernels read the exact counts from `counts` on the device and surplus blocks exit.  Otherwise one
+        # read-back per plan (the reference synchronises ~10x per update for the same information).
+        if n_patches_ub is not None and n_pairs_ub is not None:
+            self.n_patches_host, self.n_pairs_host = int(min(max(n_patches_ub, 1), max(E, 1))), int(min(max(n_pairs_ub, 1), max(E, 1)))
+            self.exact = False
+        else:
+            c = self.counts[:2].tolist()
+            self.n_patches_host, self.n_pairs_host = int(c[0]), int(c[1])
+            self.exact = True
 
     def n_patches(self):
-        return self.n_patches_host
+        return self.n_patches_host if self.exact else int(self.counts[0].item())
 
     def n_pairs(self):
-        return self.n_pairs_host
+        return self.n_pairs_host if self.exact else int(self.counts[1].item())
