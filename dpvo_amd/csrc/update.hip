@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const void* __restrict__ A,
 // ---------------------------------------------------------------------------------------------------
 constexpr int NST = 3;
 constexpr int STAGE_HALVES = (BM + BN) * BK;          // 8192 halves = 16 KB
-__device__ unsigned g_zero_row[64];                    // 256 B of zeros: source of masked / gathered(-1) rows
+__device__ unsigned g_zero_row[256];                   // 1 KB of zeros: source of masked / gathered(-1) rows
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
@@ -306,6 +306,517 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const _Float16* __restr
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
   }
   linear_epilogue(acc, bias, out, ldo, gate, ldg, out16, ld16, epilogue, n_split, M, N, m0, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// linear_ws_kernel: weights-stationary persistent GEMM for the 384-wide layers (K = 384, N a multiple of 384; each
+// workgroup owns 384 output columns, N = 768 runs as two column groups).
+//   The update operator multiplies E ~ 47 712 rows by 384x384 weights: the weights are tiny, the rows are many, and at
+//   73 MB of activation traffic per 14 GFLOP the layer sits on the HBM side of the roofline.  So the kernel is built
+//   around keeping the memory queue full, and everything else out of its way:
+//     * each of the 4 waves of a workgroup (ONE wave per SIMD: the whole 512-entry VGPR+AGPR file is its own) keeps
+//       its 96 output columns of W (72 MFMA fragments = 288 registers) resident for the whole kernel -- no weight
+//       byte is re-fetched, and W itself arrives through LDS-DMA in full cache lines after one L2-warming touch
+//       (all 256 workgroups miss on the same lines at the same time otherwise);
+//     * activation rows stream through LDS exactly once: 32-row stages (rows padded to 1 KB = one LDS-DMA instruction
+//       per row, source-side XOR swizzle of the 16-byte chunks with the row index), FOUR stage buffers, the DMA of
+//       stage t+3 issued row by row between the MFMA k-steps of stage t, one barrier per stage;
+//     * vmcnt is in-order and counts stores too, so waiting for "stage t has landed" is a COUNTED wait: every
+//       vector-memory instruction of the stage body is unconditional (rows past M are clamped for loads and sent to a
+//       sink for stores) so that the number of younger instructions is a compile-time constant;
+//     * LDS reads are issued by hand (inline asm) two k-steps ahead of their MFMAs with counted lgkmcnt waits -- the
+//       compiler would order every LDS read it knows about behind all outstanding LDS-DMA;
+//     * the epilogue of a stage is split: E1 (activation, one rounding to f16, transpose through a wave-private LDS
+//       scratch so that global accesses are 16-byte and row-contiguous) at the end of the stage, E2 (residual / gate
+//       loads, stores) in the middle of the NEXT stage, under its MFMAs.  The bias rides in the accumulator init.
+// ---------------------------------------------------------------------------------------------------
+constexpr int WS_K = 384, WS_PITCH = 512;                    // halves per LDS row (1 KB)
+constexpr int WS_SROWS = 32;                                 // rows per stage: 2 m-tiles
+constexpr int WS_NBUF = 4;
+constexpr int WS_NT = 6;                                     // n-tiles (of 16 columns) per wave: 4 waves x 96 = 384
+constexpr int WS_ROW_BYTES = WS_PITCH * 2;
+constexpr int WS_STAGE_BYTES = WS_SROWS * WS_ROW_BYTES;      // 32 KB
+constexpr int WS_EP_PITCH = 208;                             // bytes per scratch row: 96 halves + 16 B pad
+constexpr int WS_EP_BYTES = 32 * WS_EP_PITCH;                // per wave
+constexpr int WS_LDS_BYTES = WS_NBUF * WS_STAGE_BYTES + 4 * WS_EP_BYTES;
+
+__device__ uint4 g_ws_sink[64 * 4];                          // 64 B per lane: where the stores of rows >= M go
+
+#ifdef WS_TRACE
+__device__ unsigned long long g_ws_trace[512][4][32];
+#define WS_T(i) do { if (lane == 0 && (i) < 32) g_ws_trace[blockIdx.y * gridDim.x + blockIdx.x][wave][i] = wall_clock64(); } while (0)
+#else
+#define WS_T(i) do {} while (0)
+#endif
+#define WS_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define WS_DSWRITE8(addr, val, off) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(val), "n"(off) : "memory")
+
+struct WsOut {                 // everything the epilogue needs (uniform)
+  void* out; int64_t ldo; const _Float16* gate; int64_t ldg; _Float16* out16; int64_t ld16;
+  int epilogue, n_split, N, n_base; int64_t M;
+};
+struct WsE2 {                  // registers of the deferred epilogue half
+  h8 ep[6]; f4 o0[6], o1[6]; h8 g[6];
+  uint32_t sabs[6], eoff[6];   // (plain-store kernel only) resident scratch addresses / output byte offsets of the 6 chunks
+};
+
+// Schedule constants.  Vector-memory instructions per stage body: 8 DMA rows + E2 (RMW: 12 + 6 loads, 12 + 6 stores).
+// E2 runs in G groups of NCH chunks: loads at k-step SL (before that step's DMA row), scratch read-back at SR, combine
+// and store at SC (after that step's DMA row).  The read-modify-write kernel splits it in two to halve its registers.
+template <bool RMW> struct WsCount {
+  static constexpr int E2_STORES = RMW ? 18 : 6;
+  static constexpr int BODY = 8 + (RMW ? 18 : 0) + E2_STORES;
+  static constexpr int G = RMW ? 2 : 1, NCH = 6 / G;
+  static constexpr int SL(int g) { return g == 0 ? 0 : 5; }
+  static constexpr int SR(int g) { return RMW ? (g == 0 ? 3 : 8) : 3; }
+  static constexpr int SC(int g) { return RMW ? (g == 0 ? 5 : 10) : 5; }
+  // DMA rows (k-steps 0..7, one each) issued between the loads of group g and its combine step
+  static constexpr int VM_YOUNGER(int g) { return g == 0 ? 6 : 2; }
+  // younger than the last DMA row (k-step 7) of stage t when body t starts: what body t-3 still issued after it, and
+  // bodies t-2, t-1 in full.  vmcnt is a 6-bit counter: a smaller number only waits longer.
+  static constexpr int YOUNGER = 2 * BODY + (RMW ? 9 : 0);
+  static constexpr int WAIT = YOUNGER < 63 ? YOUNGER : 63;
+  // LDS reads run RING - 1 k-steps ahead of their MFMAs.  The read-modify-write kernel has no registers left for more
+  // than one step (12 MFMAs = 192 cycles of cover for an LDS read).
+  static constexpr int RING = RMW ? 2 : 3;
+};
+
+// LDS reads of k-step T (both m-tiles) into register slot T % RING
+template <int T, int RING>
+__device__ __forceinline__ void ws_read(h8 (&fa)[RING][2], const uint32_t (&aq)[4], uint32_t poff) {
+  const uint32_t a = aq[T & 3] + poff;
+  WS_DSREAD(fa[T % RING][0], a, (T >> 2) * 256);
+  WS_DSREAD(fa[T % RING][1], a, (T >> 2) * 256 + 16 * WS_ROW_BYTES);
+}
+
+// chunk i (of 6) of a 32 x 96 stage tile handled by this lane: 16 B = 8 columns, row-contiguous across lanes
+__device__ __forceinline__ void ws_chunk(int lane, int i, int& row, int& col8) {
+  const int c = lane + 64 * i;
+  row = (c * 171) >> 11;        // c / 12 for c < 1024
+  col8 = c - 12 * row;
+}
+
+// E2 / L: residual and gate rows of the pending stage (3 loads per chunk, always).  Issued by hand: the compiler's own
+// vmcnt bookkeeping gives up on the mix of LDS-DMA, loads and stores and waits for vmcnt(0), i.e. for the whole DMA pipeline.
+#define WS_GLOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+template <int C0, int NCH>
+__device__ __forceinline__ void ws_e2_load(WsE2& e, const WsOut& o, int64_t m0, int lane, const _Float16* zero) {
+  asm volatile("" : "+v"(lane));      // (address arithmetic is recomputed where it is used, not hoisted and spilled)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int row, col8;
+    ws_chunk(lane, C0 + i, row, col8);
+    int64_t m = m0 + row;
+    m = m < o.M ? m : o.M - 1;
+    const int n = o.n_base + col8 * 8;
+    const float* src = reinterpret_cast<const float*>(o.out) + m * o.ldo + n;
+    WS_GLOAD16(e.o0[i], src);
+    WS_GLOAD16(e.o1[i], src + 4);
+    const _Float16* gsrc = o.epilogue == DPVO_EPI_GATED ? o.gate + m * o.ldg + n : zero;
+    WS_GLOAD16(e.g[i], gsrc);
+  }
+}
+// ... and waited for by hand: YOUNGER vector-memory instructions were issued after them
+template <int YOUNGER>
+__device__ __forceinline__ void ws_e2_wait3(WsE2& e) {
+  asm volatile("s_waitcnt vmcnt(%9)"
+               : "+v"(e.o0[0]), "+v"(e.o0[1]), "+v"(e.o0[2]), "+v"(e.o1[0]), "+v"(e.o1[1]), "+v"(e.o1[2]), "+v"(e.g[0]),
+                 "+v"(e.g[1]), "+v"(e.g[2])
+               : "n"(YOUNGER));
+}
+// E2 / R: the stage tile back from the wave's scratch (NCH ds_read_b128, always)
+template <bool RMW, int C0, int NCH>
+__device__ __forceinline__ void ws_e2_read(WsE2& e, uint32_t scratch, int lane) {
+  if constexpr (RMW) {
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int row, col8;
+      ws_chunk(lane, C0 + i, row, col8);
+      WS_DSREAD(e.ep[i], scratch + row * WS_EP_PITCH + col8 * 16, 0);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) WS_DSREAD(e.ep[i], e.sabs[C0 + i], 0);
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void ws_e2_tie(WsE2& e) {      // orders the uses of ep behind the lgkmcnt wait that retired the reads
+  if constexpr (NCH == 6)
+    asm volatile("" : "+v"(e.ep[0]), "+v"(e.ep[1]), "+v"(e.ep[2]), "+v"(e.ep[3]), "+v"(e.ep[4]), "+v"(e.ep[5]));
+  else
+    asm volatile("" : "+v"(e.ep[0]), "+v"(e.ep[1]), "+v"(e.ep[2]));
+}
+// E2 / C of the plain-store kernel inside the stage loop: whole stages only (the ragged last stage of the matrix is always
+// the last stage of its workgroup and goes through the general path after the loop); "no stage pending" stores to the sink
+__device__ __forceinline__ void ws_e2_store_fast(WsE2& e, const WsOut& o, int64_t m0, int lane) {
+  const bool none = m0 >= o.M;
+  char* sb = none ? reinterpret_cast<char*>(g_ws_sink)
+                  : reinterpret_cast<char*>(reinterpret_cast<_Float16*>(o.out) + m0 * o.ldo + o.n_base);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const uint32_t off = none ? (uint32_t)lane * 64u : e.eoff[i];
+    *reinterpret_cast<h8*>(sb + off) = e.ep[i];
+  }
+}
+// E2 / C: combine and store (1 or 3 stores per chunk, always; rows >= M go to the sink)
+template <bool RMW, int C0, int NCH>
+__device__ __forceinline__ void ws_e2_store(WsE2& e, const WsOut& o, int64_t m0, int lane) {
+  asm volatile("" : "+v"(lane));
+  char* sink = reinterpret_cast<char*>(g_ws_sink) + lane * 64;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int row, col8;
+    ws_chunk(lane, C0 + i, row, col8);
+    const int64_t m = m0 + row;
+    const bool ok = m < o.M;
+    const int n = o.n_base + col8 * 8;
+    if constexpr (RMW) {
+      h8 hv = e.ep[i];
+      if (o.epilogue == DPVO_EPI_GATED) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[q] = e.g[i][q] * hv[q];
+      }
+      f4 a = e.o0[i], b = e.o1[i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q] += (float)hv[q]; b[q] += (float)hv[4 + q]; }
+      float* dst = ok ? reinterpret_cast<float*>(o.out) + m * o.ldo + n : reinterpret_cast<float*>(sink);
+      *reinterpret_cast<f4*>(dst) = a;
+      *reinterpret_cast<f4*>(dst + 4) = b;
+      h8 o16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o16[q] = (_Float16)a[q]; o16[4 + q] = (_Float16)b[q]; }
+      _Float16* d16 = (ok && o.out16) ? o.out16 + m * o.ld16 + n : reinterpret_cast<_Float16*>(sink + 32);
+      *reinterpret_cast<h8*>(d16) = o16;
+    } else {
+      _Float16* dst = ok ? reinterpret_cast<_Float16*>(o.out) + m * o.ldo + n : reinterpret_cast<_Float16*>(sink);
+      *reinterpret_cast<h8*>(dst) = e.ep[i];
+    }
+  }
+}
+// the whole E2 of a stage outside the pipeline (after the stage loop)
+template <bool RMW>
+__device__ __forceinline__ void ws_e2_flush(WsE2& e, const WsOut& o, int64_t m0, uint32_t scratch, int lane,
+                                            const _Float16* zero) {
+  using C = WsCount<RMW>;
+#pragma unroll
+  for (int g = 0; g < C::G; ++g) {
+    if (g == 0) {
+      if constexpr (RMW) ws_e2_load<0, C::NCH>(e, o, m0, lane, zero);
+      ws_e2_read<RMW, 0, C::NCH>(e, scratch, lane);
+    } else {
+      if constexpr (RMW) ws_e2_load<C::NCH, C::NCH>(e, o, m0, lane, zero);
+      ws_e2_read<RMW, C::NCH, C::NCH>(e, scratch, lane);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    ws_e2_tie<C::NCH>(e);
+    if constexpr (RMW) ws_e2_wait3<0>(e);
+    if (g == 0) ws_e2_store<RMW, 0, C::NCH>(e, o, m0, lane);
+    else ws_e2_store<RMW, C::NCH, C::NCH>(e, o, m0, lane);
+  }
+}
+
+// One LDS-DMA row: lanes 0..47 fetch the 48 16-byte chunks of a 768-byte row, chunk c of a row with swizzle key r lands
+// in slot (c & ~15) | ((c ^ r) & 15) = c ^ (r & 15) -- the DMA destination is lane-linear, so lane l fetches chunk
+// l ^ (r & 15): one xor on the resident byte offset lane16 = 16 min(lane, 47) (lanes 48..63 land in the row's padding),
+// added to a wave-uniform row base.  grow < 0 reads the (1 KB) zero row.  With a single wave per SIMD every dependent
+// address instruction is exposed issue latency, hence the care.
+__device__ __forceinline__ void ws_dma_row(const _Float16* base, int64_t ld, int32_t grow, int r, uint32_t lds_row,
+                                           uint32_t lane16, const _Float16* zero) {
+  const char* sb = reinterpret_cast<const char*>(grow >= 0 ? base + (int64_t)grow * ld : zero);
+  const uint32_t voff = lane16 ^ (uint32_t)((r & 15) << 4);
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)(sb + voff), (lds_void_t*)(uintptr_t)lds_row, 16, 0, 0);
+}
+
+// E1: row mt*16 + m16 of the stage, columns j*16 + kg*4 .. +3 -> scratch.  ACT: 0 none, 1 relu, 2 sigmoid
+template <int ACT>
+__device__ __forceinline__ void ws_e1(const f4 (&acc)[2][WS_NT], uint32_t scratch, int m16, int kg) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < WS_NT; ++j) {
+      h4 hv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hv[q] = (_Float16)acc[mt][j][q];
+      if constexpr (ACT == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = hv[q] > (_Float16)0 ? hv[q] : (_Float16)0;
+      } else if constexpr (ACT == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[q] = (_Float16)sigmoidf_((float)hv[q]);
+      }
+      const uint32_t wa = scratch + (mt * 16 + m16) * WS_EP_PITCH + kg * 8;
+      switch (j) {
+        case 0: WS_DSWRITE8(wa, hv, 0); break;
+        case 1: WS_DSWRITE8(wa, hv, 32); break;
+        case 2: WS_DSWRITE8(wa, hv, 64); break;
+        case 3: WS_DSWRITE8(wa, hv, 96); break;
+        case 4: WS_DSWRITE8(wa, hv, 128); break;
+        default: WS_DSWRITE8(wa, hv, 160); break;
+      }
+    }
+}
+
+struct WsDma {                 // next-stage DMA parameters (all wave-uniform)
+  const _Float16* A; int64_t lda; int32_t row[8]; int wave; uint32_t lds; const _Float16* zero; uint32_t lane16;
+};
+
+// k-steps S .. 11 of one stage
+template <int S, bool RMW>
+__device__ __forceinline__ void ws_steps(f4 (&acc)[2][WS_NT], const h8 (&wreg)[WS_NT][12],
+                                         h8 (&fa)[WsCount<RMW>::RING][2],
+                                         const uint32_t (&aq)[4], uint32_t poff, WsE2& e2, const WsOut& o, int64_t pend_m0,
+                                         uint32_t scratch, int lane, const WsDma& d) {
+  if constexpr (S < 12) {
+    using C = WsCount<RMW>;
+    constexpr int RING = C::RING, D = RING - 1, NCH = C::NCH;
+    constexpr int GL = (S == C::SL(0)) ? 0 : (C::G > 1 && S == C::SL(1)) ? 1 : -1;     // group whose loads go here
+    constexpr int GR = (S == C::SR(0)) ? 0 : (C::G > 1 && S == C::SR(1)) ? 1 : -1;     // ... read-back
+    constexpr int GC = (S == C::SC(0)) ? 0 : (C::G > 1 && S == C::SC(1)) ? 1 : -1;     // ... combine + store
+    if constexpr (RMW && GL == 0) ws_e2_load<0, NCH>(e2, o, pend_m0, lane, d.zero);
+    if constexpr (GR >= 0) ws_e2_read<RMW, (GR > 0 ? NCH : 0), NCH>(e2, scratch, lane);
+    if constexpr (S + D < 12) ws_read<S + D, RING>(fa, aq, poff);
+    // LDS reads younger than those of step S: steps S+1 .. S+D (2 each) and the NCH scratch reads of a read-back issued
+    // at one of the steps S-D+1 .. S (they sit in front of that step's own reads)
+    constexpr int ahead = (11 - S) < D ? (11 - S) : D;
+    constexpr bool r0 = S >= C::SR(0) && S < C::SR(0) + D;
+    constexpr bool r1 = C::G > 1 && S >= C::SR(1) && S < C::SR(1) + D;
+    constexpr int younger = 2 * ahead + ((r0 || r1) ? NCH : 0);
+    static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+    static_assert(C::SC(0) >= C::SR(0) + D && C::SC(1) >= C::SR(1) + D, "read-back must be retired before the combine step");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[S % RING][0]), "+v"(fa[S % RING][1]) : "n"(younger));
+    if constexpr (GC >= 0) ws_e2_tie<NCH>(e2);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int j = 0; j < WS_NT; ++j)
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[j][S], fa[S % RING][mt], acc[mt][j], 0, 0, 0);
+#ifndef WS_NO_DMA
+    if constexpr (S < 8)       // stage t+3, row S of this wave's 8
+      ws_dma_row(d.A, d.lda, d.row[S], d.wave * 8 + S, d.lds + S * WS_ROW_BYTES, d.lane16, d.zero);
+#endif
+#ifndef WS_NO_STORE
+    if constexpr (GC >= 0) {
+      // recompute the addresses instead of keeping pointers alive since the loads
+      int m0lo = __builtin_amdgcn_readfirstlane((int)(pend_m0 & 0xffffffff));
+      int m0hi = __builtin_amdgcn_readfirstlane((int)(pend_m0 >> 32));
+      asm volatile("" : "+s"(m0lo), "+s"(m0hi));
+      const int64_t m0s = ((int64_t)m0hi << 32) | (uint32_t)m0lo;
+      if constexpr (RMW) {
+        ws_e2_wait3<C::VM_YOUNGER(GC)>(e2);
+        ws_e2_store<true, (GC > 0 ? NCH : 0), NCH>(e2, o, m0s, lane);
+      } else {
+        ws_e2_store_fast(e2, o, m0s, lane);
+      }
+    }
+    if constexpr (RMW && GL == 1) ws_e2_load<NCH, NCH>(e2, o, pend_m0, lane, d.zero);
+#endif
+    ws_steps<S + 1, RMW>(acc, wreg, fa, aq, poff, e2, o, pend_m0, scratch, lane, d);
+  }
+}
+
+template <bool RMW>
+__global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restrict__ A, int64_t lda,
+                                                        const int32_t* __restrict__ rows,
+                                                        const _Float16* __restrict__ W, int64_t ldw,
+                                                        const _Float16* __restrict__ bias, WsOut o) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ws_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15, kg = lane >> 4;
+  o.n_base = blockIdx.y * 384 + wave * (16 * WS_NT);
+  const int n_base = o.n_base;
+  const int64_t M = o.M;
+  const int64_t nstages = (M + WS_SROWS - 1) / WS_SROWS;
+  const int64_t gstep = gridDim.x;
+  const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_row);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)ws_smem;
+  const uint32_t scratch = lds0 + WS_NBUF * WS_STAGE_BYTES + wave * WS_EP_BYTES;
+  const uint32_t lane16 = (uint32_t)(lane < 48 ? lane : 47) << 4;
+  WS_T(0);
+
+  // ---- L2 warm-up: the workgroup's 384 rows of W are 2304 cache lines, 9 per thread, fire and forget
+  unsigned sinkreg[9];                  // (allocated until the vmcnt(0) below: the loads land asynchronously)
+  {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int line = tid + 256 * i;
+      const int row = line / 6;
+      const int part = line - 6 * row;
+      const _Float16* p = W + (int64_t)(blockIdx.y * 384 + row) * ldw + part * 64;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(sinkreg[i]) : "v"(p));
+      if (i == 0) WS_T(27);
+    }
+  }
+  WS_T(28);
+  // source rows of the 8 stage rows this wave stages (stage rows 8w .. 8w+7); -1 = zero row.  The gather indices come
+  // through SCALAR loads: a vector load consumed d stages later would cap the DMA pipeline at depth d (vmcnt is in-order).
+  // (32-bit scalar arithmetic throughout: M < 2^30 is checked by the launcher; a stage past the end starts at >= M)
+  const int M32 = (int)M;
+  auto stage_rows_raw = [&](int64_t st, int32_t (&raw)[8]) {      // 8 s_load_dword, NOT waited for
+    const int g0 = (int)st * WS_SROWS + wave * 8;
+    if (rows) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t off = (g0 + i < M32) ? (uint32_t)(g0 + i) * 4u : 0u;
+        asm volatile("s_load_dword %0, %1, %2" : "=s"(raw[i]) : "s"(rows), "s"(off));
+      }
+    }
+  };
+  auto stage_rows_wait = [&](int32_t (&raw)[8]) {
+    if (rows)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw[0]), "+s"(raw[1]), "+s"(raw[2]), "+s"(raw[3]), "+s"(raw[4]), "+s"(raw[5]),
+                   "+s"(raw[6]), "+s"(raw[7]));
+  };
+  auto stage_rows_fix = [&](int64_t st, const int32_t (&raw)[8], int32_t (&r)[8]) {
+    const int g0 = (int)st * WS_SROWS + wave * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (g0 + i < M32) ? (rows ? raw[i] : g0 + i) : -1;
+  };
+  int64_t st = blockIdx.x;
+  // bias of this lane's accumulator columns n_base + 16 j + 4 kg .. +3 (by hand as well: these loads and the warm-up
+  // are simply older than the first W tile in the in-order queue, the tile-0 wait below retires them)
+  h4 breg[WS_NT];
+#pragma unroll
+  for (int j = 0; j < WS_NT; ++j) {
+    const _Float16* bp = bias ? bias + n_base + j * 16 + kg * 4 : zero;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(breg[j]) : "v"(bp));
+  }
+  WS_T(1);
+
+  // LDS byte address of this lane's MFMA fragment for k-step s of row (lane & 15): chunk 4s + kg lives in slot
+  // (c & ~15) | ((c ^ row) & 15) = 16 (s >> 2) + ((kg ^ m16) ^ 4 (s & 3)); m-tile and k-quarter are immediates.
+  uint32_t aq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aq[q] = lds0 + m16 * WS_ROW_BYTES + (((kg ^ m16) ^ (4 * q)) << 4);
+
+  // ---- prologue: the wave's 96 columns x 384 k of W, tile by tile (16 rows) through its own 8-row slices of the stage
+  // buffers: tile j -> rows 0..7 in buffer 2 (j & 1), rows 8..15 in buffer 2 (j & 1) + 1; two tiles in flight.  The slices
+  // are private to the wave (it later fills the same ones with activation rows), so no barrier is needed.
+  h8 wreg[WS_NT][12];
+  const uint32_t slice = lds0 + wave * 8 * WS_ROW_BYTES;
+  auto w_tile = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      ws_dma_row(W, ldw, n_base + j * 16 + i, i, slice + (2 * (j & 1) + (i >> 3)) * WS_STAGE_BYTES + (i & 7) * WS_ROW_BYTES, lane16,
+                 zero);
+  };
+  auto a_stage = [&](int b, int64_t stg) {
+    int32_t raw[8], r[8];
+    stage_rows_raw(stg, raw);
+    stage_rows_wait(raw);
+    stage_rows_fix(stg, raw, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      ws_dma_row(A, lda, r[i], wave * 8 + i, slice + b * WS_STAGE_BYTES + i * WS_ROW_BYTES, lane16, zero);
+  };
+  const uint32_t wq0 = slice + (m16 >> 3) * WS_STAGE_BYTES + (m16 & 7) * WS_ROW_BYTES;
+  WS_T(29);
+  w_tile(0);
+  WS_T(30);
+  w_tile(1);
+  WS_T(31);
+#pragma unroll
+  for (int j = 0; j < WS_NT; ++j) {
+    if (j == 0)       // younger than tile j: exactly the 16 rows issued after it
+      asm volatile("s_waitcnt vmcnt(16)" : "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]), "+v"(breg[4]), "+v"(breg[5]),
+               "+v"(sinkreg[0]), "+v"(sinkreg[1]), "+v"(sinkreg[2]), "+v"(sinkreg[3]), "+v"(sinkreg[4]), "+v"(sinkreg[5]),
+               "+v"(sinkreg[6]), "+v"(sinkreg[7]), "+v"(sinkreg[8]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    WS_T(2 + j);
+    const uint32_t wo = wq0 + (j & 1) * 2 * WS_STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      h8 v;
+      const uint32_t a = wo + (((kg ^ m16) ^ (4 * (s & 3))) << 4);
+      switch (s >> 2) {
+        case 0: WS_DSREAD(v, a, 0); break;
+        case 1: WS_DSREAD(v, a, 256); break;
+        default: WS_DSREAD(v, a, 512); break;
+      }
+      wreg[j][s] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(wreg[j][0]), "+v"(wreg[j][1]), "+v"(wreg[j][2]), "+v"(wreg[j][3]), "+v"(wreg[j][4]), "+v"(wreg[j][5]),
+                   "+v"(wreg[j][6]), "+v"(wreg[j][7]), "+v"(wreg[j][8]), "+v"(wreg[j][9]), "+v"(wreg[j][10]), "+v"(wreg[j][11])
+                 :
+                 : "memory");
+    if (j + 2 < WS_NT) {
+      w_tile(j + 2);
+    } else if (j + 2 == WS_NT) {       // buffers 0, 1 are free: activation stages 0 and 1 (16 rows) follow tile 5
+      a_stage(0, st);
+      a_stage(1, st + gstep);
+    } else {                           // buffers 2, 3: stage 2
+      a_stage(2, st + 2 * gstep);
+    }
+  }
+  WS_T(8);
+
+  // activation of this wave's 96 columns (RELU_SIG: n_split is a multiple of 96)
+  const int act = (o.epilogue == DPVO_EPI_RELU || (o.epilogue == DPVO_EPI_RELU_SIG && n_base < o.n_split)) ? 1
+                  : (o.epilogue == DPVO_EPI_SIGMOID || o.epilogue == DPVO_EPI_RELU_SIG) ? 2 : 0;
+  WsE2 e2;
+  if constexpr (!RMW) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      int row, col8;
+      ws_chunk(lane, i, row, col8);
+      e2.sabs[i] = scratch + row * WS_EP_PITCH + col8 * 16;
+      e2.eoff[i] = (uint32_t)((row * o.ldo + col8 * 8) * 2);
+    }
+  }
+  WsDma d{A, lda, {0, 0, 0, 0, 0, 0, 0, 0}, wave, 0, zero, lane16};
+  {
+    int32_t raw[8];
+    stage_rows_raw(st + 3 * gstep, raw);
+    stage_rows_wait(raw);
+    stage_rows_fix(st + 3 * gstep, raw, d.row);
+  }
+  int64_t pend_m0 = M;                 // "no rows": loads clamp to row M-1, stores go to the sink
+  int it = 0;
+  for (; st < nstages; st += gstep, ++it) {
+    // stage `it` has landed when at most WAIT younger instructions are outstanding.  The first two stages were issued by
+    // the prologue with only 16 rows behind stage 0.
+    if (it < 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (WsCount<RMW>::WAIT == 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WsCount<RMW>::WAIT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    WS_T(9 + 3 * it);
+    const int buf = it & 3;
+    d.lds = slice + (uint32_t)((it + 3) & 3) * WS_STAGE_BYTES;
+    f4 acc[2][WS_NT];
+#pragma unroll
+    for (int j = 0; j < WS_NT; ++j) {
+      f4 b4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = (float)breg[j][q];
+      acc[0][j] = b4;
+      acc[1][j] = b4;
+    }
+    const uint32_t poff = (uint32_t)buf * WS_STAGE_BYTES;
+    constexpr int RING = WsCount<RMW>::RING;
+    h8 fa[RING][2];
+    ws_read<0, RING>(fa, aq, poff);
+    if constexpr (RING > 2) ws_read<1, RING>(fa, aq, poff);
+    ws_steps<0, RMW>(acc, wreg, fa, aq, poff, e2, o, pend_m0, scratch, lane, d);
+    WS_T(10 + 3 * it);
+    int32_t raw_next[8];
+    stage_rows_raw(st + 4 * gstep, raw_next);      // scalar loads fly under E1
+    // E1: activation (uniform per wave), one rounding to f16, transpose through the scratch
+    if (act == 1) ws_e1<1>(acc, scratch, m16, kg);
+    else if (act == 2) ws_e1<2>(acc, scratch, m16, kg);
+    else ws_e1<0>(acc, scratch, m16, kg);
+    pend_m0 = st * WS_SROWS;
+    stage_rows_wait(raw_next);
+    stage_rows_fix(st + 4 * gstep, raw_next, d.row);
+    WS_T(11 + 3 * it);
+  }
+  // the last stage still owes its E2
+  if (pend_m0 < M) {
+    ws_e2_flush<RMW>(e2, o, pend_m0, scratch, lane, zero);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the speculative DMA of stages past the end targets our LDS
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -456,6 +967,26 @@ extern "C" int dpvo_linear(const void* A, int a_dtype, int64_t lda, const int32_
     if (out16) return DPVO_E_UNSUPPORTED;                 // the f16 image output belongs to the f16 (DMA) variant
     hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, lda, rows, (const _Float16*)W,
                        ldw, (const _Float16*)bias, out, ldo, (const _Float16*)gate, ldg, epilogue, n_split, M, N, K);
+  } else if (a_dtype == DPVO_F16 && K == WS_K && (N % 384) == 0 && M >= 4096 && M < (1 << 30) &&
+             (epilogue != DPVO_EPI_RELU_SIG || (n_split % 96) == 0)) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const size_t sh = (size_t)WS_LDS_BYTES;                                       // 154 KB: one workgroup per CU
+    const bool rmw = epilogue == DPVO_EPI_RESADD || epilogue == DPVO_EPI_GATED;
+    auto kern = rmw ? linear_ws_kernel<true> : linear_ws_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    const int ngrp = (N + 383) / 384;
+    const int64_t nst = cdiv64(M, WS_SROWS);
+    int gx = n_cu / ngrp;
+    if (gx > nst) gx = (int)nst;
+    if (gx < 1) gx = 1;
+    WsOut wo{out, ldo, (const _Float16*)gate, ldg, (_Float16*)out16, ld16, epilogue, n_split, N, 0, M};
+    hipLaunchKernelGGL(kern, dim3(gx, ngrp), dim3(256), sh, (hipStream_t)stream, (const _Float16*)A, lda, rows,
+                       (const _Float16*)W, ldw, (const _Float16*)bias, wo);
   } else if (a_dtype == DPVO_F16) {
     hipLaunchKernelGGL(linear_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)A, lda, rows,
                        (const _Float16*)W, ldw, (const _Float16*)bias, out, ldo, (const _Float16*)gate, ldg,

@@ -25,7 +25,12 @@ def t(fn, flops):
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
     return ms, flops / ms / 1e9
+out32 = torch.zeros(E, 384, dtype=torch.float32, device=dev); gate = torch.rand(E, 384, generator=g).half().to(dev)
+o16 = torch.empty(E, 384, dtype=torch.float16, device=dev)
 for name, fn, fl in (("384x384 f16", lambda: N.linear(A, W, b, out=out), 2 * E * 384 * 384),
+                     ("384x384 relu", lambda: N.linear(A, W, b, out=out, epilogue=N.EPI_RELU), 2 * E * 384 * 384),
+                     ("384x384 resadd", lambda: N.linear(A, W, b, out=out32, epilogue=N.EPI_RESADD, out16=o16), 2 * E * 384 * 384),
+                     ("384x384 gated", lambda: N.linear(A, W, b, out=out32, epilogue=N.EPI_GATED, gate=gate, out16=o16), 2 * E * 384 * 384),
                      ("896x384 f16", lambda: N.linear(A9, W9, b, out=out, K=896), 2 * E * 896 * 384),
                      ("384x768 f16", lambda: N.linear(A, W7, b7, out=out7), 2 * E * 384 * 768)):
     ms, tf = t(fn, fl)
