@@ -191,30 +191,42 @@ __global__ void motion_model_kernel(float* __restrict__ poses, int n, float scal
 }
 
 // ---- depth initialisation (dpvo.py:427-432): patches[n][:, 2] = median(patches[n-3:n, :, 2]) (torch.median = lower
-//      median of the flattened values).  One block, bitonic sort in LDS (count <= 4096). ------------------------------
-__global__ __launch_bounds__(1024) void median_depth_kernel(float* __restrict__ patches, int n, int M, int PP) {
-  // rank counting instead of a sort: element i is the lower median iff exactly (cnt-1)/2 elements precede it in the
-  // total order (value, index).  All lanes read the same v[j] (LDS broadcast), ~cnt^2/1024 compares per thread.
-  __shared__ float v[4096];
+//      median of the flattened values).  Rank counting instead of a sort: element i is the lower median iff exactly
+//      (cnt-1)/2 elements precede it in the total order (value, index).  32 elements per block, 8 lanes per element each
+//      counting an eighth of the candidates (LDS, float4 reads); the one block that owns the median writes the new frame.
+__global__ __launch_bounds__(256) void median_depth_kernel(float* __restrict__ patches, int n, int M, int PP) {
+  __shared__ __attribute__((aligned(16))) float v[4096 + 32];
   __shared__ float med_s;
+  __shared__ int found_s;
   const int per = M * PP, cnt = 3 * per;
   const float* src = patches + (int64_t)(n - 3) * M * 3 * PP;
-  for (int i = threadIdx.x; i < cnt; i += 1024) {
+  if (threadIdx.x == 0) found_s = 0;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
     const int f = i / per, r = i - f * per, m = r / PP, p = r - m * PP;
     v[i] = src[((int64_t)(f * M + m) * 3 + 2) * PP + p];
   }
   __syncthreads();
-  const int target = (cnt - 1) / 2;
-  for (int i = threadIdx.x; i < cnt; i += 1024) {
-    const float x = v[i];
-    int rank = 0;
-    for (int j = 0; j < cnt; ++j) { const float y = v[j]; rank += (y < x) || (y == x && j < i); }
-    if (rank == target) med_s = x;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+  const int chunk = (((cnt + 7) >> 3) + 3) & ~3;          // candidates per lane, a multiple of 4
+  const int j0 = part * chunk, j1 = min(cnt, j0 + chunk);
+  const float x = i < cnt ? v[i] : 0.f;
+  int rank = 0;
+  for (int j = j0; j < j1; j += 4) {
+    const float4 y = *reinterpret_cast<const float4*>(v + j);
+    rank += (y.x < x) || (y.x == x && j < i);
+    if (j + 1 < j1) rank += (y.y < x) || (y.y == x && j + 1 < i);
+    if (j + 2 < j1) rank += (y.z < x) || (y.z == x && j + 2 < i);
+    if (j + 3 < j1) rank += (y.w < x) || (y.w == x && j + 3 < i);
   }
+  rank += __shfl_xor(rank, 1);
+  rank += __shfl_xor(rank, 2);
+  rank += __shfl_xor(rank, 4);
+  if (part == 0 && i < cnt && rank == (cnt - 1) / 2) { med_s = x; found_s = 1; }
   __syncthreads();
+  if (!found_s) return;
   const float med = med_s;
   float* dst = patches + (int64_t)n * M * 3 * PP;
-  for (int i = threadIdx.x; i < per; i += 1024) { const int m = i / PP, p = i - m * PP; dst[((int64_t)m * 3 + 2) * PP + p] = med; }
+  for (int k = threadIdx.x; k < per; k += 256) { const int m = k / PP, p = k - m * PP; dst[((int64_t)m * 3 + 2) * PP + p] = med; }
 }
 
 inline unsigned grid_for(int64_t n, int cap = 4096) {
@@ -305,7 +317,8 @@ extern "C" int dpvo_motion_model(float* poses, int n, float scale, void* stream)
 extern "C" int dpvo_median_depth(float* patches, int n, int M, int P, void* stream) {
   if (!patches || n < 3 || M <= 0 || P <= 0) return DPVO_E_INVALID;
   if (3 * M * P * P > 4096) return DPVO_E_UNSUPPORTED;
-  hipLaunchKernelGGL(median_depth_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, patches, n, M, P * P);
+  hipLaunchKernelGGL(median_depth_kernel, dim3((3 * M * P * P + 31) / 32), dim3(256), 0, (hipStream_t)stream, patches, n, M,
+                     P * P);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
