@@ -18,7 +18,8 @@ whole-job frames/sec = N*K / max-over-ranks seconds; scaling is "weak".
 The JSON line also carries
   roofline     -- the dominant kernel of the north-star path, corr_pyramid_kernel: ALGORITHMIC bytes per launch
                   (E x 52 884 B) / its mean duration measured with HIP events on the launch stream
-                  inside the timed region, against the 8 TB/s HBM3E peak;
+                  inside the timed region, against the 8 TB/s HBM3E peak; `traffic` = bytes per launch seen by the
+                  memory-side counters in the committed PMC pass (profiles/rNN_corr_pmc.json);
   cpu_baseline -- the CPU oracle ("port": oracle/liboracle.so + oracle/update_ref.py) timed on rank 0 at N = 1 on
                   ONE full hot-path step (reproject, corr, update, 2 BA iterations at E = 45 312).
 """
@@ -36,6 +37,19 @@ if ROOT not in sys.path:
 
 B_EDGE = 52884          # algorithmic bytes per edge, both pyramid levels, f16 features
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def pmc_traffic():
+    """HBM-side bytes per corr_pyramid_kernel launch from the newest committed PMC pass (tools/pmc_corr.sh, two separate
+    rocprofv3 --pmc runs of this same command; corrected as MI355X_MICROARCH.md prescribes), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corr_pmc.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def make_stream(n_frames, ht, wd, device, seed=1234):
@@ -160,7 +174,7 @@ def main():
         avg_E = sum(corr_edges) / len(corr_edges)
         achieved = avg_E * B_EDGE / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "corr_pyramid_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                 "avg_launch_ms": round(avg_ms, 4), "edges_per_launch": round(avg_E, 1), "bytes_per_edge": B_EDGE,
                 "launches": len(corr_ms)}
 
