@@ -27,7 +27,7 @@ SYMBOLS = [
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges",
-    "dpvo_motion_model", "dpvo_median_depth",
+    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_pool4_nhwc",
 ]
 

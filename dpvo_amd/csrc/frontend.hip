@@ -229,6 +229,83 @@ __global__ __launch_bounds__(256) void median_depth_kernel(float* __restrict__ p
   for (int k = threadIdx.x; k < per; k += 256) { const int m = k / PP, p = k - m * PP; dst[((int64_t)m * 3 + 2) * PP + p] = med; }
 }
 
+// ---- everything a new frame contributes besides its feature maps, in one launch (Patchifier.forward's gathers
+//      net.py:136-147 + the state stores of dpvo.py:401-438): per patch m
+//        gmap_slot[m][a][b][c]  = patchify(fmap, coords, 1)        (bilinear blend of the floor-gathered 4x4 window)
+//        imap_slot[m][c]        = patchify(imap, coords, 0)
+//        patches_slot[m]        = patchify((x, y, 1) grid, coords, 1), plane 2 overwritten with depth[m]
+//        colors_slot[m]         = patchify(image, 4 (coords + 0.5), 0) in RGB order, uint8
+//      plus intrinsics_slot = intrinsics / res, index_row[:] = frame + 1, index_map = m_next.
+//      coords come either as float [M,2] or as the two int64 randint draws (x, y) of net.py:132-133. -----------------
+__device__ __forceinline__ int fp_floor_int(float v) {
+  float f = floorf(v);
+  if (!(f > -1.0e6f)) f = -1.0e6f;   // also catches NaN
+  if (f > 1.0e6f) f = 1.0e6f;
+  return (int)f;
+}
+template <typename F>
+__device__ __forceinline__ float fp_blend(float x, float y, int i0, int j0, int H, int W, F at) {
+  const float dx = x - floorf(x), dy = y - floorf(y);
+  float v[2][2];
+#pragma unroll
+  for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int i = i0 + aa, j = j0 + bb;
+      v[aa][bb] = (i >= 0 && i < H && j >= 0 && j < W) ? at(i, j) : 0.f;
+    }
+  // same term order as the reference: x00 + x01 + x10 + x11 (correlation.py:62-66)
+  float o = (1.f - dy) * (1.f - dx) * v[0][0];
+  o += (1.f - dy) * dx * v[0][1];
+  o += dy * (1.f - dx) * v[1][0];
+  o += dy * dx * v[1][1];
+  return o;
+}
+__global__ __launch_bounds__(256) void frame_patches_kernel(
+    const _Float16* __restrict__ fmap, const _Float16* __restrict__ imap, const uint8_t* __restrict__ img,
+    const float* __restrict__ coords, const int64_t* __restrict__ xs, const int64_t* __restrict__ ys,
+    const float* __restrict__ depth, const float* __restrict__ intr, float res, _Float16* __restrict__ gmap_slot,
+    _Float16* __restrict__ imap_slot, float* __restrict__ patches_slot, uint8_t* __restrict__ colors_slot,
+    float* __restrict__ intr_slot, int64_t* __restrict__ index_row, int64_t* __restrict__ index_map, float* __restrict__ coords_out,
+    int M, int h, int w, int H, int W, int CF, int CI, int64_t frame_next, int64_t m_next) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  const float x = coords ? coords[2 * m] : (float)xs[m], y = coords ? coords[2 * m + 1] : (float)ys[m];
+  const int fi = fp_floor_int(y), fj = fp_floor_int(x);
+  // gmap: 9 window positions x CF channels (channels fastest in both the NHWC source and the channels-last slot)
+  for (int e = t; e < 9 * CF; e += 256) {
+    const int c = e % CF, ab = e / CF, a = ab / 3, b = ab - 3 * a;
+    const float o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w,
+                             [&](int i, int j) { return (float)fmap[((int64_t)i * w + j) * CF + c]; });
+    gmap_slot[((int64_t)m * 9 + ab) * CF + c] = (_Float16)o;
+  }
+  for (int c = t; c < CI; c += 256) {
+    const float o = fp_blend(x, y, fi, fj, h, w, [&](int i, int j) { return (float)imap[((int64_t)i * w + j) * CI + c]; });
+    imap_slot[(int64_t)m * CI + c] = (_Float16)o;
+  }
+  if (t < 27) {
+    const int pl = t / 9, ab = t - 9 * pl, a = ab / 3, b = ab - 3 * a;
+    float o;
+    if (pl == 2) o = depth[m];
+    else o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w, [&](int i, int j) { return pl == 0 ? (float)j : (float)i; });
+    patches_slot[(int64_t)m * 27 + t] = o;
+  } else if (t >= 32 && t < 35) {
+    const int c = t - 32, cs = 2 - c;                                            // clr[0,:,[2,1,0]]
+    const float cx = 4.0f * (x + 0.5f), cy = 4.0f * (y + 0.5f);
+    const float o = fp_blend(cx, cy, (int)floorf(cy), (int)floorf(cx), H, W, [&](int i, int j) {
+      return 2.0f * ((float)img[((int64_t)cs * H + i) * W + j] * (1.0f / 255.0f)) - 0.5f;
+    });
+    const float f = (o + 0.5f) * (255.0f / 2.0f);
+    colors_slot[m * 3 + c] = (uint8_t)(int)f;
+  } else if (t >= 64 && t < 66 && coords_out) {
+    coords_out[2 * m + (t - 64)] = t == 64 ? x : y;
+  }
+  if (m == 0) {
+    if (t >= 96 && t < 100 && intr_slot) intr_slot[t - 96] = intr[t - 96] / res;
+    if (t == 100 && index_map) *index_map = m_next;
+  }
+  if (index_row && t == 128) index_row[m] = frame_next;
+}
+
 inline unsigned grid_for(int64_t n, int cap = 4096) {
   int64_t g = cdiv64(n, 256);
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -303,6 +380,26 @@ extern "C" int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* i
   if (!idx || !ii || !jj || !kk || !oii || !ojj || !okk) return DPVO_E_INVALID;
   hipLaunchKernelGGL(gather_edges_kernel, dim3(grid_for(onet ? n * (D / 4) : n, 2048)), dim3(256), 0, (hipStream_t)stream,
                      idx, n, ii, jj, kk, net, target, weight, oii, ojj, okk, onet, otarget, oweight, D);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void* img_u8, const float* coords,
+                                  const int64_t* xs, const int64_t* ys, const float* depth, const float* intrinsics,
+                                  float res, void* gmap_slot, void* imap_slot, float* patches_slot, void* colors_slot,
+                                  float* intrinsics_slot, int64_t* index_row, int64_t* index_map, float* coords_out, int M,
+                                  int h, int w, int H, int W, int CF, int CI, int P, int64_t frame_next, int64_t m_next,
+                                  void* stream) {
+  if (M < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || CF <= 0 || CI <= 0) return DPVO_E_INVALID;
+  if (P != 3) return DPVO_E_UNSUPPORTED;
+  if (M == 0) return DPVO_OK;
+  if (!fmap || !imap || !img_u8 || !depth || !gmap_slot || !imap_slot || !patches_slot || !colors_slot) return DPVO_E_INVALID;
+  if (!coords && !(xs && ys)) return DPVO_E_INVALID;
+  if (intrinsics_slot && !intrinsics) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(frame_patches_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const _Float16*)fmap,
+                     (const _Float16*)imap, (const uint8_t*)img_u8, coords, xs, ys, depth, intrinsics, res,
+                     (_Float16*)gmap_slot, (_Float16*)imap_slot, patches_slot, (uint8_t*)colors_slot, intrinsics_slot,
+                     index_row, index_map, coords_out, M, h, w, H, W, CF, CI, frame_next, m_next);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

@@ -23,6 +23,7 @@ from .patchgraph import PatchGraph
 from .utils import Timer, flatmeshgrid
 
 autocast = torch.autocast
+_CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0")))
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 
 
@@ -250,17 +251,32 @@ class DPVO:
         self._plan = None
 
     def remove_factors(self, m, store: bool):
-        """dpvo.py:223-238.  m: bool mask over the active edges."""
-        if store:
-            rem = m.nonzero().squeeze(1)
-            if rem.numel():
-                dst = self.pg.edges_inac
-                dst.reserve(rem.numel())
-                self.pg.edges.gather_into(rem, dst.a, dst.E)
-                dst.E += rem.numel()
-        keep = (~m).nonzero().squeeze(1)
-        self.pg.edges.keep(keep)
+        """dpvo.py:223-238.  m: bool mask over the active edges (a device tensor as in the reference, or a host numpy
+        mask computed from the edge store's mirror: then no read-back is needed)."""
+        es = self.pg.edges
+        if isinstance(m, np.ndarray):
+            rem_h, keep_h = np.flatnonzero(m), np.flatnonzero(~m)
+            rem = es.stage_indices(rem_h) if store and rem_h.size else None
+            keep = es.stage_indices(keep_h)
+        else:
+            rem = m.nonzero().squeeze(1) if store else None
+            keep, keep_h = (~m).nonzero().squeeze(1), None
+        if store and rem is not None and rem.numel():
+            dst = self.pg.edges_inac
+            dst.reserve(rem.numel())
+            es.gather_into(rem, dst.a, dst.E)
+            dst.E += rem.numel()
+        es.keep(keep, keep_h)
         self._plan = None
+
+    def _removal_mask(self, h):
+        """edges falling outside the optimization window (dpvo.py:305-310), from the host mirror (ix[kk] == kk // M)"""
+        to_remove = (h["kk"] // self.M) < self.n - self.cfg.REMOVAL_WINDOW
+        if self.cfg.LOOP_CLOSURE:
+            # ...unless they are being used for loop closure
+            lc_edges = ((h["jj"] - h["ii"]) > 30) & (h["jj"] > (self.n - self.cfg.OPTIMIZATION_WINDOW))
+            to_remove = to_remove & ~lc_edges
+        return to_remove
 
     def motion_probe(self):
         """ kinda hacky way to ensure enough motion for initialization (dpvo.py:240-255) """
@@ -288,8 +304,12 @@ class DPVO:
         i = self.n - self.cfg.KEYFRAME_INDEX - 1
         j = self.n - self.cfg.KEYFRAME_INDEX + 1
         # m = self.motionmag(i, j) + self.motionmag(j, i): one kernel + one read-back (was 2 x ~12 launches + 2 syncs)
-        m_ij, m_ji = pops.motionmag_pair(self.poses, self.patches, self.intrinsics, self.pg.ii, self.pg.jj, self.pg.kk,
-                                         i, j, beta=0.5, plan=self._plan)
+        m_pending = pops.motionmag_pair(self.poses, self.patches, self.intrinsics, self.pg.ii, self.pg.jj, self.pg.kk,
+                                        i, j, beta=0.5, plan=self._plan, defer=True)
+        # while the GPU is still busy with this frame: the removal mask of the common case (keyframe kept), on the host
+        es = self.pg.edges
+        to_remove = self._removal_mask(es.host())
+        m_ij, m_ji = m_pending()            # the one host read-back of the frame
         m = m_ij + m_ji
 
         if m / 2 < self.cfg.KEYFRAME_THRESH:
@@ -300,12 +320,16 @@ class DPVO:
             dP = SE3(self.pg.poses_[k]) * SE3(self.pg.poses_[k - 1]).inv()
             self.pg.delta[t1] = (t0, dP)
 
-            to_remove = (self.pg.ii == k) | (self.pg.jj == k)
-            self.remove_factors(to_remove, store=False)
+            h = es.host()
+            self.remove_factors((h["ii"] == k) | (h["jj"] == k), store=False)
 
             self.pg.kk[self.pg.ii > k] -= self.M
             self.pg.ii[self.pg.ii > k] -= 1
             self.pg.jj[self.pg.jj > k] -= 1
+            h = es.host()                   # same renumbering on the mirror (in-place views)
+            h["kk"][h["ii"] > k] -= self.M
+            h["ii"][h["ii"] > k] -= 1
+            h["jj"][h["jj"] > k] -= 1
 
             # shift the ring buffers down by one slot (the reference does this with a Python loop of
             # device-to-device copies, dpvo.py:289-299; tstamps_ is a host array)
@@ -324,13 +348,13 @@ class DPVO:
             self.n -= 1
             self.m -= self.M
             self._plan = None
+            to_remove = self._removal_mask(es.host())
 
-        to_remove = self.ix[self.pg.kk] < self.n - self.cfg.REMOVAL_WINDOW  # Remove edges falling outside the optimization window
-        if self.cfg.LOOP_CLOSURE:
-            # ...unless they are being used for loop closure
-            lc_edges = ((self.pg.jj - self.pg.ii) > 30) & (self.pg.jj > (self.n - self.cfg.OPTIMIZATION_WINDOW))
-            to_remove = to_remove & ~lc_edges
         self.remove_factors(to_remove, store=True)
+        if _CHECK_MIRROR:       # tests: the host mirror must track the device arrays exactly
+            h = es.host()
+            for k in ("ii", "jj", "kk"):
+                assert np.array_equal(h[k], getattr(self.pg, k).cpu().numpy()), f"edge mirror diverged ({k})"
 
     def __run_global_BA(self):
         """ Global bundle adjustment
@@ -435,66 +459,112 @@ class DPVO:
             self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
             maps = (slot, self._imap_full)
 
-        fmap, gmap, imap, patches, _, coords = \
-            self.network.patchify(img32 if img32 is not None else img16,
-                                  patches_per_image=self.cfg.PATCHES_PER_FRAME,
-                                  centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
-                                  coords=patch_coords, half=self._enc_half, images_f16=img16, return_coords=True,
-                                  maps=maps)
-
-        ### update state attributes ###
-        self.tlist.append(tstamp)
-        self.pg.tstamps_[self.n] = self.counter
-        self.pg.intrinsics_[self.n] = intrinsics / self.RES
-
-        # color info for visualization (clr = (clr[0,:,[2,1,0]] + 0.5) * (255.0 / 2) -> uint8): one kernel on the u8 image
-        L.check(L.lib().dpvo_patch_colors(L.ptr(image_u8), L.ptr(coords[0].contiguous()), L.ptr(self.pg.colors_[self.n]),
-                                          L.i32(self.M), L.i32(H), L.i32(W), L.stream()), "dpvo_patch_colors")
-
-        self.pg.index_[self.n + 1] = self.n + 1
-        self.pg.index_map_[self.n + 1] = self.m + self.M
-
-        if self.n > 1:
-            if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                # To deal with varying camera hz
-                *_, a, b, c = [1] * 3 + self.tlist
-                fac = (c - b) / (b - a)
-                # poses_[n] = Exp(MOTION_DAMPING * fac * Log(P1 * P2^-1)) * P1: one kernel (was ~8 lietorch launches)
-                L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
-                                                  L.f32(self.cfg.MOTION_DAMPING * fac), L.stream()), "dpvo_motion_model")
-            else:
-                tvec_qvec = self.poses[self.n - 1]
-                self.pg.poses_[self.n] = tvec_qvec
-
-        # TODO better depth initialization
-        patches = patches.float()
-        if depth_init is None:
-            patches[:, :, 2] = torch.rand_like(patches[:, :, 2, 0, 0, None, None])
-        else:
-            patches[:, :, 2] = depth_init.view(1, -1, 1, 1).to(patches)
-        self.pg.patches_[self.n] = patches
-        if self.is_initialized:
-            # s = torch.median(patches_[n-3:n,:,2]); patches[:,:,2] = s: one kernel (was sort + gather + fills)
-            if 3 * self.M * self.P * self.P <= 4096:
-                L.check(L.lib().dpvo_median_depth(L.ptr(self.pg.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.P),
-                                                  L.stream()), "dpvo_median_depth")
-            else:
-                self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
-
-        ### update network attributes ###
-        self.imap_[self.n % self.pmem] = imap.squeeze()
-        self.gmap_[self.n % self.pmem] = gmap.squeeze()
-        # fmap1_[:, n % mem] = avg_pool2d(fmap, 1, 1); fmap2_[:, n % mem] = avg_pool2d(fmap, 4, 4): one transposing kernel
-        if maps is not None:
+        fast = maps is not None and self.P == 3 and (patch_coords is None or patch_coords.numel() == 2 * self.M)
+        if fast:
+            # Patchifier's gathers + every per-frame state store in ONE launch (dpvo_frame_patches); the three random
+            # draws are the reference's own, in its order: randint x, randint y (net.py:132-133), rand depth (dpvo.py:427)
             hh, ww = maps[0].shape[:2]
+            xs = ys = cdev = None
+            if patch_coords is None:
+                xs = torch.randint(1, ww - 1, size=[1, self.M], device=self.device)
+                ys = torch.randint(1, hh - 1, size=[1, self.M], device=self.device)
+            else:
+                cdev = patch_coords.reshape(self.M, 2).to(device=self.device, dtype=torch.float32).contiguous()
+            if depth_init is None:
+                depth = torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device)
+            else:
+                depth = depth_init.reshape(self.M).to(device=self.device, dtype=torch.float32).contiguous()
+            self.tlist.append(tstamp)
+            self.pg.tstamps_[self.n] = self.counter
+            intr_dev = intrinsics if (torch.is_tensor(intrinsics) and intrinsics.is_cuda and
+                                      intrinsics.dtype == torch.float32 and intrinsics.is_contiguous()) else None
+            if intr_dev is None:
+                self.pg.intrinsics_[self.n] = intrinsics / self.RES
+            L.check(L.lib().dpvo_frame_patches(
+                L.ptr(maps[0]), L.ptr(maps[1]), L.ptr(image_u8), L.ptr(cdev), L.ptr(xs), L.ptr(ys), L.ptr(depth),
+                L.ptr(intr_dev), L.f32(self.RES), L.ptr(self._gmap_cl[self.n % self.pmem]),
+                L.ptr(self.imap_[self.n % self.pmem]), L.ptr(self.pg.patches_[self.n]), L.ptr(self.pg.colors_[self.n]),
+                L.ptr(self.pg.intrinsics_[self.n]) if intr_dev is not None else L.ptr(None),
+                L.ptr(self.pg.index_[self.n + 1]), L.ptr(self.pg.index_map_[self.n + 1:self.n + 2]), L.ptr(None),
+                L.i32(self.M), L.i32(hh), L.i32(ww), L.i32(H), L.i32(W), L.i32(128), L.i32(self.DIM), L.i32(self.P),
+                L.i64(self.n + 1), L.i64(self.m + self.M), L.stream()), "dpvo_frame_patches")
+            if self.n > 1:
+                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                    *_, a, b, c = [1] * 3 + self.tlist
+                    fac = (c - b) / (b - a)
+                    L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
+                                                      L.f32(self.cfg.MOTION_DAMPING * fac), L.stream()), "dpvo_motion_model")
+                else:
+                    self.pg.poses_[self.n] = self.poses[self.n - 1]
+            if self.is_initialized:
+                if 3 * self.M * self.P * self.P <= 4096:
+                    L.check(L.lib().dpvo_median_depth(L.ptr(self.pg.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.P),
+                                                      L.stream()), "dpvo_median_depth")
+                else:
+                    self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
             L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(hh), L.i32(ww),
                                             L.i32(128), L.stream()), "dpvo_pool4_nhwc")
         else:
-            fm = fmap[0, 0].contiguous()
-            L.check(L.lib().dpvo_store_features(L.ptr(fm), L.ptr(self._fmap1_cl[self.n % self.mem]),
-                                                L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(L.dtype_code(fm.dtype)),
-                                                L.i32(fm.shape[0]), L.i32(fm.shape[1]), L.i32(fm.shape[2]), L.stream()),
-                    "dpvo_store_features")
+            fmap, gmap, imap, patches, _, coords = \
+                self.network.patchify(img32 if img32 is not None else img16,
+                                      patches_per_image=self.cfg.PATCHES_PER_FRAME,
+                                      centroid_sel_strat=self.cfg.CENTROID_SEL_STRAT,
+                                      coords=patch_coords, half=self._enc_half, images_f16=img16, return_coords=True,
+                                      maps=maps)
+
+            ### update state attributes ###
+            self.tlist.append(tstamp)
+            self.pg.tstamps_[self.n] = self.counter
+            self.pg.intrinsics_[self.n] = intrinsics / self.RES
+
+            # color info for visualization (clr = (clr[0,:,[2,1,0]] + 0.5) * (255.0 / 2) -> uint8): one kernel on the u8 image
+            L.check(L.lib().dpvo_patch_colors(L.ptr(image_u8), L.ptr(coords[0].contiguous()), L.ptr(self.pg.colors_[self.n]),
+                                              L.i32(self.M), L.i32(H), L.i32(W), L.stream()), "dpvo_patch_colors")
+
+            self.pg.index_[self.n + 1] = self.n + 1
+            self.pg.index_map_[self.n + 1] = self.m + self.M
+
+            if self.n > 1:
+                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                    # To deal with varying camera hz
+                    *_, a, b, c = [1] * 3 + self.tlist
+                    fac = (c - b) / (b - a)
+                    # poses_[n] = Exp(MOTION_DAMPING * fac * Log(P1 * P2^-1)) * P1: one kernel (was ~8 lietorch launches)
+                    L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
+                                                      L.f32(self.cfg.MOTION_DAMPING * fac), L.stream()), "dpvo_motion_model")
+                else:
+                    tvec_qvec = self.poses[self.n - 1]
+                    self.pg.poses_[self.n] = tvec_qvec
+
+            # TODO better depth initialization
+            patches = patches.float()
+            if depth_init is None:
+                patches[:, :, 2] = torch.rand_like(patches[:, :, 2, 0, 0, None, None])
+            else:
+                patches[:, :, 2] = depth_init.view(1, -1, 1, 1).to(patches)
+            self.pg.patches_[self.n] = patches
+            if self.is_initialized:
+                # s = torch.median(patches_[n-3:n,:,2]); patches[:,:,2] = s: one kernel (was sort + gather + fills)
+                if 3 * self.M * self.P * self.P <= 4096:
+                    L.check(L.lib().dpvo_median_depth(L.ptr(self.pg.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.P),
+                                                      L.stream()), "dpvo_median_depth")
+                else:
+                    self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
+
+            ### update network attributes ###
+            self.imap_[self.n % self.pmem] = imap.squeeze()
+            self.gmap_[self.n % self.pmem] = gmap.squeeze()
+            # fmap1_[:, n % mem] = avg_pool2d(fmap, 1, 1); fmap2_[:, n % mem] = avg_pool2d(fmap, 4, 4): one transposing kernel
+            if maps is not None:
+                hh, ww = maps[0].shape[:2]
+                L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(hh), L.i32(ww),
+                                                L.i32(128), L.stream()), "dpvo_pool4_nhwc")
+            else:
+                fm = fmap[0, 0].contiguous()
+                L.check(L.lib().dpvo_store_features(L.ptr(fm), L.ptr(self._fmap1_cl[self.n % self.mem]),
+                                                    L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(L.dtype_code(fm.dtype)),
+                                                    L.i32(fm.shape[0]), L.i32(fm.shape[1]), L.i32(fm.shape[2]), L.stream()),
+                        "dpvo_store_features")
 
         self.counter += 1
         if self.n > 0 and not self.is_initialized:

@@ -19,10 +19,20 @@ class EdgeStore:
     ~45 small launches and ~150 MB of copies.  Here appends write into the tail of capacity buffers (one kernel) and
     removals compact into a second buffer set (one nonzero + one gather kernel), then the sets swap."""
 
-    def __init__(self, D, device, with_state=True, cap=65536):
+    def __init__(self, D, device, with_state=True, cap=65536, mirror=False):
         self.D, self.dev, self.with_state = D, device, with_state
         self.E = 0
         self._alloc(cap)
+        # Host mirror of (ii, jj, kk) as int32 numpy arrays: the integer bookkeeping is deterministic, so the removal masks
+        # of DPVO.keyframe can be computed on the host WHILE the GPU runs the update -- no nonzero() read-back.
+        # _h is None when the mirror is unknown (re-read from the device on demand); _log holds the mutations that have been
+        # applied to the device arrays but not yet to the mirror (applied lazily, off the critical path).
+        self.mirror = mirror
+        self._h = None if not mirror else {k: np.empty(cap, dtype=np.int32) for k in ("ii", "jj", "kk")}
+        self._hE = 0
+        self._log = []
+        self._stage = None          # pinned / device index staging buffers (ping-pong)
+        self._stage_flip = 0
 
     def _new(self, cap):
         d = {k: torch.empty(cap, dtype=torch.long, device=self.dev) for k in ("ii", "jj", "kk")}
@@ -43,6 +53,73 @@ class EdgeStore:
         self._alloc(max(2 * self.cap, self.E + n))
         for k, v in old.items():
             self.a[k][:E] = v[:E]
+        self._stage = None
+        if self._h is not None:
+            for k in self._h:
+                h = np.empty(self.cap, dtype=np.int32)
+                h[:self._hE] = self._h[k][:self._hE]
+                self._h[k] = h
+
+    # ---- host mirror -------------------------------------------------------------------------------------------
+    def host(self):
+        """(ii, jj, kk) of the active edges as int32 numpy views.  Appends and compactions are only LOGGED when they happen
+        (the GPU is starved for launches in that part of the frame) and replayed here, where the caller has slack; one
+        device read-back only if the mirror was lost"""
+        if not self.mirror:
+            raise RuntimeError("EdgeStore created without a host mirror")
+        if self._h is None:
+            self._h = {k: np.empty(self.cap, dtype=np.int32) for k in ("ii", "jj", "kk")}
+            for k in self._h:
+                self._h[k][:self.E] = self.a[k][:self.E].cpu().numpy()
+            self._hE, self._log = self.E, []
+        for op in self._log:
+            if op[0] == "keep":
+                idx = op[1]
+                for k in self._h:
+                    self._h[k][:idx.size] = self._h[k][:self._hE][idx]
+                self._hE = idx.size
+            elif op[0] == "frame":
+                # append_edges_kernel's edges (ix[k] == k // M: index_ rows hold their own frame number, dpvo.py:405)
+                _, n, M, r = op
+                E0 = self._hE
+                f0, f1 = M * max(n - r, 0), M * max(n - 1, 0)
+                nf = f1 - f0
+                jlo = max(n - r, 0)
+                nj = n - jlo
+                total = nf + M * nj
+                hk, hj, hi = self._h["kk"], self._h["jj"], self._h["ii"]
+                hk[E0:E0 + nf] = np.arange(f0, f1, dtype=np.int32)
+                hj[E0:E0 + nf] = n - 1
+                hk[E0 + nf:E0 + total] = np.repeat(np.arange(f1, f1 + M, dtype=np.int32), nj)
+                hj[E0 + nf:E0 + total] = np.tile(np.arange(jlo, n, dtype=np.int32), M)
+                hi[E0:E0 + total] = hk[E0:E0 + total] // M
+                self._hE = E0 + total
+            else:
+                _, ii, jj, kk = op
+                n = ii.size
+                for k, v in (("ii", ii), ("jj", jj), ("kk", kk)):
+                    self._h[k][self._hE:self._hE + n] = v
+                self._hE += n
+        self._log = []
+        assert self._hE == self.E
+        return {k: v[:self.E] for k, v in self._h.items()}
+
+    def invalidate_host(self):
+        if self.mirror:
+            self._h, self._log = None, []
+
+    def stage_indices(self, idx_np):
+        """host int64 indices -> device tensor, through pinned memory, without blocking the host"""
+        n = int(idx_np.size)
+        if self._stage is None:
+            mk = lambda: (torch.empty(self.cap, dtype=torch.int64).pin_memory(),
+                          torch.empty(self.cap, dtype=torch.int64, device=self.dev))
+            self._stage = [mk() for _ in range(4)]
+        pin, dev = self._stage[self._stage_flip]
+        self._stage_flip = (self._stage_flip + 1) % len(self._stage)
+        pin[:n].numpy()[:] = idx_np
+        dev[:n].copy_(pin[:n], non_blocking=True)
+        return dev[:n]
 
     def view(self, name):
         return self.a[name][:self.E]
@@ -53,6 +130,8 @@ class EdgeStore:
         if name in ("ii", "jj", "kk") and n != self.E:
             raise ValueError("edge arrays must be resized through EdgeStore.append / keep")
         self.a[name][:n] = value
+        if name in ("ii", "jj", "kk"):
+            self.invalidate_host()
 
     def append_frame(self, ix, n, M, r):
         """append_factors(edges_forw) + append_factors(edges_back) for frame count n: one kernel"""
@@ -65,6 +144,8 @@ class EdgeStore:
                                           L.ptr(self.a["net"]), L.ptr(ix), L.i64(self.E), L.i32(n), L.i32(M), L.i32(r),
                                           L.i32(self.D), ctypes.byref(cnt), L.stream()), "dpvo_append_edges")
         assert cnt.value == total
+        if self._h is not None:
+            self._log.append(("frame", n, M, r))
         self.E += total
 
     def append(self, ii, jj, kk, net=None, target=None, weight=None):
@@ -82,6 +163,8 @@ class EdgeStore:
                 self.a[name][E:E + n].zero_()
             else:
                 self.a[name][E:E + n] = val.reshape(n, 2)
+        if self._h is not None and n:
+            self._log.append(("edges",) + tuple(v.cpu().numpy().astype(np.int32) for v in (ii, jj, kk)))
         self.E += n
 
     def gather_into(self, idx, dst, dst_off):
@@ -95,10 +178,16 @@ class EdgeStore:
             L.ptr(o(dst.get("net"))), L.ptr(o(dst["target"])), L.ptr(o(dst["weight"])), L.i32(self.D), L.stream()),
             "dpvo_gather_edges")
 
-    def keep(self, idx):
-        """compact to the edges listed in idx (sorted ascending), ping-pong buffers"""
+    def keep(self, idx, idx_host=None):
+        """compact to the edges listed in idx (sorted ascending), ping-pong buffers.  idx_host: the same indices as a numpy
+        array, which keeps the host mirror alive (applied lazily)"""
         self.gather_into(idx, self.b, 0)
         self.a, self.b = self.b, self.a
+        if self._h is not None:
+            if idx_host is None:
+                self.invalidate_host()
+            else:
+                self._log.append(("keep", idx_host))
         self.E = idx.numel()
 
 
@@ -162,7 +251,7 @@ class PatchGraph:
         self.delta = {}
 
         ### edge information: preallocated stores, exposed under the reference's attribute names ###
-        self.edges = EdgeStore(DIM, dev, with_state=True)
+        self.edges = EdgeStore(DIM, dev, with_state=True, mirror=True)
         ### inactive edge information (i.e., no longer updated, but useful for BA) ###
         self.edges_inac = EdgeStore(DIM, dev, with_state=False, cap=1 << 17)
 

@@ -245,6 +245,19 @@ int dpvo_append_edges(int64_t* ii, int64_t* jj, int64_t* kk, float* net, const i
 int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* ii, const int64_t* jj, const int64_t* kk,
                       const float* net, const float* target, const float* weight, int64_t* oii, int64_t* ojj,
                       int64_t* okk, float* onet, float* otarget, float* oweight, int D, void* stream);
+/* Everything a new frame contributes besides its feature maps, in one launch: Patchifier.forward's gathers
+ * (net.py:136-147: gmap = patchify(fmap, coords, 1), imap = patchify(imap, coords, 0), patches = patchify(grid, coords, 1),
+ * clr = patchify(image, 4 (coords + 0.5), 0)) and the per-frame state stores of dpvo.py:401-438 (intrinsics / RES,
+ * index_, index_map_, patches[:,:,2] = depth, colours as RGB uint8).  fmap [h,w,CF] / imap [h,w,CI] are NHWC f16 (the
+ * encoders' output), img_u8 [3,H,W]; coords [M,2] f32 OR the two randint draws xs, ys [M] int64 (net.py:132-133);
+ * depth [M] f32.  Slots: gmap [M,3,3,CF] f16 (channels-last), imap [M,CI] f16, patches [M,3,3,3] f32, colours [M,3] u8,
+ * intrinsics_slot [4] (may be NULL), index_row [M] = frame_next and *index_map = m_next (may be NULL), coords_out [M,2]
+ * (may be NULL).  P must be 3. */
+int dpvo_frame_patches(const void* fmap, const void* imap, const void* img_u8, const float* coords, const int64_t* xs,
+                       const int64_t* ys, const float* depth, const float* intrinsics, float res, void* gmap_slot,
+                       void* imap_slot, float* patches_slot, void* colors_slot, float* intrinsics_slot,
+                       int64_t* index_row, int64_t* index_map, float* coords_out, int M, int h, int w, int H, int W, int CF,
+                       int CI, int P, int64_t frame_next, int64_t m_next, void* stream);
 /* damped-linear motion model (dpvo.py:410-421): poses[n] = Exp(scale * Log(P[n-1] * P[n-2]^-1)) * P[n-1]. */
 int dpvo_motion_model(float* poses, int n, float scale, void* stream);
 /* depth initialisation (dpvo.py:430-432): patches[n][:,2] = torch.median(patches[n-3:n,:,2]) (lower median). */

@@ -31,9 +31,10 @@ def _run(dev, decisions, M=16, seed=0, ht=96, wd=128):
     thresh = cfg.KEYFRAME_THRESH
     calls = []
 
-    def fake(*a, **k):
+    def fake(*a, defer=False, **k):
         calls.append(orig(*a, **k))           # the real kernel still runs (and must not crash)
-        return (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
+        res = (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
+        return (lambda: res) if defer else res
     pops.motionmag_pair = fake
     try:
         for t, (accept, drop) in enumerate(decisions):

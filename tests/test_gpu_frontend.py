@@ -86,3 +86,50 @@ def test_edge_store_matches_replay(dev):
         born = torch.maximum(st.view("jj"), st.view("kk") // cfg.M) + 1
         assert torch.equal(st.view("net")[:, 0], born.float()) and torch.equal(st.view("target")[:, 1], born.float())
     assert inac.E > 0 and (inac.view("ii") < 24 - cfg.REMOVAL_WINDOW).all()
+
+
+@pytest.mark.parametrize("mode", ["float_coords", "randint"])
+def test_frame_patches_matches_patchifier_composition(dev, mode):
+    """dpvo_frame_patches == the separate patchify gathers (net.py:136-147) + state stores (dpvo.py:401-438), bit for bit"""
+    from dpvo_amd.utils import coords_grid_with_index
+    g = torch.Generator().manual_seed(3)
+    H, W, M, CF, CI = 96, 128, 48, 128, 384
+    h, w = H // 4, W // 4
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)
+    fmap = (torch.randn(h, w, CF, generator=g) / 2).half().to(dev)
+    imap = (torch.randn(h, w, CI, generator=g) / 2).half().to(dev)
+    xs = torch.randint(1, w - 1, (1, M), generator=g).to(dev)
+    ys = torch.randint(1, h - 1, (1, M), generator=g).to(dev)
+    coords = torch.stack([xs, ys], -1).float()
+    if mode == "float_coords":
+        coords = coords + torch.rand(1, M, 2, generator=g).to(dev) * 0.9
+        coords[0, 0] = torch.tensor([w - 1.4, 0.3], device=dev)           # windows partly out of bounds
+        coords[0, 1] = torch.tensor([0.2, h - 1.1], device=dev)
+    depth = torch.rand(M, generator=g).to(dev)
+    intr = torch.tensor([320.0, 321.0, 64.0, 48.0], device=dev)
+    # composition (the code path DPVO uses without the fused kernel)
+    f_nchw, i_nchw = fmap.permute(2, 0, 1)[None], imap.permute(2, 0, 1)[None]
+    ref_imap = altcorr.patchify(i_nchw, coords, 0).view(M, CI)
+    ref_gmap = altcorr.patchify(f_nchw, coords, 1).view(M, CF, 3, 3).permute(0, 2, 3, 1)
+    grid, _ = coords_grid_with_index(torch.ones(1, 1, h, w, device=dev), device=dev)
+    ref_patches = altcorr.patchify(grid[0], coords, 1).view(M, 3, 3, 3).float().clone()
+    ref_patches[:, 2] = depth.view(M, 1, 1)
+    img_n = 2 * (img[None, None] / 255.0) - 0.5
+    clr = altcorr.patchify(img_n[0], 4 * (coords + 0.5), 0).view(1, -1, 3)
+    ref_clr = ((clr[0, :, [2, 1, 0]] + 0.5) * (255.0 / 2)).to(torch.uint8)
+    # fused
+    gmap = torch.zeros(M, 3, 3, CF, dtype=torch.float16, device=dev); im = torch.zeros(M, CI, dtype=torch.float16, device=dev)
+    patches = torch.zeros(M, 3, 3, 3, device=dev); colors = torch.zeros(M, 3, dtype=torch.uint8, device=dev)
+    intr_o = torch.zeros(4, device=dev); idx_row = torch.zeros(M, dtype=torch.long, device=dev)
+    idx_map = torch.zeros(1, dtype=torch.long, device=dev); cout = torch.zeros(M, 2, device=dev)
+    use_xy = mode == "randint"
+    L.check(L.lib().dpvo_frame_patches(
+        L.ptr(fmap), L.ptr(imap), L.ptr(img), L.ptr(None if use_xy else coords[0].contiguous()),
+        L.ptr(xs if use_xy else None), L.ptr(ys if use_xy else None), L.ptr(depth), L.ptr(intr), L.f32(4.0), L.ptr(gmap),
+        L.ptr(im), L.ptr(patches), L.ptr(colors), L.ptr(intr_o), L.ptr(idx_row), L.ptr(idx_map), L.ptr(cout), L.i32(M),
+        L.i32(h), L.i32(w), L.i32(H), L.i32(W), L.i32(CF), L.i32(CI), L.i32(3), L.i64(7), L.i64(7 * M), L.stream()),
+        "dpvo_frame_patches")
+    assert torch.equal(gmap, ref_gmap) and torch.equal(im, ref_imap)
+    assert torch.equal(patches, ref_patches) and torch.equal(colors, ref_clr)
+    assert torch.equal(intr_o, intr / 4.0) and torch.equal(cout, coords[0])
+    assert (idx_row == 7).all() and idx_map.item() == 7 * M
