@@ -13,59 +13,81 @@
 
 namespace {
 
-constexpr int kKeyShift = 24;   // jj (frame index) < 2^24; BUFFER_SIZE is 4096 in the reference (config.py:6)
+constexpr int kKeyShift = 24;   // generic path: jj (frame index) < 2^24; BUFFER_SIZE is 4096 in the reference (config.py:6)
 
-__global__ void make_keys_kernel(const int64_t* __restrict__ hi, const int64_t* __restrict__ lo,
-                                 uint64_t* __restrict__ keys, int32_t* __restrict__ vals, int64_t E) {
+// keys of BOTH sorts in one pass: kA = kk<<shift | jj, kB = ii<<shift | jj, value = edge id
+template <typename K>
+__global__ void make_keys_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                 const int64_t* __restrict__ kk, K* __restrict__ keysA, K* __restrict__ keysB,
+                                 int32_t* __restrict__ vals, int64_t E, int shift) {
+  const K lomask = ((K)1 << shift) - 1;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-    keys[e] = ((uint64_t)hi[e] << kKeyShift) | (uint64_t)(lo[e] & ((1 << kKeyShift) - 1));
+    const K lo = (K)jj[e] & lomask;
+    if (keysA) keysA[e] = ((K)kk[e] << shift) | lo;
+    if (keysB) keysB[e] = ((K)ii[e] << shift) | lo;
     vals[e] = (int32_t)e;
   }
 }
 
-// flags[p] = 1 where a new group (same_hi: group by the high part only; else by the whole key) starts
-__global__ void flag_kernel(const uint64_t* __restrict__ keys, int32_t* __restrict__ flags, int64_t E, int by_hi) {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
-    int f = 1;
-    if (p > 0) {
-      const uint64_t a = by_hi ? (keys[p] >> kKeyShift) : keys[p];
-      const uint64_t b = by_hi ? (keys[p - 1] >> kKeyShift) : keys[p - 1];
-      f = (a != b);
-    }
-    flags[p] = f;
-  }
-}
-
-// rank[p] = inclusive scan of flags; scatter group structures.
-__global__ void scatter_patch_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm,
-                                     const int32_t* __restrict__ flags, const int32_t* __restrict__ rank,
-                                     int32_t* __restrict__ ku, int32_t* __restrict__ kx, int32_t* __restrict__ off,
-                                     int32_t* __restrict__ ix, int32_t* __restrict__ jx, int32_t* __restrict__ count,
-                                     int64_t E) {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t g = rank[p] - 1;
+// Group structures of a sorted key array in ONE launch (flag + scan + scatter), 1024 positions per workgroup.  A workgroup
+// gets the rank of its first position by counting the group starts of ALL preceding positions itself (coalesced, L2
+// resident: ~E/2048 loads per thread) instead of waiting for a scan pass -- no inter-workgroup communication at all.
+// by_hi: a group is a run of equal high parts (patch), else of equal whole keys (frame pair).
+//   PATCH: ku[e] = group, kx[g] = patch id, off[g] = first position, ix/jx[e] = previous / next edge of the patch
+//   PAIR : pu[e] = group, pair_ij[g] = (i, j), off[g]
+template <typename K, bool PATCH>
+__global__ __launch_bounds__(1024) void group_kernel(const K* __restrict__ keys, const int32_t* __restrict__ perm,
+                                                     int32_t* __restrict__ gu, int32_t* __restrict__ gx,
+                                                     int32_t* __restrict__ off, int32_t* __restrict__ ix,
+                                                     int32_t* __restrict__ jx, int32_t* __restrict__ count,
+                                                     int32_t* __restrict__ zero2, int64_t E, int shift) {
+  __shared__ int32_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  auto gkey = [&](int64_t p) -> K { return PATCH ? (K)(keys[p] >> shift) : keys[p]; };
+  auto is_start = [&](int64_t p) -> bool { return p == 0 || gkey(p) != gkey(p - 1); };
+  // (a) group starts before this workgroup's first position
+  const int64_t first = (int64_t)blockIdx.x * 1024;
+  int32_t c = 0;
+  for (int64_t p = t; p < first; p += 1024) c += is_start(p);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) wsum[wv] = c;
+  __syncthreads();
+  int32_t base = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) base += wsum[i];
+  __syncthreads();
+  // (b) ranks inside the workgroup
+  const int64_t p = first + t;
+  const bool valid = p < E;
+  const bool start = valid && is_start(p);
+  const unsigned long long bal = __ballot(start);
+  const int32_t wpre = __popcll(bal & ((1ull << lane) - 1));
+  if (lane == 0) wsum[wv] = __popcll(bal);
+  __syncthreads();
+  int32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { wbase += i < wv ? wsum[i] : 0; total += wsum[i]; }
+  const int32_t g = base + wbase + wpre + (start ? 1 : 0) - 1;
+  // (c) scatter
+  if (valid) {
     const int32_t e = perm[p];
-    ku[e] = g;
-    if (flags[p]) { off[g] = (int32_t)p; kx[g] = (int32_t)(keys[p] >> kKeyShift); }
-    ix[e] = flags[p] ? -1 : perm[p - 1];
-    jx[e] = (p + 1 < E && !flags[p + 1]) ? perm[p + 1] : -1;
-    if (p == E - 1) { off[g + 1] = (int32_t)E; *count = g + 1; }
-  }
-}
-
-__global__ void scatter_pair_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm,
-                                    const int32_t* __restrict__ flags, const int32_t* __restrict__ rank,
-                                    int32_t* __restrict__ pu, int32_t* __restrict__ off, int32_t* __restrict__ pair_ij,
-                                    int32_t* __restrict__ count, int64_t E) {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t g = rank[p] - 1;
-    pu[perm[p]] = g;
-    if (flags[p]) {
+    gu[e] = g;
+    const K lomask = ((K)1 << shift) - 1;
+    if (start) {
       off[g] = (int32_t)p;
-      pair_ij[2 * g + 0] = (int32_t)(keys[p] >> kKeyShift);
-      pair_ij[2 * g + 1] = (int32_t)(keys[p] & ((1 << kKeyShift) - 1));
+      if (PATCH) gx[g] = (int32_t)(keys[p] >> shift);
+      else { gx[2 * g + 0] = (int32_t)(keys[p] >> shift); gx[2 * g + 1] = (int32_t)(keys[p] & lomask); }
     }
-    if (p == E - 1) { off[g + 1] = (int32_t)E; *count = g + 1; }
+    if (PATCH) {
+      ix[e] = start ? -1 : perm[p - 1];
+      jx[e] = (p + 1 < E && gkey(p + 1) == gkey(p)) ? perm[p + 1] : -1;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && t == 0) {
+    off[base + total] = (int32_t)E;
+    *count = base + total;
+    if (zero2) { zero2[0] = 0; zero2[1] = 0; }
   }
 }
 
@@ -84,47 +106,66 @@ inline unsigned grid_for(int64_t n) {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-  size_t keys_in, keys_out, vals_in, flags, rank, temp, temp_bytes, total;
+  size_t keys_a, keys_b, keys_out, vals_in, temp, temp_bytes, total;
 };
 
+// (sized for the 64-bit generic path; the 32-bit path uses a prefix of every buffer)
 int ws_layout(int64_t E, WsLayout* L) {
-  size_t sort_bytes = 0, scan_bytes = 0;
+  size_t sort_bytes = 0, sort_bytes32 = 0;
   const size_t n = (size_t)(E > 0 ? E : 1);
   hipError_t e1 = rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr,
                                             (int32_t*)nullptr, (int32_t*)nullptr, n, 0, 64, (hipStream_t)0);
-  hipError_t e2 = rocprim::inclusive_scan(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n,
-                                          rocprim::plus<int32_t>(), (hipStream_t)0);
+  hipError_t e2 = rocprim::radix_sort_pairs(nullptr, sort_bytes32, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                            (int32_t*)nullptr, (int32_t*)nullptr, n, 0, 32, (hipStream_t)0);
   if (e1 != hipSuccess) return (int)e1;
   if (e2 != hipSuccess) return (int)e2;
   size_t o = 0;
-  L->keys_in = o; o += align256(n * 8);
+  L->keys_a = o; o += align256(n * 8);
+  L->keys_b = o; o += align256(n * 8);
   L->keys_out = o; o += align256(n * 8);
   L->vals_in = o; o += align256(n * 4);
-  L->flags = o; o += align256(n * 4);
-  L->rank = o; o += align256(n * 4);
   L->temp = o;
-  L->temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  L->temp_bytes = sort_bytes > sort_bytes32 ? sort_bytes : sort_bytes32;
   o += align256(L->temp_bytes);
   L->total = o;
   return 0;
 }
 
-// sorts (hi<<24|lo, edge id), leaves sorted keys in ws.keys_out, perm in `perm`, flags/rank in ws
-int sort_and_rank(const int64_t* hi, const int64_t* lo, int64_t E, int32_t* perm, char* ws, const WsLayout& L,
-                  int by_hi, hipStream_t st) {
-  uint64_t* keys_in = (uint64_t*)(ws + L.keys_in);
-  uint64_t* keys_out = (uint64_t*)(ws + L.keys_out);
-  int32_t* vals_in = (int32_t*)(ws + L.vals_in);
-  int32_t* flags = (int32_t*)(ws + L.flags);
-  int32_t* rank = (int32_t*)(ws + L.rank);
-  hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(E)), dim3(256), 0, st, hi, lo, keys_in, vals_in, E);
-  size_t tb = L.temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs((void*)(ws + L.temp), tb, keys_in, keys_out, vals_in, perm, (size_t)E, 0, 64, st);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(flag_kernel, dim3(grid_for(E)), dim3(256), 0, st, keys_out, flags, E, by_hi);
-  tb = L.temp_bytes;
-  e = rocprim::inclusive_scan((void*)(ws + L.temp), tb, flags, rank, (size_t)E, rocprim::plus<int32_t>(), st);
-  if (e != hipSuccess) return (int)e;
+inline int bits_for(int64_t n) {      // bits needed for values in [0, n)
+  int b = 1;
+  while (b < 63 && ((int64_t)1 << b) < n) ++b;
+  return b;
+}
+
+// The whole plan for key type K.  which: bit 0 = per-patch structure, bit 1 = per-pair structure.
+template <typename K>
+int build_plan(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+               const dpvo_plan_layout_t& P, char* w, const WsLayout& L, int shift, int bits_a, int bits_b, int which,
+               hipStream_t st) {
+  K* keys_a = (K*)(w + L.keys_a);
+  K* keys_b = (K*)(w + L.keys_b);
+  K* keys_out = (K*)(w + L.keys_out);
+  int32_t* vals_in = (int32_t*)(w + L.vals_in);
+  hipLaunchKernelGGL(make_keys_kernel<K>, dim3(grid_for(E)), dim3(256), 0, st, ii, jj, kk, (which & 1) ? keys_a : (K*)nullptr,
+                     (which & 2) ? keys_b : (K*)nullptr, vals_in, E, shift);
+  if (which & 1) {      // sort by (kk, jj, edge)
+    size_t tb = L.temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_a, keys_out, vals_in, plan + P.perm_k, (size_t)E, 0,
+                                             (unsigned)bits_a, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((group_kernel<K, true>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const K*)keys_out, plan + P.perm_k, plan + P.ku,
+                       plan + P.kx, plan + P.patch_off, plan + P.ix, plan + P.jx, plan + P.counts + 0, plan + P.counts + 2, E,
+                       shift);
+  }
+  if (which & 2) {      // sort by (ii, jj, edge)
+    size_t tb = L.temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_b, keys_out, vals_in, plan + P.perm_p, (size_t)E, 0,
+                                             (unsigned)bits_b, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((group_kernel<K, false>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const K*)keys_out, plan + P.perm_p, plan + P.pu,
+                       plan + P.pair_ij, plan + P.pair_off, (int32_t*)nullptr, (int32_t*)nullptr, plan + P.counts + 1,
+                       (int32_t*)nullptr, E, shift);
+  }
   return 0;
 }
 
@@ -155,8 +196,8 @@ extern "C" size_t dpvo_plan_workspace_bytes(int64_t E) {
   return L.total;
 }
 
-extern "C" int dpvo_plan_build(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
-                               void* ws, size_t ws_bytes, void* stream) {
+extern "C" int dpvo_plan_build_ranged(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+                                      void* ws, size_t ws_bytes, int64_t n_frames, int64_t n_patch_ids, void* stream) {
   if (E < 0 || !plan) return DPVO_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   dpvo_plan_layout_t P;
@@ -170,23 +211,27 @@ extern "C" int dpvo_plan_build(const int64_t* ii, const int64_t* jj, const int64
   int rc = ws_layout(E, &L);
   if (rc) return rc;
   if (ws_bytes < L.total) return DPVO_E_WORKSPACE;
-  char* w = (char*)ws;
-  hipError_t e = hipMemsetAsync(plan + P.counts, 0, 4 * sizeof(int32_t), st);
-  if (e != hipSuccess) return (int)e;
-  // --- per-patch structure: sort by (kk, jj, edge)
-  rc = sort_and_rank(kk, jj, E, plan + P.perm_k, w, L, /*by_hi=*/1, st);
+  // With bounds on the index ranges (ii, jj < n_frames, kk < n_patch_ids) the composite keys usually fit 32 bits and
+  // the LSD radix sorts only visit the bits that can be set: 4 digit passes instead of 8.
+  if (n_frames > 0 && n_patch_ids > 0) {
+    const int lo = bits_for(n_frames), hk = bits_for(n_patch_ids), hi = bits_for(n_frames);
+    if (lo + hk <= 32 && lo + hi <= 32)
+      rc = build_plan<uint32_t>(ii, jj, kk, E, plan, P, (char*)ws, L, lo, lo + hk, lo + hi, 3, st);
+    else if (lo + hk <= 64)
+      rc = build_plan<uint64_t>(ii, jj, kk, E, plan, P, (char*)ws, L, lo, lo + hk, lo + hi, 3, st);
+    else
+      return DPVO_E_UNSUPPORTED;
+  } else {
+    rc = build_plan<uint64_t>(ii, jj, kk, E, plan, P, (char*)ws, L, kKeyShift, 64, 64, 3, st);
+  }
   if (rc) return rc;
-  hipLaunchKernelGGL(scatter_patch_kernel, dim3(grid_for(E)), dim3(256), 0, st, (const uint64_t*)(w + L.keys_out),
-                     plan + P.perm_k, (const int32_t*)(w + L.flags), (const int32_t*)(w + L.rank), plan + P.ku,
-                     plan + P.kx, plan + P.patch_off, plan + P.ix, plan + P.jx, plan + P.counts + 0, E);
-  // --- per-frame-pair structure: sort by (ii, jj, edge)
-  rc = sort_and_rank(ii, jj, E, plan + P.perm_p, w, L, /*by_hi=*/0, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(scatter_pair_kernel, dim3(grid_for(E)), dim3(256), 0, st, (const uint64_t*)(w + L.keys_out),
-                     plan + P.perm_p, (const int32_t*)(w + L.flags), (const int32_t*)(w + L.rank), plan + P.pu,
-                     plan + P.pair_off, plan + P.pair_ij, plan + P.counts + 1, E);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
+}
+
+extern "C" int dpvo_plan_build(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+                               void* ws, size_t ws_bytes, void* stream) {
+  return dpvo_plan_build_ranged(ii, jj, kk, E, plan, ws, ws_bytes, 0, 0, stream);
 }
 
 // cuda_ba.neighbors API parity: ws must hold dpvo_neighbors_workspace_bytes(E).
@@ -212,11 +257,16 @@ extern "C" int dpvo_neighbors(const int64_t* kk, const int64_t* jj, int64_t* ix,
   const size_t stride = align256((size_t)E * 4) / 4;
   int32_t *perm = base, *ku = base + stride, *kx = base + 2 * stride, *ix32 = base + 3 * stride,
           *jx32 = base + 4 * stride, *off = base + 5 * stride;   // off needs E+1 <= stride*... (E+1)*4 <= align256(4E)+256
-  rc = sort_and_rank(kk, jj, E, perm, w, L, 1, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(scatter_patch_kernel, dim3(grid_for(E)), dim3(256), 0, st, (const uint64_t*)(w + L.keys_out), perm,
-                     (const int32_t*)(w + L.flags), (const int32_t*)(w + L.rank), ku, kx, off, ix32, jx32,
-                     off + E + 1 /*count scratch*/, E);
+  uint64_t* keys_a = (uint64_t*)(w + L.keys_a);
+  uint64_t* keys_out = (uint64_t*)(w + L.keys_out);
+  int32_t* vals_in = (int32_t*)(w + L.vals_in);
+  hipLaunchKernelGGL(make_keys_kernel<uint64_t>, dim3(grid_for(E)), dim3(256), 0, st, (const int64_t*)nullptr, jj, kk, keys_a,
+                     (uint64_t*)nullptr, vals_in, E, kKeyShift);
+  size_t tb = L.temp_bytes;
+  hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_a, keys_out, vals_in, perm, (size_t)E, 0, 64, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((group_kernel<uint64_t, true>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const uint64_t*)keys_out, perm, ku, kx, off,
+                     ix32, jx32, off + E + 1 /*count scratch*/, (int32_t*)nullptr, E, kKeyShift);
   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(E)), dim3(256), 0, st, ix32, jx32, ix, jx, E);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;

@@ -250,14 +250,22 @@ class DPVO:
         self.pg.edges.append_frame(self.ix, self.n, self.M, self.cfg.PATCH_LIFETIME)
         self._plan = None
 
-    def remove_factors(self, m, store: bool):
-        """dpvo.py:223-238.  m: bool mask over the active edges (a device tensor as in the reference, or a host numpy
-        mask computed from the edge store's mirror: then no read-back is needed)."""
+    def _stage_removal(self, m, store):
+        """host mask -> (rem, keep) index tensors on the device (async copies through pinned memory) + keep on the host"""
         es = self.pg.edges
-        if isinstance(m, np.ndarray):
-            rem_h, keep_h = np.flatnonzero(m), np.flatnonzero(~m)
-            rem = es.stage_indices(rem_h) if store and rem_h.size else None
-            keep = es.stage_indices(keep_h)
+        rem_h, keep_h = np.flatnonzero(m), np.flatnonzero(~m)
+        rem = es.stage_indices(rem_h) if store and rem_h.size else None
+        return rem, es.stage_indices(keep_h), keep_h
+
+    def remove_factors(self, m, store: bool, staged=None):
+        """dpvo.py:223-238.  m: bool mask over the active edges (a device tensor as in the reference, or a host numpy
+        mask computed from the edge store's mirror: then no read-back is needed; `staged` = _stage_removal(m, store)
+        done ahead of time)."""
+        es = self.pg.edges
+        if staged is not None:
+            rem, keep, keep_h = staged
+        elif isinstance(m, np.ndarray):
+            rem, keep, keep_h = self._stage_removal(m, store)
         else:
             rem = m.nonzero().squeeze(1) if store else None
             keep, keep_h = (~m).nonzero().squeeze(1), None
@@ -309,6 +317,7 @@ class DPVO:
         # while the GPU is still busy with this frame: the removal mask of the common case (keyframe kept), on the host
         es = self.pg.edges
         to_remove = self._removal_mask(es.host())
+        staged = self._stage_removal(to_remove, True)
         m_ij, m_ji = m_pending()            # the one host read-back of the frame
         m = m_ij + m_ji
 
@@ -348,9 +357,9 @@ class DPVO:
             self.n -= 1
             self.m -= self.M
             self._plan = None
-            to_remove = self._removal_mask(es.host())
+            to_remove, staged = self._removal_mask(es.host()), None
 
-        self.remove_factors(to_remove, store=True)
+        self.remove_factors(to_remove, store=True, staged=staged)
         if _CHECK_MIRROR:       # tests: the host mirror must track the device arrays exactly
             h = es.host()
             for k in ("ii", "jj", "kk"):
@@ -381,7 +390,8 @@ class DPVO:
                 nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
                 ub_p = nf * self.M
                 ub_g = nf * (2 * self.cfg.PATCH_LIFETIME + 2)
-            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g)
+            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
+                                   n_frames=self.N, n_patch_ids=self.N * self.M)
         return self._plan
 
     def update(self):

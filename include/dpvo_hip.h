@@ -150,6 +150,12 @@ int dpvo_plan_layout(int64_t E, dpvo_plan_layout_t* layout);
 size_t dpvo_plan_workspace_bytes(int64_t E);
 int dpvo_plan_build(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
                     void* ws, size_t ws_bytes, void* stream);
+/* Same, with bounds on the index ranges supplied by the caller (every ii, jj < n_frames, every kk < n_patch_ids, e.g.
+ * BUFFER_SIZE and BUFFER_SIZE * PATCHES_PER_FRAME of dpvo/config.py:6): the composite sort keys then fit 32 bits and the
+ * radix sorts visit only the bits that can be set.  Indices outside the bounds give an undefined (but memory-safe)
+ * grouping.  n_frames = n_patch_ids = 0 means "unknown" (64-bit keys). */
+int dpvo_plan_build_ranged(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
+                           size_t ws_bytes, int64_t n_frames, int64_t n_patch_ids, void* stream);
 
 /* cuda_ba.neighbors(kk, jj) -- ba.cpp:59-97,187: int64 outputs for API parity (device resident). */
 size_t dpvo_neighbors_workspace_bytes(int64_t E);

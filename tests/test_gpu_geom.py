@@ -79,8 +79,9 @@ def test_reproject_flow_points(oracle, dev):
     H.assert_close(co2[0].cpu().numpy()[(ok & front).numpy()], ref[(ok & front).numpy()], 5e-3, 1e-4, "cuda_ba.reproject")
 
 
+@pytest.mark.parametrize("ranged", [False, True])
 @pytest.mark.parametrize("case", ["replay40", "small", "shuffled", "single", "empty"])
-def test_plan_bit_exact(oracle, dev, case):
+def test_plan_bit_exact(oracle, dev, case, ranged):
     if case == "replay40":
         ii, jj, kk = S.replay_graph(40)
     elif case == "small":
@@ -96,7 +97,9 @@ def test_plan_bit_exact(oracle, dev, case):
     else:
         ii = jj = kk = torch.zeros(0, dtype=torch.long)
     E = ii.numel()
-    plan = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev))
+    # ranged: bounds on the index values -> 32-bit keys, partial-width radix sorts (dpvo_plan_build_ranged)
+    rng = dict(n_frames=4096, n_patch_ids=4096 * 96) if ranged else {}
+    plan = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), **rng)
     if E == 0:
         assert plan.n_patches() == 0 and plan.n_pairs() == 0
         return
