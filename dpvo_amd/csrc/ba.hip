@@ -149,12 +149,16 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
   for (int a = tid; a < 6 * kMaxDim; a += 256) (&rowS[0][0])[a] = 0.f;
   __syncthreads();
   const int2* pl = (ng <= kMaxPairsLds) ? plist : pg;   // (global fallback for very large graphs)
-  if (wave == 0) {
+  __shared__ float dpart[4][42];
+  {
+    // diagonal block + y: all 256 threads stride over the pairs, per-thread partial sums, fixed-order reduction
+    // (butterfly inside a wave, then waves 0..3 in order)
     float acc[42];
 #pragma unroll
     for (int a = 0; a < 42; ++a) acc[a] = 0.f;
-    for (int g = lane; g < ng; g += 64) {
+    for (int g = tid; g < ng; g += 256) {
       const int2 ij = pl[g];
+      if (ij.x != f && ij.y != f) continue;
       const float* pb = pairbuf + (int64_t)g * kPairStride;
       if (ij.x == f) {                                            // i-side: + w Ji Ji^T, v -= w r Ji
 #pragma unroll
@@ -182,10 +186,10 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
 #pragma unroll
     for (int a = 0; a < 42; ++a) {
       const float s = wave_sum(acc[a]);
-      if (lane == 0) { if (a < 36) rowS[a / 6][6 * p + a % 6] = s; else rowy[a - 36] = s; }
+      if (lane == 0) dpart[wave][a] = s;
     }
-  } else {
-    for (int ent = tid - 64; ent < (N - 1) * 36; ent += 192) {
+    // off-diagonal blocks (two binary searches in the LDS copy of the sorted pair list)
+    for (int ent = tid; ent < (N - 1) * 36; ent += 256) {
       int q = ent / 36; const int r = ent - q * 36;
       if (q >= p) q += 1;
       const int a = r / 6, b = r - a * 6;
@@ -196,6 +200,11 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
       if (g2 >= 0) s += -pairbuf[(int64_t)g2 * kPairStride + b * 16 + 6 + a];
       rowS[a][6 * q + b] = s;
     }
+  }
+  __syncthreads();
+  if (tid < 42) {
+    const float s = ((dpart[0][tid] + dpart[1][tid]) + dpart[2][tid]) + dpart[3][tid];
+    if (tid < 36) rowS[tid / 6][6 * p + tid % 6] = s; else rowy[tid - 36] = s;
   }
   __syncthreads();
   // Schur complement (ba_cuda.cu:557-558) + damping (:560): entries = 6 x n6 of S, then 6 of y; 4 lanes per entry, the
@@ -212,11 +221,20 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
     gent[it] = (e4 < 6 * n6) ? (6 * p + e4 / n6) * n6 + (e4 % n6) : n6 * n6 + 6 * p + (e4 - 6 * n6);
     if (e4 >= nrow) gent[it] = -1;
   }
-  for (int b = sub; b < n_spart; b += 4) {
-    const float* sp = spart + (int64_t)b * kSEntries;
+  // (four partial matrices per trip: their loads are independent and overlap; the adds keep the order b, b+4, ...)
+  for (int b0 = sub; b0 < n_spart; b0 += 16) {
+    float v[4][kIt];
 #pragma unroll
-    for (int it = 0; it < kIt; ++it)
-      if (gent[it] >= 0) sc[it] += sp[gent[it]];
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + 4 * u;
+      const float* sp = spart + (int64_t)(b < n_spart ? b : 0) * kSEntries;
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) v[u][it] = (b < n_spart && gent[it] >= 0) ? sp[gent[it]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) sc[it] += v[u][it];
   }
 #pragma unroll
   for (int it = 0; it < kIt; ++it) {
