@@ -29,8 +29,17 @@ _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # 
 
 class DPVO:
 
-    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda"):
+    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda", defer_keyframe=None):
+        """defer_keyframe: resolve the keyframe decision of frame t (its one host read-back, dpvo.py:266-310) at the
+        start of the call for frame t+1, after that frame's encoders have been enqueued, so that the GPU never waits
+        for the host.  Same operations in the same order; state read from outside between calls must go through
+        `flush()` first (terminate() does).  Default: env DPVO_DEFER_KEYFRAME, else off."""
         self.cfg = cfg
+        if defer_keyframe is None:
+            defer_keyframe = bool(int(__import__("os").environ.get("DPVO_DEFER_KEYFRAME", "0")))
+        self.defer_keyframe = bool(defer_keyframe)
+        self._kf_pending = None
+        self._mm_host = None
         self.device = torch.device(device)
         self.load_weights(network)
         self.is_initialized = False
@@ -186,6 +195,7 @@ class DPVO:
         return dP * self.get_pose(t0)
 
     def terminate(self):
+        self.flush()
         if self.cfg.LOOP_CLOSURE:
             self.append_factors(*self.pg.edges_loop())
 
@@ -308,16 +318,40 @@ class DPVO:
         flow, _ = pops.flow_mag(self.poses, self.patches, self.intrinsics, ii, jj, kk, beta=0.5)
         return flow.mean().item()
 
-    def keyframe(self):
+    def _keyframe_begin(self):
+        """enqueue the flow test of dpvo.py:266-269 and everything of the removal step that does not need its answer"""
         i = self.n - self.cfg.KEYFRAME_INDEX - 1
         j = self.n - self.cfg.KEYFRAME_INDEX + 1
-        # m = self.motionmag(i, j) + self.motionmag(j, i): one kernel + one read-back (was 2 x ~12 launches + 2 syncs)
+        # m = self.motionmag(i, j) + self.motionmag(j, i): one kernel + one read-back (was 2 x ~12 launches + 2 syncs);
+        # the read-back goes through pinned memory + an event, so waiting for it does not wait for later launches
+        if self._mm_host is None:
+            self._mm_host = [torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._mm_flip = 0
+        host = self._mm_host[self._mm_flip]
+        self._mm_flip ^= 1
         m_pending = pops.motionmag_pair(self.poses, self.patches, self.intrinsics, self.pg.ii, self.pg.jj, self.pg.kk,
-                                        i, j, beta=0.5, plan=self._plan, defer=True)
+                                        i, j, beta=0.5, plan=self._plan, defer=True, host_buf=host)
         # while the GPU is still busy with this frame: the removal mask of the common case (keyframe kept), on the host
         es = self.pg.edges
         to_remove = self._removal_mask(es.host())
         staged = self._stage_removal(to_remove, True)
+        return m_pending, to_remove, staged
+
+    def flush(self):
+        """apply a deferred keyframe decision (no-op otherwise)"""
+        if self._kf_pending is not None:
+            pending, self._kf_pending = self._kf_pending, None
+            self._keyframe_finish(*pending)
+
+    def keyframe(self):
+        pending = self._keyframe_begin()
+        if self.defer_keyframe:
+            self._kf_pending = pending
+        else:
+            self._keyframe_finish(*pending)
+
+    def _keyframe_finish(self, m_pending, to_remove, staged):
+        es = self.pg.edges
         m_ij, m_ji = m_pending()            # the one host read-back of the frame
         m = m_ij + m_ji
 
@@ -467,7 +501,15 @@ class DPVO:
             if self._imap_full is None:
                 self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
             self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
+            if self._kf_pending is not None:
+                # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
+                n_spec = self.n
+                self.flush()
+                if self.n != n_spec:            # that keyframe was dropped: the new frame lives one slot lower
+                    self._fmap1_cl[self.n % self.mem].copy_(slot)
+                    slot = self._fmap1_cl[self.n % self.mem]
             maps = (slot, self._imap_full)
+        self.flush()
 
         fast = maps is not None and self.P == 3 and (patch_coords is None or patch_coords.numel() == 2 * self.M)
         if fast:

@@ -83,7 +83,7 @@ def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta=0.3):
     return flow, val
 
 
-def motionmag_pair(poses, patches, intrinsics, ii, jj, kk, i, j, beta=0.5, plan=None, defer=False):
+def motionmag_pair(poses, patches, intrinsics, ii, jj, kk, i, j, beta=0.5, plan=None, defer=False, host_buf=None):
     """DPVO.motionmag(i,j) + DPVO.motionmag(j,i) (dpvo.py:257-264,269) as ONE kernel + ONE host read-back.
     Returns (mean flow i->j, mean flow j->i) as Python floats (NaN when a direction has no edge); with defer=True
     returns a callable that performs the read-back, so that the caller can do host work while the kernel runs."""
@@ -93,8 +93,18 @@ def motionmag_pair(poses, patches, intrinsics, ii, jj, kk, i, j, beta=0.5, plan=
     L.check(L.lib().dpvo_motionmag(L.ptr(pd), L.ptr(pt), L.ptr(it), L.ptr(ii), L.ptr(jj), L.ptr(kk),
                                    L.ptr(plan.buf if plan is not None and plan.E == E else None), L.i64(E), L.i32(P),
                                    L.i64(i), L.i64(j), L.f32(beta), L.ptr(out), L.stream()), "dpvo_motionmag")
+    ev = None
+    if host_buf is not None:            # pinned host buffer: asynchronous copy + event instead of a stream-wide sync
+        host_buf.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
     def finish():
-        s0, n0, s1, n1 = out.tolist()
+        if ev is not None:
+            ev.synchronize()
+            s0, n0, s1, n1 = host_buf.tolist()
+        else:
+            s0, n0, s1, n1 = out.tolist()
         nan = float("nan")
         return (s0 / n0 if n0 > 0 else nan), (s1 / n1 if n1 > 0 else nan)
     return finish if defer else finish()

@@ -15,13 +15,13 @@ from dpvo_amd.net import VONet
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, decisions, M=16, seed=0, ht=96, wd=128):
+def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True):
     from oracle.graph_ref import GraphRef
     cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
     cfg.PATCHES_PER_FRAME = M
     cfg.BUFFER_SIZE = 256
     torch.manual_seed(seed)
-    slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev)
+    slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev, defer_keyframe=defer)
     ref = GraphRef(M=M, PATCH_LIFETIME=cfg.PATCH_LIFETIME, REMOVAL_WINDOW=cfg.REMOVAL_WINDOW, BUFFER_SIZE=256)
     g = torch.Generator().manual_seed(seed)
     intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
@@ -31,7 +31,7 @@ def _run(dev, decisions, M=16, seed=0, ht=96, wd=128):
     thresh = cfg.KEYFRAME_THRESH
     calls = []
 
-    def fake(*a, defer=False, **k):
+    def fake(*a, defer=False, host_buf=None, **k):
         calls.append(orig(*a, **k))           # the real kernel still runs (and must not crash)
         res = (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
         return (lambda: res) if defer else res
@@ -42,6 +42,9 @@ def _run(dev, decisions, M=16, seed=0, ht=96, wd=128):
             img = torch.randint(0, 255, (3, ht, wd), generator=g, dtype=torch.uint8).to(dev)
             slam(float(t), img, intr)
             ev = ref.frame(accept, drop)
+            if not check:
+                continue
+            slam.flush()                          # (a deferred keyframe decision must be applied before state is read)
             assert slam.n == ref.n and slam.m == ref.m and slam.counter == ref.counter, (t, ev)
             assert np.array_equal(slam.pg.ii.cpu().numpy(), ref.ii), (t, ev)
             assert np.array_equal(slam.pg.jj.cpu().numpy(), ref.jj), (t, ev)
@@ -72,6 +75,22 @@ def test_bookkeeping_bit_exact_and_state_sane(dev):
     assert np.isfinite(poses).all()
     # every frame that was skipped / dropped is recoverable through pg.delta
     assert set(ref.delta.keys()) == set(int(k) for k in slam.pg.delta.keys())
+
+
+def test_deferred_keyframe_is_bit_identical(dev):
+    """defer_keyframe=True resolves each keyframe decision during the next frame's encoders: same state, bit for bit"""
+    decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 20 + [(True, True), (True, False), (True, True)] + \
+                [(True, False)] * 5
+    a, ra, _ = _run(dev, decisions, seed=5)
+    b, rb, _ = _run(dev, decisions, seed=5, defer=True, check=False)
+    b.flush()
+    assert a.n == b.n == ra.n and a.m == b.m
+    for k in ("ii", "jj", "kk"):
+        assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)) and np.array_equal(getattr(b.pg, k).cpu().numpy(), getattr(rb, k))
+    assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
+    assert torch.equal(a.pg.net, b.pg.net) and torch.equal(a._fmap1_cl, b._fmap1_cl) and torch.equal(a._gmap_cl, b._gmap_cl)
+    pa, _ = a.terminate(); pb, _ = b.terminate()
+    assert np.array_equal(pa, pb)
 
 
 def test_run_to_run_determinism(dev):
