@@ -17,6 +17,7 @@ namespace {
 
 constexpr int TH = 8, TW = 32;           // output tile (pixels)
 constexpr float kInEps = 1e-5f;          // nn.InstanceNorm2d default eps
+constexpr int kStatCopies = 16;          // accumulator copies per statistics set: spreads the same-address f64 atomics
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 
 struct EncPtrs {                         // one per encoder (z = 0 fnet, z = 1 inet)
@@ -34,14 +35,18 @@ struct EncArgs { EncPtrs e[2]; };
 
 __device__ __forceinline__ int swz4(int px) { return (0x78 >> (2 * ((px >> 2) & 3))) & 3; }   // 64 B pixels (Cin 32)
 
-// mean / rstd of the producer's channels from its f64 (sum, sum^2) accumulators.  Producers add one f64 atomic per
-// channel per workgroup (hardware global_atomic_add_f64); summation order effects are ~1e-16 relative, far below the
-// f32 statistics derived here.
+// mean / rstd of the producer's channels from its f64 (sum, sum^2) accumulators [kStatCopies][2][64].  Producers add one
+// f64 atomic per channel per workgroup (hardware global_atomic_add_f64) into copy blockIdx.x % kStatCopies -- a few
+// hundred workgroups hitting the same 128 addresses serialise in L2 otherwise; summation order effects are ~1e-16
+// relative, far below the f32 statistics derived here.
 template <int CIN>
 __device__ __forceinline__ void reduce_stats(const double* acc, int /*unused*/, float inv_n, float* s_mean, float* s_rstd) {
   for (int c = threadIdx.x; c < CIN; c += blockDim.x) {
-    const double mean = acc[c] * (double)inv_n;
-    const double var = acc[64 + c] * (double)inv_n - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kStatCopies; ++k) { s1 += acc[k * 128 + c]; s2 += acc[k * 128 + 64 + c]; }
+    const double mean = s1 * (double)inv_n;
+    const double var = s2 * (double)inv_n - mean * mean;
     s_mean[c] = (float)mean;
     s_rstd[c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)kInEps));
   }
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       if (c < 16 * NT && n0 + c < ncout) {
         const float v = ((s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c]) +
                          (s_red[(2 * 2 + which) * 64 + c] + s_red[(3 * 2 + which) * 64 + c]));
-        unsafeAtomicAdd(&P.out_part[which * 64 + n0 + c], (double)v);
+        unsafeAtomicAdd(&P.out_part[(blockIdx.x % kStatCopies) * 128 + which * 64 + n0 + c], (double)v);
       }
     }
   }
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
     __syncthreads();
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
-      unsafeAtomicAdd(&P.out_part[which * 64 + c],
+      unsafeAtomicAdd(&P.out_part[(blockIdx.x % kStatCopies) * 128 + which * 64 + c],
                       (double)((s_red[(0 * 2 + which) * 32 + c] + s_red[(1 * 2 + which) * 32 + c]) +
                                (s_red[(2 * 2 + which) * 32 + c] + s_red[(3 * 2 + which) * 32 + c])));
     }
@@ -357,7 +362,7 @@ extern "C" size_t dpvo_encoders_workspace_bytes(int H, int W) {
   const size_t h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4;
   const size_t a32 = enc_al(h2 * w2 * 32 * 2), a64 = enc_al(h4 * w4 * 64 * 2);
   const size_t t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW);
-  return 2 * (3 * a32 + 3 * a64) + enc_al(2 * 10 * 128 * 8) + 4096;
+  return 2 * (3 * a32 + 3 * a64) + enc_al((size_t)2 * 10 * kStatCopies * 128 * 8) + 4096;
 }
 
 // fmap_out [H/4][W/4][128], imap_out [H/4][W/4][384] f16 NHWC, both already divided by 4 (net.py:116-117).
@@ -379,12 +384,12 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
   // ten (sum, sum^2) accumulator sets per tower, one per statistics-producing conv, zeroed once per forward
   double* Sacc = (double*)base;
   {
-    hipError_t e = hipMemsetAsync(Sacc, 0, (size_t)2 * 10 * 128 * 8, st);
+    hipError_t e = hipMemsetAsync(Sacc, 0, (size_t)2 * 10 * kStatCopies * 128 * 8, st);
     if (e != hipSuccess) return (int)e;
   }
   double* Pt[2][10];
   for (int z = 0; z < 2; ++z)
-    for (int i = 0; i < 10; ++i) Pt[z][i] = Sacc + ((size_t)z * 10 + i) * 128;
+    for (int i = 0; i < 10; ++i) Pt[z][i] = Sacc + ((size_t)z * 10 + i) * kStatCopies * 128;
   auto Wp = [&](int z, int i) { return (const _Float16*)weights[z * 22 + i]; };
   const bool nm[2] = {true, false};                       // fnet: instance norm, inet: none (net.py:98-99)
   const int64_t np2 = (int64_t)h2 * w2, np4 = (int64_t)h4 * w4;
