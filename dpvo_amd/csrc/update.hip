@@ -333,12 +333,18 @@ __global__ __launch_bounds__(256) void linear_dma_kernel(const _Float16* __restr
 constexpr int WS_K = 384, WS_PITCH = 512;                    // halves per LDS row (1 KB)
 constexpr int WS_SROWS = 32;                                 // rows per stage: 2 m-tiles
 constexpr int WS_NBUF = 4;
-constexpr int WS_NT = 6;                                     // n-tiles (of 16 columns) per wave: 4 waves x 96 = 384
+// NT = n-tiles (of 16 columns) per wave.  NT = 6: a workgroup owns 384 columns (4 waves x 96).  NT = 3: 192 columns --
+// N = 384 then runs as TWO column groups that walk the same rows on the same XCD (the second read of an activation row
+// hits L2) and every CU pulls only half of W through L2 in its prologue.
 constexpr int WS_ROW_BYTES = WS_PITCH * 2;
 constexpr int WS_STAGE_BYTES = WS_SROWS * WS_ROW_BYTES;      // 32 KB
-constexpr int WS_EP_PITCH = 208;                             // bytes per scratch row: 96 halves + 16 B pad
-constexpr int WS_EP_BYTES = 32 * WS_EP_PITCH;                // per wave
-constexpr int WS_LDS_BYTES = WS_NBUF * WS_STAGE_BYTES + 4 * WS_EP_BYTES;
+template <int NT> struct WsGeom {
+  static constexpr int CPR = 2 * NT;                         // 16-byte chunks per scratch row (16 NT columns)
+  static constexpr int NCHT = NT;                            // chunks per lane of a 32-row stage tile (32 CPR / 64)
+  static constexpr int EP_PITCH = 32 * NT + 16;              // bytes per scratch row: 16 NT halves + 16 B pad
+  static constexpr int EP_BYTES = 32 * EP_PITCH;             // per wave
+  static constexpr int LDS_BYTES = WS_NBUF * WS_STAGE_BYTES + 4 * EP_BYTES;
+};
 
 __device__ uint4 g_ws_sink[64 * 4];                          // 64 B per lane: where the stores of rows >= M go
 
@@ -360,21 +366,23 @@ struct WsE2 {                  // registers of the deferred epilogue half
   uint32_t sabs[6], eoff[6];   // (plain-store kernel only) resident scratch addresses / output byte offsets of the 6 chunks
 };
 
-// Schedule constants.  Vector-memory instructions per stage body: 8 DMA rows + E2 (RMW: 12 + 6 loads, 12 + 6 stores).
-// E2 runs in G groups of NCH chunks: loads at k-step SL (before that step's DMA row), scratch read-back at SR, combine
-// and store at SC (after that step's DMA row).  The read-modify-write kernel splits it in two to halve its registers.
-template <bool RMW> struct WsCount {
-  static constexpr int E2_STORES = RMW ? 18 : 6;
-  static constexpr int BODY = 8 + (RMW ? 18 : 0) + E2_STORES;
-  static constexpr int G = RMW ? 2 : 1, NCH = 6 / G;
+// Schedule constants.  Vector-memory instructions per stage body: 8 DMA rows + E2 (RMW: 3 loads and 3 stores per chunk,
+// else 1 store per chunk).  E2 runs in G groups of NCH chunks: loads at k-step SL (before that step's DMA row), scratch
+// read-back at SR, combine and store at SC (after that step's DMA row).  The 96-column read-modify-write kernel splits
+// it in two to halve its registers.
+template <bool RMW, int NT> struct WsCount {
+  static constexpr int NCHT = WsGeom<NT>::NCHT;
+  static constexpr int E2_STORES = RMW ? 3 * NCHT : NCHT;
+  static constexpr int BODY = 8 + (RMW ? 3 * NCHT : 0) + E2_STORES;
+  static constexpr int G = (RMW && NT == 6) ? 2 : 1, NCH = NCHT / G;
   static constexpr int SL(int g) { return g == 0 ? 0 : 5; }
-  static constexpr int SR(int g) { return RMW ? (g == 0 ? 3 : 8) : 3; }
-  static constexpr int SC(int g) { return RMW ? (g == 0 ? 5 : 10) : 5; }
+  static constexpr int SR(int g) { return RMW ? (G == 2 ? (g == 0 ? 3 : 8) : 7) : 3; }
+  static constexpr int SC(int g) { return RMW ? (G == 2 ? (g == 0 ? 5 : 10) : 9) : 5; }
   // DMA rows (k-steps 0..7, one each) issued between the loads of group g and its combine step
-  static constexpr int VM_YOUNGER(int g) { return g == 0 ? 6 : 2; }
-  // younger than the last DMA row (k-step 7) of stage t when body t starts: what body t-3 still issued after it, and
-  // bodies t-2, t-1 in full.  vmcnt is a 6-bit counter: a smaller number only waits longer.
-  static constexpr int YOUNGER = 2 * BODY + (RMW ? 9 : 0);
+  static constexpr int VM_YOUNGER(int g) { return G == 2 ? (g == 0 ? 6 : 2) : 8; }
+  // younger than the last DMA row (k-step 7) of stage t when body t starts: what body t-3 still issued after it (the
+  // stores of the last RMW group), and bodies t-2, t-1 in full.  vmcnt is a 6-bit counter: a smaller number only waits longer.
+  static constexpr int YOUNGER = 2 * BODY + (RMW ? 3 * NCH : 0);
   static constexpr int WAIT = YOUNGER < 63 ? YOUNGER : 63;
   // LDS reads run RING - 1 k-steps ahead of their MFMAs.  The read-modify-write kernel has no registers left for more
   // than one step (12 MFMAs = 192 cycles of cover for an LDS read).
@@ -389,23 +397,24 @@ __device__ __forceinline__ void ws_read(h8 (&fa)[RING][2], const uint32_t (&aq)[
   WS_DSREAD(fa[T % RING][1], a, (T >> 2) * 256 + 16 * WS_ROW_BYTES);
 }
 
-// chunk i (of 6) of a 32 x 96 stage tile handled by this lane: 16 B = 8 columns, row-contiguous across lanes
+// chunk i (of NT) of a 32 x 16 NT stage tile handled by this lane: 16 B = 8 columns, row-contiguous across lanes
+template <int NT>
 __device__ __forceinline__ void ws_chunk(int lane, int i, int& row, int& col8) {
   const int c = lane + 64 * i;
-  row = (c * 171) >> 11;        // c / 12 for c < 1024
-  col8 = c - 12 * row;
+  row = c / WsGeom<NT>::CPR;
+  col8 = c - WsGeom<NT>::CPR * row;
 }
 
 // E2 / L: residual and gate rows of the pending stage (3 loads per chunk, always).  Issued by hand: the compiler's own
 // vmcnt bookkeeping gives up on the mix of LDS-DMA, loads and stores and waits for vmcnt(0), i.e. for the whole DMA pipeline.
 #define WS_GLOAD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
-template <int C0, int NCH>
+template <int NT, int C0, int NCH>
 __device__ __forceinline__ void ws_e2_load(WsE2& e, const WsOut& o, int64_t m0, int lane, const _Float16* zero) {
   asm volatile("" : "+v"(lane));      // (address arithmetic is recomputed where it is used, not hoisted and spilled)
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int row, col8;
-    ws_chunk(lane, C0 + i, row, col8);
+    ws_chunk<NT>(lane, C0 + i, row, col8);
     int64_t m = m0 + row;
     m = m < o.M ? m : o.M - 1;
     const int n = o.n_base + col8 * 8;
@@ -425,15 +434,15 @@ __device__ __forceinline__ void ws_e2_wait3(WsE2& e) {
                : "n"(YOUNGER));
 }
 // E2 / R: the stage tile back from the wave's scratch (NCH ds_read_b128, always)
-template <bool RMW, int C0, int NCH>
+template <bool RMW, int NT, int C0, int NCH>
 __device__ __forceinline__ void ws_e2_read(WsE2& e, uint32_t scratch, int lane) {
   if constexpr (RMW) {
     asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int row, col8;
-      ws_chunk(lane, C0 + i, row, col8);
-      WS_DSREAD(e.ep[i], scratch + row * WS_EP_PITCH + col8 * 16, 0);
+      ws_chunk<NT>(lane, C0 + i, row, col8);
+      WS_DSREAD(e.ep[i], scratch + row * WsGeom<NT>::EP_PITCH + col8 * 16, 0);
     }
   } else {
 #pragma unroll
@@ -449,25 +458,26 @@ __device__ __forceinline__ void ws_e2_tie(WsE2& e) {      // orders the uses of 
 }
 // E2 / C of the plain-store kernel inside the stage loop: whole stages only (the ragged last stage of the matrix is always
 // the last stage of its workgroup and goes through the general path after the loop); "no stage pending" stores to the sink
+template <int NT>
 __device__ __forceinline__ void ws_e2_store_fast(WsE2& e, const WsOut& o, int64_t m0, int lane) {
   const bool none = m0 >= o.M;
   char* sb = none ? reinterpret_cast<char*>(g_ws_sink)
                   : reinterpret_cast<char*>(reinterpret_cast<_Float16*>(o.out) + m0 * o.ldo + o.n_base);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < WsGeom<NT>::NCHT; ++i) {
     const uint32_t off = none ? (uint32_t)lane * 64u : e.eoff[i];
     *reinterpret_cast<h8*>(sb + off) = e.ep[i];
   }
 }
 // E2 / C: combine and store (1 or 3 stores per chunk, always; rows >= M go to the sink)
-template <bool RMW, int C0, int NCH>
+template <bool RMW, int NT, int C0, int NCH>
 __device__ __forceinline__ void ws_e2_store(WsE2& e, const WsOut& o, int64_t m0, int lane) {
   asm volatile("" : "+v"(lane));
   char* sink = reinterpret_cast<char*>(g_ws_sink) + lane * 64;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int row, col8;
-    ws_chunk(lane, C0 + i, row, col8);
+    ws_chunk<NT>(lane, C0 + i, row, col8);
     const int64_t m = m0 + row;
     const bool ok = m < o.M;
     const int n = o.n_base + col8 * 8;
@@ -495,24 +505,24 @@ __device__ __forceinline__ void ws_e2_store(WsE2& e, const WsOut& o, int64_t m0,
   }
 }
 // the whole E2 of a stage outside the pipeline (after the stage loop)
-template <bool RMW>
+template <bool RMW, int NT>
 __device__ __forceinline__ void ws_e2_flush(WsE2& e, const WsOut& o, int64_t m0, uint32_t scratch, int lane,
                                             const _Float16* zero) {
-  using C = WsCount<RMW>;
+  using C = WsCount<RMW, NT>;
 #pragma unroll
   for (int g = 0; g < C::G; ++g) {
     if (g == 0) {
-      if constexpr (RMW) ws_e2_load<0, C::NCH>(e, o, m0, lane, zero);
-      ws_e2_read<RMW, 0, C::NCH>(e, scratch, lane);
+      if constexpr (RMW) ws_e2_load<NT, 0, C::NCH>(e, o, m0, lane, zero);
+      ws_e2_read<RMW, NT, 0, C::NCH>(e, scratch, lane);
     } else {
-      if constexpr (RMW) ws_e2_load<C::NCH, C::NCH>(e, o, m0, lane, zero);
-      ws_e2_read<RMW, C::NCH, C::NCH>(e, scratch, lane);
+      if constexpr (RMW) ws_e2_load<NT, C::NCH, C::NCH>(e, o, m0, lane, zero);
+      ws_e2_read<RMW, NT, C::NCH, C::NCH>(e, scratch, lane);
     }
     asm volatile("s_waitcnt lgkmcnt(0)");
     ws_e2_tie<C::NCH>(e);
     if constexpr (RMW) ws_e2_wait3<0>(e);
-    if (g == 0) ws_e2_store<RMW, 0, C::NCH>(e, o, m0, lane);
-    else ws_e2_store<RMW, C::NCH, C::NCH>(e, o, m0, lane);
+    if (g == 0) ws_e2_store<RMW, NT, 0, C::NCH>(e, o, m0, lane);
+    else ws_e2_store<RMW, NT, C::NCH, C::NCH>(e, o, m0, lane);
   }
 }
 
@@ -529,12 +539,12 @@ __device__ __forceinline__ void ws_dma_row(const _Float16* base, int64_t ld, int
 }
 
 // E1: row mt*16 + m16 of the stage, columns j*16 + kg*4 .. +3 -> scratch.  ACT: 0 none, 1 relu, 2 sigmoid
-template <int ACT>
-__device__ __forceinline__ void ws_e1(const f4 (&acc)[2][WS_NT], uint32_t scratch, int m16, int kg) {
+template <int ACT, int NT>
+__device__ __forceinline__ void ws_e1(const f4 (&acc)[2][NT], uint32_t scratch, int m16, int kg) {
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int j = 0; j < WS_NT; ++j) {
+    for (int j = 0; j < NT; ++j) {
       h4 hv;
 #pragma unroll
       for (int q = 0; q < 4; ++q) hv[q] = (_Float16)acc[mt][j][q];
@@ -545,7 +555,7 @@ __device__ __forceinline__ void ws_e1(const f4 (&acc)[2][WS_NT], uint32_t scratc
 #pragma unroll
         for (int q = 0; q < 4; ++q) hv[q] = (_Float16)sigmoidf_((float)hv[q]);
       }
-      const uint32_t wa = scratch + (mt * 16 + m16) * WS_EP_PITCH + kg * 8;
+      const uint32_t wa = scratch + (mt * 16 + m16) * WsGeom<NT>::EP_PITCH + kg * 8;
       switch (j) {
         case 0: WS_DSWRITE8(wa, hv, 0); break;
         case 1: WS_DSWRITE8(wa, hv, 32); break;
@@ -562,19 +572,19 @@ struct WsDma {                 // next-stage DMA parameters (all wave-uniform)
 };
 
 // k-steps S .. 11 of one stage
-template <int S, bool RMW>
-__device__ __forceinline__ void ws_steps(f4 (&acc)[2][WS_NT], const h8 (&wreg)[WS_NT][12],
-                                         h8 (&fa)[WsCount<RMW>::RING][2],
+template <int S, bool RMW, int NT>
+__device__ __forceinline__ void ws_steps(f4 (&acc)[2][NT], const h8 (&wreg)[NT][12],
+                                         h8 (&fa)[WsCount<RMW, NT>::RING][2],
                                          const uint32_t (&aq)[4], uint32_t poff, WsE2& e2, const WsOut& o, int64_t pend_m0,
                                          uint32_t scratch, int lane, const WsDma& d) {
   if constexpr (S < 12) {
-    using C = WsCount<RMW>;
+    using C = WsCount<RMW, NT>;
     constexpr int RING = C::RING, D = RING - 1, NCH = C::NCH;
     constexpr int GL = (S == C::SL(0)) ? 0 : (C::G > 1 && S == C::SL(1)) ? 1 : -1;     // group whose loads go here
     constexpr int GR = (S == C::SR(0)) ? 0 : (C::G > 1 && S == C::SR(1)) ? 1 : -1;     // ... read-back
     constexpr int GC = (S == C::SC(0)) ? 0 : (C::G > 1 && S == C::SC(1)) ? 1 : -1;     // ... combine + store
-    if constexpr (RMW && GL == 0) ws_e2_load<0, NCH>(e2, o, pend_m0, lane, d.zero);
-    if constexpr (GR >= 0) ws_e2_read<RMW, (GR > 0 ? NCH : 0), NCH>(e2, scratch, lane);
+    if constexpr (RMW && GL == 0) ws_e2_load<NT, 0, NCH>(e2, o, pend_m0, lane, d.zero);
+    if constexpr (GR >= 0) ws_e2_read<RMW, NT, (GR > 0 ? NCH : 0), NCH>(e2, scratch, lane);
     if constexpr (S + D < 12) ws_read<S + D, RING>(fa, aq, poff);
     // LDS reads younger than those of step S: steps S+1 .. S+D (2 each) and the NCH scratch reads of a read-back issued
     // at one of the steps S-D+1 .. S (they sit in front of that step's own reads)
@@ -589,7 +599,7 @@ __device__ __forceinline__ void ws_steps(f4 (&acc)[2][WS_NT], const h8 (&wreg)[W
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int j = 0; j < WS_NT; ++j)
+      for (int j = 0; j < NT; ++j)
         acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[j][S], fa[S % RING][mt], acc[mt][j], 0, 0, 0);
 #ifndef WS_NO_DMA
     if constexpr (S < 8)       // stage t+3, row S of this wave's 8
@@ -604,18 +614,18 @@ __device__ __forceinline__ void ws_steps(f4 (&acc)[2][WS_NT], const h8 (&wreg)[W
       const int64_t m0s = ((int64_t)m0hi << 32) | (uint32_t)m0lo;
       if constexpr (RMW) {
         ws_e2_wait3<C::VM_YOUNGER(GC)>(e2);
-        ws_e2_store<true, (GC > 0 ? NCH : 0), NCH>(e2, o, m0s, lane);
+        ws_e2_store<true, NT, (GC > 0 ? NCH : 0), NCH>(e2, o, m0s, lane);
       } else {
-        ws_e2_store_fast(e2, o, m0s, lane);
+        ws_e2_store_fast<NT>(e2, o, m0s, lane);
       }
     }
-    if constexpr (RMW && GL == 1) ws_e2_load<NCH, NCH>(e2, o, pend_m0, lane, d.zero);
+    if constexpr (RMW && GL == 1) ws_e2_load<NT, NCH, NCH>(e2, o, pend_m0, lane, d.zero);
 #endif
-    ws_steps<S + 1, RMW>(acc, wreg, fa, aq, poff, e2, o, pend_m0, scratch, lane, d);
+    ws_steps<S + 1, RMW, NT>(acc, wreg, fa, aq, poff, e2, o, pend_m0, scratch, lane, d);
   }
 }
 
-template <bool RMW>
+template <bool RMW, int NT>
 __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restrict__ A, int64_t lda,
                                                         const int32_t* __restrict__ rows,
                                                         const _Float16* __restrict__ W, int64_t ldw,
@@ -624,26 +634,29 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, kg = lane >> 4;
-  o.n_base = blockIdx.y * 384 + wave * (16 * WS_NT);
+  constexpr int WGCOLS = 64 * NT;                           // output columns per workgroup
+  o.n_base = blockIdx.y * WGCOLS + wave * (16 * NT);
   const int n_base = o.n_base;
   const int64_t M = o.M;
   const int64_t nstages = (M + WS_SROWS - 1) / WS_SROWS;
   const int64_t gstep = gridDim.x;
   const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_row);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)ws_smem;
-  const uint32_t scratch = lds0 + WS_NBUF * WS_STAGE_BYTES + wave * WS_EP_BYTES;
+  const uint32_t scratch = lds0 + WS_NBUF * WS_STAGE_BYTES + wave * WsGeom<NT>::EP_BYTES;
   const uint32_t lane16 = (uint32_t)(lane < 48 ? lane : 47) << 4;
   WS_T(0);
 
-  // ---- L2 warm-up: the workgroup's 384 rows of W are 2304 cache lines, 9 per thread, fire and forget
-  unsigned sinkreg[9];                  // (allocated until the vmcnt(0) below: the loads land asynchronously)
+  // ---- L2 warm-up: the workgroup's 64 NT rows of W are 384 NT cache lines, fire and forget
+  constexpr int NWARM = (384 * NT + 255) / 256;
+  unsigned sinkreg[NWARM];              // (allocated until the first tile wait below: the loads land asynchronously)
   {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int line = tid + 256 * i;
+    for (int i = 0; i < NWARM; ++i) {
+      int line = tid + 256 * i;
+      line = line < 384 * NT ? line : 0;
       const int row = line / 6;
       const int part = line - 6 * row;
-      const _Float16* p = W + (int64_t)(blockIdx.y * 384 + row) * ldw + part * 64;
+      const _Float16* p = W + (int64_t)(blockIdx.y * WGCOLS + row) * ldw + part * 64;
       asm volatile("global_load_dword %0, %1, off" : "=v"(sinkreg[i]) : "v"(p));
       if (i == 0) WS_T(27);
     }
@@ -676,9 +689,9 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   int64_t st = blockIdx.x;
   // bias of this lane's accumulator columns n_base + 16 j + 4 kg .. +3 (by hand as well: these loads and the warm-up
   // are simply older than the first W tile in the in-order queue, the tile-0 wait below retires them)
-  h4 breg[WS_NT];
+  h4 breg[NT];
 #pragma unroll
-  for (int j = 0; j < WS_NT; ++j) {
+  for (int j = 0; j < NT; ++j) {
     const _Float16* bp = bias ? bias + n_base + j * 16 + kg * 4 : zero;
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(breg[j]) : "v"(bp));
   }
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   // ---- prologue: the wave's 96 columns x 384 k of W, tile by tile (16 rows) through its own 8-row slices of the stage
   // buffers: tile j -> rows 0..7 in buffer 2 (j & 1), rows 8..15 in buffer 2 (j & 1) + 1; two tiles in flight.  The slices
   // are private to the wave (it later fills the same ones with activation rows), so no barrier is needed.
-  h8 wreg[WS_NT][12];
+  h8 wreg[NT][12];
   const uint32_t slice = lds0 + wave * 8 * WS_ROW_BYTES;
   auto w_tile = [&](int j) {
 #pragma unroll
@@ -717,13 +730,22 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   w_tile(1);
   WS_T(31);
 #pragma unroll
-  for (int j = 0; j < WS_NT; ++j) {
-    if (j == 0)       // younger than tile j: exactly the 16 rows issued after it
-      asm volatile("s_waitcnt vmcnt(16)" : "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]), "+v"(breg[4]), "+v"(breg[5]),
-               "+v"(sinkreg[0]), "+v"(sinkreg[1]), "+v"(sinkreg[2]), "+v"(sinkreg[3]), "+v"(sinkreg[4]), "+v"(sinkreg[5]),
-               "+v"(sinkreg[6]), "+v"(sinkreg[7]), "+v"(sinkreg[8]) : : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  for (int j = 0; j < NT; ++j) {
+    // Issue order: T0, T1, X0, X1, ... where X_i (issued after tile i has been read out of its buffer pair) is tile i+2,
+    // or, once the tiles are exhausted, the activation stages that live in the freed pair (pair 0: stages 0 and 1 = 16
+    // rows, pair 1: stage 2 = 8 rows).  Younger than tile j when it is awaited: T1 for j = 0, else X_{j-1}.
+    {
+      const int i = j - 1;
+      const int younger = (j == 0 || i + 2 < NT || (i & 1) == 0) ? 16 : 8;
+      if (younger == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    if (j == 0) {     // the warm-up and bias loads are older than tile 0: retired by now
+#pragma unroll
+      for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(breg[i]));
+#pragma unroll
+      for (int i = 0; i < NWARM; ++i) asm volatile("" : "+v"(sinkreg[i]));
+    }
     WS_T(2 + j);
     const uint32_t wo = wq0 + (j & 1) * 2 * WS_STAGE_BYTES;
 #pragma unroll
@@ -742,9 +764,9 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
                    "+v"(wreg[j][6]), "+v"(wreg[j][7]), "+v"(wreg[j][8]), "+v"(wreg[j][9]), "+v"(wreg[j][10]), "+v"(wreg[j][11])
                  :
                  : "memory");
-    if (j + 2 < WS_NT) {
+    if (j + 2 < NT) {
       w_tile(j + 2);
-    } else if (j + 2 == WS_NT) {       // buffers 0, 1 are free: activation stages 0 and 1 (16 rows) follow tile 5
+    } else if ((j & 1) == 0) {         // buffers 0, 1 are free: activation stages 0 and 1
       a_stage(0, st);
       a_stage(1, st + gstep);
     } else {                           // buffers 2, 3: stage 2
@@ -759,10 +781,10 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   WsE2 e2;
   if constexpr (!RMW) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < WsGeom<NT>::NCHT; ++i) {
       int row, col8;
-      ws_chunk(lane, i, row, col8);
-      e2.sabs[i] = scratch + row * WS_EP_PITCH + col8 * 16;
+      ws_chunk<NT>(lane, i, row, col8);
+      e2.sabs[i] = scratch + row * WsGeom<NT>::EP_PITCH + col8 * 16;
       e2.eoff[i] = (uint32_t)((row * o.ldo + col8 * 8) * 2);
     }
   }
@@ -778,16 +800,16 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   for (; st < nstages; st += gstep, ++it) {
     // stage `it` has landed when at most WAIT younger instructions are outstanding.  The first two stages were issued by
     // the prologue with only 16 rows behind stage 0.
-    if (it < 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (WsCount<RMW>::WAIT == 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WsCount<RMW>::WAIT) : "memory");
+    // (NT even: stages were issued 0, 1, 2 -> 16 rows behind stage 0; NT odd: 2, 0, 1 -> 8 rows behind stage 0)
+    if (it < 2) { if constexpr ((NT & 1) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WsCount<RMW, NT>::WAIT) : "memory");
     __builtin_amdgcn_s_barrier();
     WS_T(9 + 3 * it);
     const int buf = it & 3;
     d.lds = slice + (uint32_t)((it + 3) & 3) * WS_STAGE_BYTES;
-    f4 acc[2][WS_NT];
+    f4 acc[2][NT];
 #pragma unroll
-    for (int j = 0; j < WS_NT; ++j) {
+    for (int j = 0; j < NT; ++j) {
       f4 b4;
 #pragma unroll
       for (int q = 0; q < 4; ++q) b4[q] = (float)breg[j][q];
@@ -795,18 +817,18 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
       acc[1][j] = b4;
     }
     const uint32_t poff = (uint32_t)buf * WS_STAGE_BYTES;
-    constexpr int RING = WsCount<RMW>::RING;
+    constexpr int RING = WsCount<RMW, NT>::RING;
     h8 fa[RING][2];
     ws_read<0, RING>(fa, aq, poff);
     if constexpr (RING > 2) ws_read<1, RING>(fa, aq, poff);
-    ws_steps<0, RMW>(acc, wreg, fa, aq, poff, e2, o, pend_m0, scratch, lane, d);
+    ws_steps<0, RMW, NT>(acc, wreg, fa, aq, poff, e2, o, pend_m0, scratch, lane, d);
     WS_T(10 + 3 * it);
     int32_t raw_next[8];
     stage_rows_raw(st + 4 * gstep, raw_next);      // scalar loads fly under E1
     // E1: activation (uniform per wave), one rounding to f16, transpose through the scratch
-    if (act == 1) ws_e1<1>(acc, scratch, m16, kg);
-    else if (act == 2) ws_e1<2>(acc, scratch, m16, kg);
-    else ws_e1<0>(acc, scratch, m16, kg);
+    if (act == 1) ws_e1<1, NT>(acc, scratch, m16, kg);
+    else if (act == 2) ws_e1<2, NT>(acc, scratch, m16, kg);
+    else ws_e1<0, NT>(acc, scratch, m16, kg);
     pend_m0 = st * WS_SROWS;
     stage_rows_wait(raw_next);
     stage_rows_fix(st + 4 * gstep, raw_next, d.row);
@@ -814,7 +836,7 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
   }
   // the last stage still owes its E2
   if (pend_m0 < M) {
-    ws_e2_flush<RMW>(e2, o, pend_m0, scratch, lane, zero);
+    ws_e2_flush<RMW, NT>(e2, o, pend_m0, scratch, lane, zero);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the speculative DMA of stages past the end targets our LDS
 }
@@ -971,22 +993,34 @@ extern "C" int dpvo_linear(const void* A, int a_dtype, int64_t lda, const int32_
              (epilogue != DPVO_EPI_RELU_SIG || (n_split % 96) == 0)) {
     static int n_cu = 0;
     if (n_cu == 0) {
-      int dev = 0; hipDeviceProp_t prop;
+      int dev = 0;
+      hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
       if (n_cu <= 0) n_cu = 256;
     }
-    const size_t sh = (size_t)WS_LDS_BYTES;                                       // 154 KB: one workgroup per CU
     const bool rmw = epilogue == DPVO_EPI_RESADD || epilogue == DPVO_EPI_GATED;
-    auto kern = rmw ? linear_ws_kernel<true> : linear_ws_kernel<false>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    const int ngrp = (N + 383) / 384;
+    // N = 384: two column groups of 192 (NT = 3) -- half the W prologue per CU, the twin's activation reads hit L2;
+    // N = 768: two groups of 384 (NT = 6)
+    const bool half = (N == 384) && epilogue != DPVO_EPI_RELU_SIG;
+    const int wgcols = half ? 192 : 384;
+    const int ngrp = N / wgcols;
     const int64_t nst = cdiv64(M, WS_SROWS);
     int gx = n_cu / ngrp;
     if (gx > nst) gx = (int)nst;
     if (gx < 1) gx = 1;
     WsOut wo{out, ldo, (const _Float16*)gate, ldg, (_Float16*)out16, ld16, epilogue, n_split, N, 0, M};
-    hipLaunchKernelGGL(kern, dim3(gx, ngrp), dim3(256), sh, (hipStream_t)stream, (const _Float16*)A, lda, rows,
-                       (const _Float16*)W, ldw, (const _Float16*)bias, wo);
+    auto launch = [&](auto kern, size_t sh) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipLaunchKernelGGL(kern, dim3(gx, ngrp), dim3(256), sh, (hipStream_t)stream, (const _Float16*)A, lda, rows,
+                         (const _Float16*)W, ldw, (const _Float16*)bias, wo);
+    };
+    if (half) {
+      if (rmw) launch(linear_ws_kernel<true, 3>, (size_t)WsGeom<3>::LDS_BYTES);
+      else launch(linear_ws_kernel<false, 3>, (size_t)WsGeom<3>::LDS_BYTES);
+    } else {
+      if (rmw) launch(linear_ws_kernel<true, 6>, (size_t)WsGeom<6>::LDS_BYTES);
+      else launch(linear_ws_kernel<false, 6>, (size_t)WsGeom<6>::LDS_BYTES);
+    }
   } else if (a_dtype == DPVO_F16) {
     hipLaunchKernelGGL(linear_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)A, lda, rows,
                        (const _Float16*)W, ldw, (const _Float16*)bias, out, ldo, (const _Float16*)gate, ldg,
