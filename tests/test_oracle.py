@@ -210,3 +210,34 @@ def test_update_ref_against_plain_torch_modules():
             x = x + gr.gate(x) * gr.res(x)
         d = upd.d(x); w = upd.w(x)
     assert torch.allclose(rn, x, atol=1e-9) and torch.allclose(rd, d, atol=1e-9) and torch.allclose(rw, w, atol=1e-9)
+
+
+def test_dpvo_ref_pipeline_runs_and_tracks_graph_ref():
+    """oracle/dpvo_ref.py (the end-to-end CPU pipeline used by tests/test_gpu_trajectory.py): integer state identical to
+    GraphRef under the same decisions, float state finite, unit quaternions, positive depths"""
+    import torch
+    from oracle.dpvo_ref import DPVORef
+    from oracle.graph_ref import GraphRef
+    from dpvo_amd.net import Update
+    torch.manual_seed(0)
+    sd = {k: v.detach().float() for k, v in Update(3).state_dict().items()}
+    M, ht, wd = 8, 64, 96
+    ref = DPVORef(sd, ht, wd, M=M, BUFFER_SIZE=64)
+    g2 = GraphRef(M=M, BUFFER_SIZE=64)
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((128, ht // 4 + 8, wd // 4 + 8)) / 4
+    ibase = rng.standard_normal((384, ht // 4 + 8, wd // 4 + 8)) / 4
+    decisions = [(True, False)] * 9 + [(True, True), (True, False)]
+    for t, (acc, drop) in enumerate(decisions):
+        dx = t % 8
+        fmap = base[:, dx:dx + ht // 4, dx:dx + wd // 4].astype(np.float16).astype(np.float64)
+        imap = ibase[:, dx:dx + ht // 4, dx:dx + wd // 4].astype(np.float16).astype(np.float64)
+        coords = np.stack([rng.integers(1, wd // 4 - 1, M), rng.integers(1, ht // 4 - 1, M)], -1).astype(np.float64)
+        ref.frame(float(t), fmap, imap, coords, rng.random(M), np.array([60.0, 60.0, wd / 2, ht / 2]), acc, drop)
+        g2.frame(acc, drop)
+        assert ref.g.n == g2.n and np.array_equal(ref.g.ii, g2.ii) and np.array_equal(ref.g.jj, g2.jj) and np.array_equal(ref.g.kk, g2.kk)
+        assert ref.net.shape == (g2.ii.size, 384)
+    n = ref.n
+    assert np.isfinite(ref.poses[:n]).all() and np.isfinite(ref.patches[:n]).all()
+    assert np.abs(np.linalg.norm(ref.poses[:n, 3:], axis=-1) - 1).max() < 1e-4
+    assert (ref.patches[:n, :, 2] > 0).all()
