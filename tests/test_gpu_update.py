@@ -18,7 +18,10 @@ def _h64(x):
 
 
 @pytest.mark.parametrize("M,Nn,K,adt", [(300, 384, 384, torch.float16), (129, 768, 384, torch.float32),
-                                        (1000, 384, 896, torch.float16), (5, 16, 32, torch.float32)])
+                                        (1000, 384, 896, torch.float16), (5, 16, 32, torch.float32),
+                                        # weights-stationary kernel (M >= 4096, K = 384): ragged M, both column-group widths
+                                        (4131, 384, 384, torch.float16), (4200, 768, 384, torch.float16),
+                                        (9001, 384, 384, torch.float16)])
 def test_linear_epilogues(dev, M, Nn, K, adt):
     g = torch.Generator().manual_seed(0)
     A = torch.randn(M, K, generator=g).to(adt)
@@ -38,8 +41,11 @@ def test_linear_epilogues(dev, M, Nn, K, adt):
         H.assert_close(out.cpu().double().numpy(), r2.numpy(), 2e-3, 2e-3, "linear relu|sigmoid")
     res = torch.randn(M, Nn, generator=g)
     resd = res.clone().to(dev)
-    N.linear(Ad, Wd, bd, out=resd, epilogue=N.EPI_RESADD)
+    o16 = torch.zeros(M, Nn, dtype=torch.float16, device=dev) if adt == torch.float16 else None   # (f16-A kernels only)
+    N.linear(Ad, Wd, bd, out=resd, epilogue=N.EPI_RESADD, out16=o16)
     H.assert_close(resd.cpu().double().numpy(), (res.double() + ref).numpy(), 3e-3, 2e-3, "linear resadd")
+    if o16 is not None:
+        assert torch.equal(o16, resd.half()), "f16 image of the residual stream"
     gate = torch.rand(M, Nn, generator=g).half()
     resd = res.clone().to(dev)
     N.linear(Ad, Wd, bd, out=resd, epilogue=N.EPI_GATED, gate=gate.to(dev))
