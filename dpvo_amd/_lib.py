@@ -23,7 +23,7 @@ SYMBOLS = [
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
-    "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads",
+    "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges",

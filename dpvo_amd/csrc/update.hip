@@ -945,7 +945,8 @@ __global__ void gather_add_kernel(float* __restrict__ net, const _Float16* __res
 __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ net, const _Float16* __restrict__ Wd,
                                                     const _Float16* __restrict__ bd, const _Float16* __restrict__ Ww,
                                                     const _Float16* __restrict__ bw, float* __restrict__ delta,
-                                                    float* __restrict__ weight, int64_t E) {
+                                                    float* __restrict__ weight, const float* __restrict__ coords,
+                                                    int pp, float* __restrict__ target, int64_t E) {
   constexpr int D = 384;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -967,6 +968,10 @@ __global__ __launch_bounds__(256) void heads_kernel(const float* __restrict__ ne
     const _Float16 h0 = (_Float16)(w0 + (float)bw[0]), h1 = (_Float16)(w1 + (float)bw[1]);
     weight[2 * row + 0] = (float)(_Float16)sigmoidf_((float)h0);
     weight[2 * row + 1] = (float)(_Float16)sigmoidf_((float)h1);
+    if (target) {     // target = coords[..., P//2, P//2] + delta.float()   (dpvo.py:340)
+      target[2 * row + 0] = coords[(row * 2 + 0) * pp + pp / 2] + delta[2 * row + 0];
+      target[2 * row + 1] = coords[(row * 2 + 1) * pp + pp / 2] + delta[2 * row + 1];
+    }
   }
 }
 
@@ -1078,14 +1083,22 @@ extern "C" int dpvo_gather_add(float* net, const void* hy, const int32_t* group,
   return DPVO_OK;
 }
 
-extern "C" int dpvo_heads(const float* net, const void* Wd, const void* bd, const void* Ww, const void* bw, float* delta,
-                          float* weight, int64_t E, int D, void* stream) {
+extern "C" int dpvo_heads_target(const float* net, const void* Wd, const void* bd, const void* Ww, const void* bw,
+                                 const float* coords, int P, float* delta, float* weight, float* target, int64_t E, int D,
+                                 void* stream) {
   if (E < 0) return DPVO_E_INVALID;
   if (E == 0) return DPVO_OK;
   if (D != 384) return DPVO_E_UNSUPPORTED;
   if (!net || !Wd || !bd || !Ww || !bw || !delta || !weight) return DPVO_E_INVALID;
+  if (target && (!coords || P <= 0)) return DPVO_E_INVALID;
   hipLaunchKernelGGL(heads_kernel, dim3((unsigned)cdiv64(E, 4)), dim3(256), 0, (hipStream_t)stream, net,
-                     (const _Float16*)Wd, (const _Float16*)bd, (const _Float16*)Ww, (const _Float16*)bw, delta, weight, E);
+                     (const _Float16*)Wd, (const _Float16*)bd, (const _Float16*)Ww, (const _Float16*)bw, delta, weight, coords,
+                     P * P, target, E);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
+}
+
+extern "C" int dpvo_heads(const float* net, const void* Wd, const void* bd, const void* Ww, const void* bw, float* delta,
+                          float* weight, int64_t E, int D, void* stream) {
+  return dpvo_heads_target(net, Wd, bd, Ww, bw, nullptr, 0, delta, weight, nullptr, E, D, stream);
 }

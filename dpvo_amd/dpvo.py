@@ -434,16 +434,16 @@ class DPVO:
             coords = self.reproject()
             corr = self.corr(coords)
             netbuf = self.pg.edges.view("net")          # updated in place (the reference reassigns pg.net)
-            _, (delta, weight, _) = self.network.update(
+            # target = coords[..., P//2, P//2] + delta.float(); pg.target / pg.weight = ...  (dpvo.py:339-343): written by
+            # the heads kernel straight into the edge store
+            es = self.pg.edges
+            target, weight = es.view("target"), es.view("weight")
+            self.network.update(
                 netbuf[None], self.imap, corr, None, self.pg.ii, self.pg.jj, self.pg.kk, plan=plan,
-                inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896), out=netbuf)
-
+                inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896), out=netbuf,
+                coords=coords.contiguous(), target_out=target, weight_out=weight)
             lmbda = 1e-4
-            weight = weight.float()
-            target = coords[..., self.P // 2, self.P // 2] + delta.float()
-
-        self.pg.target = target
-        self.pg.weight = weight
+            target, weight = target[None], weight[None]
 
         with Timer("BA", enabled=self.enable_timing):
             try:

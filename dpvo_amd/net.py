@@ -61,12 +61,20 @@ def gather_add(net, hy, group, net16=None):
                                     L.stream()), "dpvo_gather_add")
 
 
-def heads(net, Wd, bd, Ww, bw):
+def heads(net, Wd, bd, Ww, bw, coords=None, target_out=None, weight_out=None):
+    """delta, weight (net.py:92); with `coords` [.,E,2,P,P] also target = coords[..., P//2, P//2] + delta (dpvo.py:340)
+    written to `target_out` [E,2]; `weight_out` [E,2] receives the weights in place"""
     E = net.shape[0]
     delta = torch.empty(E, 2, dtype=torch.float32, device=net.device)
-    weight = torch.empty(E, 2, dtype=torch.float32, device=net.device)
-    L.check(L.lib().dpvo_heads(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight),
-                               L.i64(E), L.i32(DIM), L.stream()), "dpvo_heads")
+    weight = weight_out if weight_out is not None else torch.empty(E, 2, dtype=torch.float32, device=net.device)
+    if coords is not None:
+        assert coords.is_contiguous() and coords.dtype == torch.float32 and target_out is not None
+        L.check(L.lib().dpvo_heads_target(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(coords),
+                                          L.i32(coords.shape[-1]), L.ptr(delta), L.ptr(weight), L.ptr(target_out), L.i64(E),
+                                          L.i32(DIM), L.stream()), "dpvo_heads_target")
+    else:
+        L.check(L.lib().dpvo_heads(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight),
+                                   L.i64(E), L.i32(DIM), L.stream()), "dpvo_heads")
     return delta, weight
 
 
@@ -155,10 +163,12 @@ class Update(nn.Module):
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
-                out=None):
+                out=None, coords=None, target_out=None, weight_out=None):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
         `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
+        `coords` [1,E,2,P,P] + `target_out` / `weight_out` [E,2] f32 (optional): the heads kernel also writes
+        target = coords[..., P//2, P//2] + delta (dpvo.py:340) and the weights straight into the caller's edge arrays.
         Returns net f32 [1,E,384], (delta f32 [1,E,2], weight f32 [1,E,2], None)."""
         P = self._packed or self.pack()
         L.require_cuda(net, inp, corr, ii, jj, kk)
@@ -222,7 +232,8 @@ class Update(nn.Module):
             linear(h1, Wrg, brg, out=fg, epilogue=EPI_RELU_SIG, n_split=DIM)
             linear(fg[:, :DIM], W2, b2, out=x, epilogue=EPI_GATED, gate=fg[:, DIM:])
 
-        delta, weight = heads(x, P["d"][0], P["d"][1], P["w"][0], P["w"][1])                   # net.py:92
+        delta, weight = heads(x, P["d"][0], P["d"][1], P["w"][0], P["w"][1], coords=coords,    # net.py:92
+                              target_out=target_out, weight_out=weight_out)
         return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
 
 

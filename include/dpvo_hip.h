@@ -209,6 +209,9 @@ int dpvo_gather_add(float* net, const void* hy, const int32_t* group, void* net1
  * Wd,Ww [2,D] f16, bd,bw [2] f16; outputs f32 [E,2] (the .float() of dpvo.py:339-340 folded in). */
 int dpvo_heads(const float* net, const void* Wd, const void* bd, const void* Ww, const void* bw, float* delta,
                float* weight, int64_t E, int D, void* stream);
+/* Same, and additionally target = coords[:, :, P/2, P/2] + delta (dpvo/dpvo.py:340; coords [E,2,P,P] f32, target [E,2]). */
+int dpvo_heads_target(const float* net, const void* Wd, const void* bd, const void* Ww, const void* bw, const float* coords,
+                      int P, float* delta, float* weight, float* target, int64_t E, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fastba  (replaces cuda_ba.forward: dpvo/fastba/ba.cpp:32-45,184 -> cuda_ba, ba_cuda.cu:433-582)
