@@ -460,8 +460,8 @@ class DPVO:
             except Exception as e:      # the reference swallows everything with a bare except (dpvo.py:355-356)
                 print("Warning BA failed...", repr(e))
 
-            points = pops.point_cloud(self.poses, self.patches[:, :self.m], self.intrinsics, self.ix[:self.m])
-            self.pg.points_[:len(points)] = points[:]
+            # points = pops.point_cloud(...); self.pg.points_[:len(points)] = points[:]  (dpvo.py:358-360), in place
+            pops.point_cloud(self.poses, self.patches[:, :self.m], self.intrinsics, self.ix[:self.m], out=self.pg.points_)
 
     def _edges_forw(self):
         r = self.cfg.PATCH_LIFETIME

@@ -60,12 +60,17 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     return transform_coords(poses, patches, intrinsics, ii, jj, kk).permute(0, 1, 3, 4, 2)
 
 
-def point_cloud(poses, patches, intrinsics, ix):
-    """Centre-pixel 3-D points X/W, i.e. exactly what dpvo.py:358-360 keeps of pops.point_cloud: [m,3]."""
+def point_cloud(poses, patches, intrinsics, ix, out=None):
+    """Centre-pixel 3-D points X/W, i.e. exactly what dpvo.py:358-360 keeps of pops.point_cloud: [m,3].
+    `out`: optional contiguous f32 [>=m,3] buffer to write into (its first m rows are returned)."""
     pd, pt, it, P = _prep(poses, patches, intrinsics)
     m = ix.numel()
     assert pt.shape[0] >= m
-    points = torch.empty(m, 3, dtype=torch.float32, device=pd.device)
+    if out is not None:
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] >= m and out.shape[1] == 3
+        points = out[:m]
+    else:
+        points = torch.empty(m, 3, dtype=torch.float32, device=pd.device)
     L.check(L.lib().dpvo_point_cloud(L.ptr(pd), L.ptr(pt), L.ptr(it), L.ptr(ix.long().contiguous()), L.ptr(points),
                                      L.i64(m), L.i32(P), L.stream()), "dpvo_point_cloud")
     return points
