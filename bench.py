@@ -139,7 +139,8 @@ def main():
     ht, wd = 480, 640
     torch.manual_seed(1234 + rank)
     net = VONet()
-    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, defer_keyframe=True)   # decision of frame t resolved under frame t+1's encoders
+    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, defer_keyframe=True,      # decision of frame t resolved under frame t+1's encoders
+                overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "1"))))   # ... on a second HIP stream
     slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
     total = args.warmup + args.steps
     assert total + 2 < cfg.BUFFER_SIZE

@@ -29,7 +29,7 @@ _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # 
 
 class DPVO:
 
-    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda", defer_keyframe=None):
+    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda", defer_keyframe=None, overlap_encoders=False):
         """defer_keyframe: resolve the keyframe decision of frame t (its one host read-back, dpvo.py:266-310) at the
         start of the call for frame t+1, after that frame's encoders have been enqueued, so that the GPU never waits
         for the host.  Same operations in the same order; state read from outside between calls must go through
@@ -38,6 +38,13 @@ class DPVO:
         if defer_keyframe is None:
             defer_keyframe = bool(int(__import__("os").environ.get("DPVO_DEFER_KEYFRAME", "0")))
         self.defer_keyframe = bool(defer_keyframe)
+        # overlap_encoders: run the next frame's image normalisation + encoders on a second HIP stream, so that they fill
+        # the gaps of the previous frame's update / BA kernels (only useful together with defer_keyframe, which lets the
+        # host get that far ahead).  The caller's image must be complete when __call__ is entered (it is read on the side
+        # stream without waiting for earlier work of the current stream).
+        self.overlap_encoders = bool(overlap_encoders)
+        self._enc_stream = None
+        self._fp_done = None
         self._kf_pending = None
         self._mm_host = None
         self.device = torch.device(device)
@@ -488,26 +495,39 @@ class DPVO:
         # image = 2 * (image[None,None] / 255.0) - 0.5, plus the f16 copy the encoders eat: one kernel
         image_u8 = image.contiguous()
         H, W = image_u8.shape[-2:]
-        img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
-        img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
-        L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),
-                                             L.stream()), "dpvo_normalize_image")
-
-        maps = None
-        if self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM':
-            # both encoders as 15 MFMA launches, fmap written straight into its channels-last ring slot
-            # (the reference also writes fmap1_[n % mem] before the motion probe may reject the frame, dpvo.py:437)
-            slot = self._fmap1_cl[self.n % self.mem]
-            if self._imap_full is None:
-                self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
-            self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
-            if self._kf_pending is not None:
-                # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
-                n_spec = self.n
-                self.flush()
-                if self.n != n_spec:            # that keyframe was dropped: the new frame lives one slot lower
-                    self._fmap1_cl[self.n % self.mem].copy_(slot)
-                    slot = self._fmap1_cl[self.n % self.mem]
+        hip_enc = self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM'
+        side = None
+        if hip_enc and self.overlap_encoders:
+            if self._enc_stream is None:
+                self._enc_stream = torch.cuda.Stream(device=self.device)
+            side = self._enc_stream
+            if self._fp_done is not None:       # the previous frame's readers of _imap_full / the encoder workspace
+                side.wait_event(self._fp_done)
+        main_stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(side if side is not None else main_stream):
+            img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
+            img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
+            L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),
+                                                 L.stream()), "dpvo_normalize_image")
+            maps = None
+            if hip_enc:
+                # both encoders as 15 MFMA launches, fmap written straight into its channels-last ring slot
+                # (the reference also writes fmap1_[n % mem] before the motion probe may reject the frame, dpvo.py:437)
+                slot = self._fmap1_cl[self.n % self.mem]
+                if self._imap_full is None:
+                    self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
+                self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
+                if side is not None:
+                    enc_done = torch.cuda.Event()
+                    enc_done.record(side)
+        if hip_enc:
+            n_spec = self.n
+            self.flush()                        # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
+            if side is not None:
+                main_stream.wait_event(enc_done)
+            if self.n != n_spec:                # that keyframe was dropped: the new frame lives one slot lower
+                self._fmap1_cl[self.n % self.mem].copy_(slot)
+                slot = self._fmap1_cl[self.n % self.mem]
             maps = (slot, self._imap_full)
         self.flush()
 
@@ -556,6 +576,9 @@ class DPVO:
                     self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
             L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(hh), L.i32(ww),
                                             L.i32(128), L.stream()), "dpvo_pool4_nhwc")
+            if self.overlap_encoders:
+                self._fp_done = torch.cuda.Event()
+                self._fp_done.record()
         else:
             fmap, gmap, imap, patches, _, coords = \
                 self.network.patchify(img32 if img32 is not None else img16,

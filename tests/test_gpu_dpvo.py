@@ -15,13 +15,13 @@ from dpvo_amd.net import VONet
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True):
+def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, overlap=False):
     from oracle.graph_ref import GraphRef
     cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
     cfg.PATCHES_PER_FRAME = M
     cfg.BUFFER_SIZE = 256
     torch.manual_seed(seed)
-    slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev, defer_keyframe=defer)
+    slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev, defer_keyframe=defer, overlap_encoders=overlap)
     ref = GraphRef(M=M, PATCH_LIFETIME=cfg.PATCH_LIFETIME, REMOVAL_WINDOW=cfg.REMOVAL_WINDOW, BUFFER_SIZE=256)
     g = torch.Generator().manual_seed(seed)
     intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
@@ -84,6 +84,11 @@ def test_deferred_keyframe_is_bit_identical(dev):
     a, ra, _ = _run(dev, decisions, seed=5)
     b, rb, _ = _run(dev, decisions, seed=5, defer=True, check=False)
     b.flush()
+    c, _, _ = _run(dev, decisions, seed=5, defer=True, check=False, overlap=True)     # + encoders on a second stream
+    c.flush()
+    torch.cuda.synchronize()
+    assert c.n == a.n and torch.equal(a.pg.poses_[:a.n], c.pg.poses_[:c.n]) and torch.equal(a.pg.patches_[:a.n], c.pg.patches_[:c.n])
+    assert torch.equal(a.pg.net, c.pg.net) and torch.equal(a._fmap1_cl, c._fmap1_cl) and torch.equal(a._fmap2_cl, c._fmap2_cl)
     assert a.n == b.n == ra.n and a.m == b.m
     for k in ("ii", "jj", "kk"):
         assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)) and np.array_equal(getattr(b.pg, k).cpu().numpy(), getattr(rb, k))
