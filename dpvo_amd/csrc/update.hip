@@ -1102,3 +1102,101 @@ extern "C" int dpvo_heads(const float* net, const void* Wd, const void* bd, cons
                           float* weight, int64_t E, int D, void* stream) {
   return dpvo_heads_target(net, Wd, bd, Ww, bw, nullptr, 0, delta, weight, nullptr, E, D, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The whole update operator (net.py:74-92) as ONE C-ABI call: the same 31 launches the host wrapper would issue one by
+// one through ctypes.  At > 500 frames/sec the Python side of those launches (~0.5 ms per frame) is what bounds the
+// frame rate, not the kernels.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+inline size_t upd_al(size_t x) { return (x + 255) & ~(size_t)255; }
+struct UpdWs { size_t h1, h2, x16, fg, y, hy, total; };
+inline void upd_ws_layout(int64_t E, int64_t maxg, UpdWs* w) {
+  const size_t e = (size_t)(E > 0 ? E : 1), g = (size_t)(maxg > 0 ? maxg : 1);
+  size_t o = 0;
+  w->h1 = o; o += upd_al(e * 384 * 2);
+  w->h2 = o; o += upd_al(e * 384 * 2);
+  w->x16 = o; o += upd_al(e * 384 * 2);
+  w->fg = o; o += upd_al(e * 768 * 2);
+  w->y = o; o += upd_al(g * 384 * 2);
+  w->hy = o; o += upd_al(g * 384 * 2);
+  w->total = o;
+}
+}  // namespace
+
+extern "C" size_t dpvo_update_workspace_bytes(int64_t E, int64_t max_groups) {
+  if (E < 0 || max_groups < 0) return 0;
+  UpdWs w;
+  upd_ws_layout(E, max_groups, &w);
+  return w.total;
+}
+
+extern "C" int dpvo_update_forward(const dpvo_update_params_t* p, const float* net, const void* inp, const int64_t* inp_rows,
+                                   int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan,
+                                   int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
+                                   float* delta, float* weight, float* target, int64_t E, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (E < 0 || !p) return DPVO_E_INVALID;
+  if (E == 0) return DPVO_OK;
+  if (!net || !inp || !corr || !plan || !net_out || !delta || !weight || !ws) return DPVO_E_INVALID;
+  if (ld_corr < 896 || (ld_corr % 8)) return DPVO_E_UNSUPPORTED;
+  const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
+  UpdWs L;
+  upd_ws_layout(E, maxg, &L);
+  if (ws_bytes < L.total) return DPVO_E_WORKSPACE;
+  dpvo_plan_layout_t PL;
+  dpvo_plan_layout(E, &PL);
+  char* w = (char*)ws;
+  void *h1 = w + L.h1, *h2 = w + L.h2, *x16 = w + L.x16, *fg = w + L.fg, *y = w + L.y, *hy = w + L.hy;
+  float* x = net_out;
+  int rc;
+#define UPD(call) do { rc = (call); if (rc) return rc; } while (0)
+  // net = net + inp + self.corr(corr); net = self.norm(net)                                  (net.py:77-78)
+  UPD(dpvo_linear(corr, DPVO_F16, ld_corr, nullptr, p->c0_w, 896, p->c0_b, h1, 384, nullptr, 0, nullptr, 0, DPVO_EPI_RELU, 0, E,
+                  384, 896, stream));
+  UPD(dpvo_linear(h1, DPVO_F16, 384, nullptr, p->c2_w, 384, p->c2_b, h2, 384, nullptr, 0, nullptr, 0, DPVO_EPI_NONE, 0, E, 384,
+                  384, stream));
+  UPD(dpvo_layernorm(h2, DPVO_F16, nullptr, nullptr, 0, nullptr, p->cln_g, p->cln_b, 1e-3f, nullptr, h1, 1, E, 384, stream));
+  UPD(dpvo_linear(h1, DPVO_F16, 384, nullptr, p->c5_w, 384, p->c5_b, h2, 384, nullptr, 0, nullptr, 0, DPVO_EPI_NONE, 0, E, 384,
+                  384, stream));
+  UPD(dpvo_layernorm(net, DPVO_F32, inp, inp_rows, inp_mod, h2, p->norm_g, p->norm_b, 1e-3f, x, x16, 0, E, 384, stream));
+  // net = net + c1(mask_ix * net[:,ix]); net = net + c2(mask_jx * net[:,jx])                  (net.py:80-85)
+  for (int k = 0; k < 2; ++k) {
+    const void *W0 = k ? p->c2n_w0 : p->c1_w0, *b0 = k ? p->c2n_b0 : p->c1_b0, *W2 = k ? p->c2n_w2 : p->c1_w2,
+               *b2 = k ? p->c2n_b2 : p->c1_b2;
+    const int32_t* rows = plan + (k ? PL.jx : PL.ix);
+    UPD(dpvo_linear(x16, DPVO_F16, 384, rows, W0, 384, b0, h1, 384, nullptr, 0, nullptr, 0, DPVO_EPI_RELU, 0, E, 384, 384, stream));
+    UPD(dpvo_linear(h1, DPVO_F16, 384, nullptr, W2, 384, b2, x, 384, nullptr, 0, x16, 384, DPVO_EPI_RESADD, 0, E, 384, 384, stream));
+  }
+  // net = net + agg_kk(net, kk); net = net + agg_ij(net, ii*12345 + jj)                        (net.py:87-88)
+  for (int k = 0; k < 2; ++k) {
+    const void *Wfg = k ? p->aij_wfg : p->akk_wfg, *bfg = k ? p->aij_bfg : p->akk_bfg, *Wh = k ? p->aij_wh : p->akk_wh,
+               *bh = k ? p->aij_bh : p->akk_bh;
+    const int32_t* perm = plan + (k ? PL.perm_p : PL.perm_k);
+    const int32_t* off = plan + (k ? PL.pair_off : PL.patch_off);
+    const int32_t* cnt = plan + PL.counts + k;
+    const int32_t* grp = plan + (k ? PL.pu : PL.ku);
+    int64_t ng = k ? n_pairs_ub : n_patches_ub;
+    if (ng < 1) ng = 1;
+    if (ng > E) ng = E;
+    UPD(dpvo_linear(x16, DPVO_F16, 384, nullptr, Wfg, 384, bfg, fg, 768, nullptr, 0, nullptr, 0, DPVO_EPI_NONE, 0, E, 768, 384, stream));
+    UPD(dpvo_softagg(fg, 768, perm, off, cnt, ng, y, 384, stream));
+    UPD(dpvo_linear(y, DPVO_F16, 384, nullptr, Wh, 384, bh, hy, 384, nullptr, 0, nullptr, 0, DPVO_EPI_NONE, 0, ng, 384, 384, stream));
+    UPD(dpvo_gather_add(x, hy, grp, k == 0 ? x16 : nullptr, E, 384, stream));
+  }
+  // net = self.gru(net): 2 x (LayerNorm, x + gate(x) * res(x))                                (net.py:90)
+  for (int k = 0; k < 2; ++k) {
+    const float *g = k ? p->g1_g : p->g0_g, *b = k ? p->g1_b : p->g0_b;
+    const void *Wrg = k ? p->g1_wrg : p->g0_wrg, *brg = k ? p->g1_brg : p->g0_brg, *W2 = k ? p->g1_w2 : p->g0_w2,
+               *b2 = k ? p->g1_b2 : p->g0_b2;
+    UPD(dpvo_layernorm(x, DPVO_F32, nullptr, nullptr, 0, nullptr, g, b, 1e-3f, x, h1, 0, E, 384, stream));
+    UPD(dpvo_linear(h1, DPVO_F16, 384, nullptr, Wrg, 384, brg, fg, 768, nullptr, 0, nullptr, 0, DPVO_EPI_RELU_SIG, 384, E, 768, 384,
+                    stream));
+    UPD(dpvo_linear(fg, DPVO_F16, 768, nullptr, W2, 384, b2, x, 384, (const _Float16*)fg + 384, 768, nullptr, 0, DPVO_EPI_GATED, 0, E,
+                    384, 384, stream));
+  }
+  UPD(dpvo_heads_target(x, p->d_w, p->d_b, p->w_w, p->w_b, target ? coords : nullptr, P, delta, weight, target, E, 384, stream));
+#undef UPD
+  return DPVO_OK;
+}
+

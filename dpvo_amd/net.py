@@ -5,11 +5,14 @@ dpvo_amd/csrc/update.hip instead of ~60 torch / torch_scatter launches.
 The nn.Module parameters are the single source of truth; `Update.pack()` derives the f16 operand images the
 kernels consume (what autocast's per-call weight casts produce in the reference, dpvo/dpvo.py:332).
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import workspace
 from . import altcorr
 from .extractor import BasicEncoder4
 from .graph import GraphPlan
@@ -76,6 +79,16 @@ def heads(net, Wd, bd, Ww, bw, coords=None, target_out=None, weight_out=None):
         L.check(L.lib().dpvo_heads(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight),
                                    L.i64(E), L.i32(DIM), L.stream()), "dpvo_heads")
     return delta, weight
+
+
+class _UpdParams(ctypes.Structure):
+    """dpvo_update_params_t"""
+    _fields_ = [(k, ctypes.c_void_p) for k in (
+        "c0_w", "c0_b", "c2_w", "c2_b", "cln_g", "cln_b", "c5_w", "c5_b", "norm_g", "norm_b",
+        "c1_w0", "c1_b0", "c1_w2", "c1_b2", "c2n_w0", "c2n_b0", "c2n_w2", "c2n_b2",
+        "akk_wfg", "akk_bfg", "akk_wh", "akk_bh", "aij_wfg", "aij_bfg", "aij_wh", "aij_bh",
+        "g0_g", "g0_b", "g0_wrg", "g0_brg", "g0_w2", "g0_b2", "g1_g", "g1_b", "g1_wrg", "g1_brg", "g1_w2", "g1_b2",
+        "d_w", "d_b", "w_w", "w_b")]
 
 
 # ------------------------------------------------------------------------------------------ modules (reference tree)
@@ -149,6 +162,11 @@ class Update(nn.Module):
                        h(gr.res[2].weight), h(gr.res[2].bias))
         P["d"] = (h(self.d[1].weight), h(self.d[1].bias))
         P["w"] = (h(self.w[1].weight), h(self.w[1].bias))
+        # pointer table of dpvo_update_forward (field order = dpvo_update_params_t in include/dpvo_hip.h)
+        tab = [P["c0"][0], P["c0"][1], P["c2"][0], P["c2"][1], P["cln"][0], P["cln"][1], P["c5"][0], P["c5"][1],
+               P["norm"][0], P["norm"][1], *P["c1"], *P["c2n"], *P["akk"], *P["aij"], *P["g0"], *P["g1"], *P["d"], *P["w"]]
+        assert len(tab) == len(_UpdParams._fields_)
+        P["_params"] = _UpdParams(*[ctypes.c_void_p(t.data_ptr()) for t in tab])
         self._packed = P
         return P
 
@@ -163,7 +181,7 @@ class Update(nn.Module):
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
-                out=None, coords=None, target_out=None, weight_out=None):
+                out=None, coords=None, target_out=None, weight_out=None, composite=True):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
         `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
@@ -196,6 +214,26 @@ class Update(nn.Module):
         if inp2.dtype != torch.float16:
             inp2 = inp2.half()
         inp2 = inp2.contiguous()
+
+        if composite and net2.dtype == torch.float32:
+            # the whole operator as ONE library call (dpvo_update_forward issues the same launches as the code below;
+            # `composite=False` keeps the launch-by-launch path for tests)
+            x = out.reshape(E, DIM) if out is not None else torch.empty(E, DIM, dtype=torch.float32, device=dev)
+            assert x.dtype == torch.float32 and x.is_contiguous()
+            delta = torch.empty(E, 2, dtype=torch.float32, device=dev)
+            weight = weight_out if weight_out is not None else torch.empty(E, 2, dtype=torch.float32, device=dev)
+            if coords is not None:
+                assert coords.is_contiguous() and coords.dtype == torch.float32 and target_out is not None
+            maxg = max(plan.n_patches_host, plan.n_pairs_host)
+            nbytes = L.lib().dpvo_update_workspace_bytes(L.i64(E), L.i64(maxg))
+            ws = workspace.get(nbytes, dev, "update")
+            L.check(L.lib().dpvo_update_forward(
+                ctypes.byref(P["_params"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
+                L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
+                L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta), L.ptr(weight),
+                L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws), ctypes.c_size_t(ws.numel()),
+                L.stream()), "dpvo_update_forward")
+            return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
 
         # net = net + inp + self.corr(corr); net = self.norm(net)                              (net.py:77-78)
         h1 = linear(corr2, P["c0"][0], P["c0"][1], epilogue=EPI_RELU, K=self.kpad)

@@ -272,6 +272,34 @@ int dpvo_motion_model(float* poses, int n, float scale, void* stream);
 /* depth initialisation (dpvo.py:430-432): patches[n][:,2] = torch.median(patches[n-3:n,:,2]) (lower median). */
 int dpvo_median_depth(float* patches, int n, int M, int P, void* stream);
 
+/* The whole update operator (dpvo/net.py:74-92, Update.forward) as one call: exactly the launch sequence a host would
+ * issue through dpvo_linear / dpvo_layernorm / dpvo_softagg / dpvo_gather_add / dpvo_heads_target.  Weight images (f16
+ * unless noted; the host packs them once, see dpvo_amd/net.py:Update.pack):
+ *   c0 = corr.0 padded to K = 896, c2 = corr.2, cln = corr.3 LayerNorm (f32), c5 = corr.5, norm (f32),
+ *   c1 / c2n = the two neighbour MLPs (.0 and .2), akk / aij = SoftAgg: wfg = [f; g] stacked (768 rows), wh = h,
+ *   g0 / g1 = gru.0+gru.1 / gru.2+gru.3: LayerNorm (f32), wrg = [res.0; gate.0] stacked, w2 = res.2, d / w = the heads.
+ * net [E,384] f32 in; inp f16 rows gathered by inp_rows modulo inp_mod (the imap ring, dpvo.py:334); corr [E,ld_corr] f16 with
+ * columns 882..895 zero; plan from dpvo_plan_build(_ranged) with upper bounds on its two group counts; coords [E,2,P,P] and
+ * target [E,2] optional (both or neither).  Outputs: net_out [E,384] f32 (may alias net), delta, weight [E,2] f32. */
+typedef struct {
+  const void *c0_w, *c0_b, *c2_w, *c2_b;
+  const float *cln_g, *cln_b;
+  const void *c5_w, *c5_b;
+  const float *norm_g, *norm_b;
+  const void *c1_w0, *c1_b0, *c1_w2, *c1_b2, *c2n_w0, *c2n_b0, *c2n_w2, *c2n_b2;
+  const void *akk_wfg, *akk_bfg, *akk_wh, *akk_bh, *aij_wfg, *aij_bfg, *aij_wh, *aij_bh;
+  const float *g0_g, *g0_b;
+  const void *g0_wrg, *g0_brg, *g0_w2, *g0_b2;
+  const float *g1_g, *g1_b;
+  const void *g1_wrg, *g1_brg, *g1_w2, *g1_b2;
+  const void *d_w, *d_b, *w_w, *w_b;
+} dpvo_update_params_t;
+size_t dpvo_update_workspace_bytes(int64_t E, int64_t max_groups);
+int dpvo_update_forward(const dpvo_update_params_t* params, const float* net, const void* inp, const int64_t* inp_rows,
+                        int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan, int64_t n_patches_ub,
+                        int64_t n_pairs_ub, const float* coords, int P, float* net_out, float* delta, float* weight,
+                        float* target, int64_t E, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * feature encoders  (Patchifier.fnet / .inet: dpvo/extractor.py:200-264, called at dpvo/net.py:116-117)
  * ---------------------------------------------------------------------------------------------- */

@@ -168,3 +168,31 @@ def test_update_full_size_determinism(dev):
     # permutation equivariance (group sums change order -> f16-level differences only)
     assert (c[0] - a[0][p.to(dev)]).abs().max().item() < 2e-2
     assert (wc[0] - wa[0][p.to(dev)]).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("E_frames", [14, 40])
+def test_composite_entry_equals_launch_by_launch(dev, E_frames):
+    """dpvo_update_forward (one C-ABI call) issues exactly the launches of the wrapper-by-wrapper path: same bits,
+    including the fused target / weight outputs and the imap gather"""
+    from dpvo_amd import synthetic as S
+    from dpvo_amd.graph import GraphPlan
+    torch.manual_seed(7)
+    upd = N.Update(3).to(dev)
+    ii, jj, kk = (t.to(dev) for t in S.replay_graph(E_frames))
+    E = ii.numel()
+    g = torch.Generator().manual_seed(5)
+    net = torch.randn(E, 384, generator=g).to(dev)
+    imap = torch.randn(3456, 384, generator=g).half().to(dev)
+    corr = torch.zeros(E, 896, dtype=torch.float16, device=dev)
+    corr[:, :882] = torch.randn(E, 882, generator=g).half().to(dev)
+    coords = (torch.rand(1, E, 2, 3, 3, generator=g) * 100).to(dev)
+    plan = GraphPlan(ii, jj, kk)
+    res = []
+    for comp in (False, True):
+        tgt = torch.zeros(E, 2, device=dev); wgt = torch.zeros(E, 2, device=dev)
+        x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
+                           corr_is_padded=True, coords=coords, target_out=tgt, weight_out=wgt, composite=comp)
+        res.append((x.clone(), d.clone(), w.clone(), tgt, wgt))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.equal(res[1][3], coords[0, :, :, 1, 1] + res[1][1][0])
