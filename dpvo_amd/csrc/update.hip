@@ -847,6 +847,7 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const _Float16* __restri
 template <bool X_F32>
 __global__ __launch_bounds__(256) void layernorm384_kernel(const void* __restrict__ x, const _Float16* __restrict__ add1,
                                                            const int64_t* __restrict__ add1_rows, int64_t add1_mod,
+                                                           const int32_t* __restrict__ add1_rows32,
                                                            const _Float16* __restrict__ add2,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float* __restrict__ y_f32,
@@ -868,6 +869,7 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(const void* __restric
   if (add1) {
     int64_t r1 = row;
     if (add1_rows) { r1 = add1_rows[row]; if (add1_mod > 0) r1 %= add1_mod; }
+    else if (add1_rows32) r1 = add1_rows32[row];            // (group index of the plan: the SoftAgg expand, net.py:88)
     const _Float16* a = add1 + r1 * D;
 #pragma unroll
     for (int i = 0; i < 6; ++i) v[i] += (float)a[lane + 64 * i];
@@ -1037,9 +1039,10 @@ extern "C" int dpvo_linear(const void* A, int a_dtype, int64_t lda, const int32_
   return DPVO_OK;
 }
 
-extern "C" int dpvo_layernorm(const void* x, int x_dtype, const void* add1, const int64_t* add1_rows, int64_t add1_mod,
-                              const void* add2, const float* gamma, const float* beta, float eps, float* y_f32,
-                              void* y_f16, int relu_f16, int64_t M, int D, void* stream) {
+namespace {
+int launch_layernorm(const void* x, int x_dtype, const void* add1, const int64_t* add1_rows, int64_t add1_mod,
+                     const int32_t* add1_rows32, const void* add2, const float* gamma, const float* beta, float eps,
+                     float* y_f32, void* y_f16, int relu_f16, int64_t M, int D, void* stream) {
   if (M < 0) return DPVO_E_INVALID;
   if (M == 0) return DPVO_OK;
   if (D != 384) return DPVO_E_UNSUPPORTED;
@@ -1047,14 +1050,24 @@ extern "C" int dpvo_layernorm(const void* x, int x_dtype, const void* add1, cons
   const dim3 grid((unsigned)cdiv64(M, 4));
   if (x_dtype == DPVO_F32)
     hipLaunchKernelGGL(layernorm384_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)add1,
-                       add1_rows, add1_mod, (const _Float16*)add2, gamma, beta, eps, y_f32, (_Float16*)y_f16, relu_f16, M);
+                       add1_rows, add1_mod, add1_rows32, (const _Float16*)add2, gamma, beta, eps, y_f32, (_Float16*)y_f16,
+                       relu_f16, M);
   else if (x_dtype == DPVO_F16)
     hipLaunchKernelGGL(layernorm384_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)add1,
-                       add1_rows, add1_mod, (const _Float16*)add2, gamma, beta, eps, y_f32, (_Float16*)y_f16, relu_f16, M);
+                       add1_rows, add1_mod, add1_rows32, (const _Float16*)add2, gamma, beta, eps, y_f32, (_Float16*)y_f16,
+                       relu_f16, M);
   else
     return DPVO_E_UNSUPPORTED;
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
+}
+}  // namespace
+
+extern "C" int dpvo_layernorm(const void* x, int x_dtype, const void* add1, const int64_t* add1_rows, int64_t add1_mod,
+                              const void* add2, const float* gamma, const float* beta, float eps, float* y_f32,
+                              void* y_f16, int relu_f16, int64_t M, int D, void* stream) {
+  return launch_layernorm(x, x_dtype, add1, add1_rows, add1_mod, nullptr, add2, gamma, beta, eps, y_f32, y_f16, relu_f16, M, D,
+                          stream);
 }
 
 extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, const int32_t* off,
@@ -1182,14 +1195,16 @@ extern "C" int dpvo_update_forward(const dpvo_update_params_t* p, const float* n
     UPD(dpvo_linear(x16, DPVO_F16, 384, nullptr, Wfg, 384, bfg, fg, 768, nullptr, 0, nullptr, 0, DPVO_EPI_NONE, 0, E, 768, 384, stream));
     UPD(dpvo_softagg(fg, 768, perm, off, cnt, ng, y, 384, stream));
     UPD(dpvo_linear(y, DPVO_F16, 384, nullptr, Wh, 384, bh, hy, 384, nullptr, 0, nullptr, 0, DPVO_EPI_NONE, 0, ng, 384, 384, stream));
-    UPD(dpvo_gather_add(x, hy, grp, k == 0 ? x16 : nullptr, E, 384, stream));
+    // (the expand + residual of agg_ij is folded into the LayerNorm that follows: same f32 sum, one pass less over net)
+    if (k == 0) UPD(dpvo_gather_add(x, hy, grp, x16, E, 384, stream));
   }
   // net = self.gru(net): 2 x (LayerNorm, x + gate(x) * res(x))                                (net.py:90)
   for (int k = 0; k < 2; ++k) {
     const float *g = k ? p->g1_g : p->g0_g, *b = k ? p->g1_b : p->g0_b;
     const void *Wrg = k ? p->g1_wrg : p->g0_wrg, *brg = k ? p->g1_brg : p->g0_brg, *W2 = k ? p->g1_w2 : p->g0_w2,
                *b2 = k ? p->g1_b2 : p->g0_b2;
-    UPD(dpvo_layernorm(x, DPVO_F32, nullptr, nullptr, 0, nullptr, g, b, 1e-3f, x, h1, 0, E, 384, stream));
+    UPD(launch_layernorm(x, DPVO_F32, k == 0 ? hy : nullptr, nullptr, 0, k == 0 ? plan + PL.pu : nullptr, nullptr, g, b, 1e-3f, x,
+                         h1, 0, E, 384, stream));
     UPD(dpvo_linear(h1, DPVO_F16, 384, nullptr, Wrg, 384, brg, fg, 768, nullptr, 0, nullptr, 0, DPVO_EPI_RELU_SIG, 384, E, 768, 384,
                     stream));
     UPD(dpvo_linear(fg, DPVO_F16, 768, nullptr, W2, 384, b2, x, 384, (const _Float16*)fg + 384, 768, nullptr, 0, DPVO_EPI_GATED, 0, E,
