@@ -32,6 +32,12 @@ struct EncPtrs {                         // one per encoder (z = 0 fnet, z = 1 i
   float out_scale;                       // multiplies the rounded f16 output (the "/ 4.0" of net.py:116-117)
 };
 struct EncArgs { EncPtrs e[2]; };
+#ifdef ENC_TRACE
+__device__ unsigned long long g_enc_trace[2048][8];
+#define ENC_T(i) do { if (CIN == 64 && KS == 3 && threadIdx.x == 0 && blockIdx.z == 0) g_enc_trace[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define ENC_T(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ int swz4(int px) { return (0x78 >> (2 * ((px >> 2) & 3))) & 3; }   // 64 B pixels (Cin 32)
 
@@ -74,34 +80,58 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+  ENC_T(0);
   if (P.in_mode == 2) reduce_stats<CIN>(P.in_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean, s_rstd);
   __syncthreads();
+  ENC_T(1);
 
   // ---- stage the input halo (producer's norm + relu applied here; zero padding applies to the transformed tensor)
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
-  for (int q = tid; q < IH * IW * CPP; q += 256) {
-    const int ch = q % CPP, pix = q / CPP;
-    const int ly = pix / IW, lx = pix - ly * IW;
-    const int y = iy0 + ly, x = ix0 + lx;
-    h8 v = (h8)(_Float16)0;
-    if (y >= 0 && y < Hin && x >= 0 && x < Win) {
-      v = *reinterpret_cast<const h8*>(P.in + ((int64_t)y * Win + x) * CIN + ch * 8);
-      if (P.in_mode == 2) {
+  {
+    // all global loads of this thread first (they are independent), then the transform + LDS writes: the naive
+    // load -> normalise -> store loop is a chain of ~1 us round trips (measured: 4.7 us of a 23 us workgroup)
+    constexpr int NCHUNK = IH * IW * CPP, NPT = (NCHUNK + 255) / 256;
+    h8 pf[NPT];
+    unsigned inimg = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const _Float16 nv = (_Float16)(((float)v[k] - s_mean[ch * 8 + k]) * s_rstd[ch * 8 + k]);   // IN output is f16
-          v[k] = nv > (_Float16)0 ? nv : (_Float16)0;
-        }
-      } else if (P.in_mode == 1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = v[k] > (_Float16)0 ? v[k] : (_Float16)0;
+    for (int k = 0; k < NPT; ++k) {
+      const int q = tid + 256 * k;
+      const int ch = q % CPP, pix = q / CPP;
+      const int ly = pix / IW, lx = pix - ly * IW;
+      const int y = iy0 + ly, x = ix0 + lx;
+      pf[k] = (h8)(_Float16)0;
+      if (q < NCHUNK && y >= 0 && y < Hin && x >= 0 && x < Win) {
+        pf[k] = *reinterpret_cast<const h8*>(P.in + ((int64_t)y * Win + x) * CIN + ch * 8);
+        inimg |= 1u << k;
       }
     }
-    const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
-    *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int q = tid + 256 * k;
+      if (q < NCHUNK) {
+        const int ch = q % CPP, pix = q / CPP;
+        const int lx = pix % IW;
+        h8 v = pf[k];
+        if ((inimg >> k) & 1) {
+          if (P.in_mode == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const _Float16 nv = (_Float16)(((float)v[e] - s_mean[ch * 8 + e]) * s_rstd[ch * 8 + e]);   // IN output is f16
+              v[e] = nv > (_Float16)0 ? nv : (_Float16)0;
+            }
+          } else if (P.in_mode == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > (_Float16)0 ? v[e] : (_Float16)0;
+          }
+        }
+        const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+        *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
+      }
+    }
   }
   __syncthreads();
 
+  ENC_T(2);
   // ---- implicit GEMM: wave w owns output rows 2w, 2w+1 (4 M-tiles of 16 pixels), 4 N-tiles (64 channels)
   f4 acc[4][NT];
 #pragma unroll
@@ -111,36 +141,45 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   const int m = lane & 15, kg = lane >> 4;
   const int ncout = P.cout;
   constexpr int K = KS * KS * CIN;
+  // flat k-steps t = (kh*KS + kw)*(CIN/32) + kc; the filter fragments of step t+2 are fetched (L2) while step t runs:
+  // un-prefetched they were a dependent ~0.5 us round trip per step (9 us of a 23 us workgroup for 2 us of MFMA)
+  constexpr int KC = CIN / 32, T = KS * KS * KC, PD = 2;
+  h8 fwr[PD + 1][NT];
+  auto wload = [&](int t, h8 (&dst)[NT]) {
 #pragma unroll
-  for (int kh = 0; kh < KS; ++kh)
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + m;
+      dst[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w + (int64_t)n * K + (t * 32 + kg * 8)) : (h8)(_Float16)0;
+    }
+  };
 #pragma unroll
-    for (int kw = 0; kw < KS; ++kw)
+  for (int t = 0; t < PD && t < T; ++t) wload(t, fwr[t]);
 #pragma unroll
-      for (int kc = 0; kc < CIN / 32; ++kc) {
-        h8 fw[NT];
+  for (int t = 0; t < T; ++t) {
+    if (t + PD < T) wload(t + PD, fwr[(t + PD) % (PD + 1)]);
+    const int kc = t % KC, kw = (t / KC) % KS, kh = t / (KC * KS);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = n0 + j * 16 + m;
-          fw[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w + (int64_t)n * K + ((kh * KS + kw) * CIN + kc * 32 + kg * 8))
-                              : (h8)(_Float16)0;
-        }
+    for (int i = 0; i < 4; ++i) {
+      const int ly = (2 * wave + (i >> 1)) * S + kh, lx = ((i & 1) * 16 + m) * S + kw;
+      const int ch = kc * 4 + kg;
+      const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+      const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ly = (2 * wave + (i >> 1)) * S + kh, lx = ((i & 1) * 16 + m) * S + kw;
-          const int ch = kc * 4 + kg;
-          const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
-          const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa, acc[i][j], 0, 0, 0);
-        }
-      }
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % (PD + 1)][j], fa, acc[i][j], 0, 0, 0);
+    }
+  }
 
+  ENC_T(3);
   // ---- epilogue: bias, f16 rounding, NHWC store, per-channel partial statistics of the ROUNDED values
   float ssum[NT][4], ssq[NT][4];
+  h4 bias4[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + kg * 4;
+    bias4[j] = (n < ncout) ? *reinterpret_cast<const h4*>(P.bias + n) : (h4)(_Float16)0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int oy = oy0 + 2 * wave + (i >> 1), ox = ox0 + (i & 1) * 16 + m;
@@ -149,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + j * 16 + kg * 4;
       if (n >= ncout) continue;
-      const h4 bv = *reinterpret_cast<const h4*>(P.bias + n);
+      const h4 bv = bias4[j];
       h4 hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -160,6 +199,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       if (inb) *reinterpret_cast<h4*>(P.out + ((int64_t)oy * Wout + ox) * ncout + n) = hv;
     }
   }
+  ENC_T(4);
   if (P.out_part) {
     // reduce over the 16 pixel lanes (xor 1,2,4,8 keeps kg), then over the 4 waves through LDS, fixed order
 #pragma unroll
@@ -181,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       }
     }
   }
+  ENC_T(5);
 }
 
 // ---------------------------------------------------------------------------------------------------
