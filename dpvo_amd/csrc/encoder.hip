@@ -23,7 +23,7 @@ typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 struct EncPtrs {                         // one per encoder (z = 0 fnet, z = 1 inet)
   const _Float16* in;                    // input activation NHWC (raw conv output of the producer, or materialised)
   const double* in_part;                 // producer's per-channel (sum, sum^2) accumulators [2][64] or null
-  const _Float16* w;                     // weights [Cout][K]
+  const _Float16* w;                     // weights [K/32][Cout][32] (k-step major: fragment loads are 1 KB contiguous)
   const _Float16* bias;                  // [Cout]
   _Float16* out;                         // NHWC raw conv output (bias added, f16)
   double* out_part;                      // this conv's (sum, sum^2) accumulators [2][64] (zeroed by the host) or null
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + j * 16 + m;
-      dst[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w + (int64_t)n * K + (t * 32 + kg * 8)) : (h8)(_Float16)0;
+      dst[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w + ((int64_t)t * ncout + n) * 32 + kg * 8) : (h8)(_Float16)0;
     }
   };
 #pragma unroll
@@ -392,7 +392,7 @@ __global__ void pool4_nhwc_kernel(const _Float16* __restrict__ in, _Float16* __r
 
 // Weight / bias pointer table, per encoder (fnet then inet), in this order (all f16, repacked by the host):
 //   0 conv1 w[32][192]  1 conv1 b     (K = (kh, c, kw padded to 8), zero padded to 192)
-//   then for each 3x3 / 1x1 conv  w[Cout][KS*KS*Cin] with K = (kh, kw, cin), b[Cout]:
+//   then for each 3x3 / 1x1 conv  w[K/32][Cout][32] with K = KS*KS*Cin ordered (kh, kw, cin) (k-step major), b[Cout]:
 //   2,3   layer1.0.conv1 (32->32)     4,5   layer1.0.conv2      6,7   layer1.1.conv1     8,9   layer1.1.conv2
 //   10,11 layer2.0.conv1 (32->64 s2)  12,13 layer2.0.conv2 (64) 14,15 layer2.0.downsample.0 (1x1 s2 32->64)
 //   16,17 layer2.1.conv1 (64->64)     18,19 layer2.1.conv2      20,21 conv2 (1x1, 64 -> 128 | 384)

@@ -309,7 +309,8 @@ int dpvo_update_forward(const dpvo_update_params_t* params, const float* net, co
  *   imap_out [H/4][W/4][384] = inet(image) / 4   (no normalisation)        -- NHWC f16
  * weights: 44 device pointers (22 per tower, fnet first) to f16 tensors repacked by the host:
  *   [0] conv1.weight as [32][192]: K ordered (kh, c, kw) with kw padded 7->8 and K padded 168->192; [1] conv1.bias;
- *   then weight [Cout][kh][kw][Cin] / bias pairs of layer1.0.conv1, layer1.0.conv2, layer1.1.conv1, layer1.1.conv2,
+ *   then weight / bias pairs -- weight as [K/32][Cout][32] where K = (kh, kw, cin) is the flattened filter, i.e. the
+ *   [Cout][kh][kw][Cin] tensor cut into 32-wide k-steps with the k-step index outermost -- of layer1.0.conv1, layer1.0.conv2, layer1.1.conv1, layer1.1.conv2,
  *   layer2.0.conv1 (stride 2), layer2.0.conv2, layer2.0.downsample.0 (1x1 stride 2), layer2.1.conv1, layer2.1.conv2,
  *   conv2 (1x1).  15 launches for both towers (MIOpen path: ~114). */
 size_t dpvo_encoders_workspace_bytes(int H, int W);
