@@ -240,12 +240,23 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-  for (int q = tid; q < 3 * IH * IWP; q += 256) {
-    const int lx = q % IWP, ly = (q / IWP) % IH, c = q / (IWP * IH);
-    const int y = iy0 + ly, x = ix0 + lx;
-    _Float16 v = (_Float16)0;
-    if (lx < IW && y >= 0 && y < H && x >= 0 && x < W) v = img[((int64_t)c * H + y) * W + x];
-    halo[q] = v;
+  {
+    // independent loads first, LDS writes after (see conv_kernel)
+    constexpr int NEL = 3 * IH * IWP, NPT = (NEL + 255) / 256;
+    _Float16 pf[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int q = tid + 256 * k;
+      const int lx = q % IWP, ly = (q / IWP) % IH, c = q / (IWP * IH);
+      const int y = iy0 + ly, x = ix0 + lx;
+      pf[k] = (_Float16)0;
+      if (q < NEL && lx < IW && y >= 0 && y < H && x >= 0 && x < W) pf[k] = img[((int64_t)c * H + y) * W + x];
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int q = tid + 256 * k;
+      if (q < NEL) halo[q] = pf[k];
+    }
   }
   __syncthreads();
   f4 acc[4][2];
@@ -273,10 +284,13 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
     }
   }
   float ssum[2][4], ssq[2][4];
+  h4 bias4[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) {
+    bias4[j] = *reinterpret_cast<const h4*>(P.bias + j * 16 + kg * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int oy = oy0 + 2 * wave + (i >> 1), ox = ox0 + (i & 1) * 16 + m;
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = j * 16 + kg * 4;
-      const h4 bv = *reinterpret_cast<const h4*>(P.bias + n);
+      const h4 bv = bias4[j];
       h4 hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
