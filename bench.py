@@ -137,7 +137,10 @@ def main():
     cfg.merge_from_dict(DEFAULT_YAML if args.config == "default" else FAST_YAML)
     cfg.KEYFRAME_THRESH = -1.0                       # keep every keyframe (see module docstring)
     ht, wd = 480, 640
-    total = args.warmup + args.steps
+    # the metric is quoted at the steady state of default.yaml (E = 45 312 edges), reached ~36 frames after initialisation:
+    # frames needed beyond the requested warm-up are run as an untimed pre-roll BEFORE the W warm-up steps
+    preroll = max(0, 45 - args.warmup)
+    total = preroll + args.warmup + args.steps
     cfg.BUFFER_SIZE = max(cfg.BUFFER_SIZE, total + 16)      # every frame stays a keyframe in this workload
     torch.manual_seed(1234 + rank)
     net = VONet()
@@ -154,11 +157,11 @@ def main():
     from dpvo_amd import multiseq
     clock = multiseq.Clock(dist=dist, device=device)
     with torch.no_grad():
-        for t in range(args.warmup):
+        for t in range(preroll + args.warmup):
             step(t)
         corr_mod.PROFILE = []
         clock.start()                                 # barrier + torch.cuda.synchronize()
-        for t in range(args.warmup, total):
+        for t in range(preroll + args.warmup, total):
             step(t)
         slam.flush()                                  # the last frame's deferred keyframe decision belongs to the timed region
         local = clock.stop()                          # torch.cuda.synchronize() + barrier
