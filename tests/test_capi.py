@@ -62,3 +62,29 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_argument_validation_is_host_only():
+    """every entry validates its arguments before touching the device: error codes without a GPU, never a crash / exit
+    (the reference calls exit(1) in block_e.cu:20-27 and ba.cpp:151-152)"""
+    from dpvo_amd import _lib as L
+    lib = L.lib()
+    null = ctypes.c_void_p(0)
+    INVALID, UNSUPPORTED = -1, -2
+    assert lib.dpvo_update_workspace_bytes(L.i64(45312), L.i64(2300)) > 45312 * 384 * 2 * 5
+    assert lib.dpvo_update_workspace_bytes(L.i64(-1), L.i64(0)) == 0
+    assert lib.dpvo_update_forward(null, null, null, null, L.i64(0), null, L.i64(896), null, L.i64(1), L.i64(1), null, L.i32(3),
+                                   null, null, null, null, L.i64(10), null, ctypes.c_size_t(0), null) == INVALID
+    assert lib.dpvo_plan_build_ranged(null, null, null, L.i64(-1), null, null, ctypes.c_size_t(0), L.i64(0), L.i64(0), null) == INVALID
+    assert lib.dpvo_frame_patches(null, null, null, null, null, null, null, null, L.f32(4.0), null, null, null, null, null, null,
+                                  null, null, L.i32(-1), L.i32(1), L.i32(1), L.i32(4), L.i32(4), L.i32(128), L.i32(384), L.i32(3),
+                                  L.i64(0), L.i64(0), null) == INVALID
+    assert lib.dpvo_frame_patches(null, null, null, null, null, null, null, null, L.f32(4.0), null, null, null, null, null, null,
+                                  null, null, L.i32(4), L.i32(1), L.i32(1), L.i32(4), L.i32(4), L.i32(128), L.i32(384), L.i32(5),
+                                  L.i64(0), L.i64(0), null) == UNSUPPORTED
+    assert lib.dpvo_heads_target(null, null, null, null, null, null, L.i32(3), null, null, null, L.i64(-3), L.i32(384), null) == INVALID
+    assert lib.dpvo_heads_target(null, null, null, null, null, null, L.i32(3), null, null, null, L.i64(0), L.i32(384), null) == 0
+    assert lib.dpvo_linear(null, L.i32(0), L.i64(384), null, null, L.i64(384), null, null, L.i64(384), null, L.i64(0), null, L.i64(0),
+                           L.i32(0), L.i32(0), L.i64(0), L.i32(384), L.i32(384), null) == 0       # M = 0: nothing to do
+    assert lib.dpvo_encoders_workspace_bytes(L.i32(480), L.i32(640)) > 0
+    assert lib.dpvo_encoders_workspace_bytes(L.i32(481), L.i32(640)) == 0                          # H, W multiples of 16
