@@ -59,6 +59,7 @@ def test_trajectory_matches_oracle_pipeline(dev):
             coords = torch.stack([x, y], -1).float()
             depth = torch.rand(M, generator=g)
             slam(float(t), img, intr, patch_coords=coords.to(dev), depth_init=depth.to(dev))
+            slam.flush()                              # (no-op unless DPVO_DEFER_KEYFRAME is set)
             fmap, imap = captured[-1]
             ref.frame(float(t), fmap, imap, coords[0].numpy(), depth.numpy(), intr.cpu().numpy(), accept, drop)
             n = slam.n
