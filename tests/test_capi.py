@@ -88,3 +88,14 @@ def test_argument_validation_is_host_only():
                            L.i32(0), L.i32(0), L.i64(0), L.i32(384), L.i32(384), null) == 0       # M = 0: nothing to do
     assert lib.dpvo_encoders_workspace_bytes(L.i32(480), L.i32(640)) > 0
     assert lib.dpvo_encoders_workspace_bytes(L.i32(481), L.i32(640)) == 0                          # H, W multiples of 16
+
+
+def test_reference_import_names_resolve():
+    """`from dpvo.dpvo import DPVO` etc. (demo.py:10-14, evaluate_euroc.py:14-19) resolve to this package after compat.install()"""
+    import subprocess, sys
+    code = ("import dpvo_amd.compat as c; c.install(); "
+            "from dpvo.dpvo import DPVO; from dpvo.config import cfg; from dpvo.utils import Timer; "
+            "from dpvo.net import VONet; from dpvo.patchgraph import PatchGraph; from dpvo import altcorr, fastba, lietorch; "
+            "from dpvo.lietorch import SE3; import dpvo_amd.dpvo as d; assert DPVO is d.DPVO; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
