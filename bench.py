@@ -89,19 +89,21 @@ def cpu_baseline():
     g32, a, b = gmap.float().numpy(), f0.float().numpy(), f1.float().numpy()
     gen = torch.Generator().manual_seed(0)
     net = torch.randn(E, 384, generator=gen)
+    nstep = 2                                # ~10-12 s of CPU work on the GPU box's host cores
     t0 = time.perf_counter()
-    coords = oracle.reproject(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy(), dtype=np.float32)
-    corr = oracle.corr_pyramid(g32, [a, b], coords, (kk % 3456).numpy(), (jj % 36).numpy(), dtype=np.float32)
-    inp = imap[kk % 3456]
-    _, delta, weight = update_ref.update_forward(sd, net, inp, torch.from_numpy(corr), ii, jj, kk)
-    target = coords[:, :, 1, 1] + delta.numpy().astype(np.float32)
-    oracle.ba(poses.numpy(), patches.numpy(), intr.numpy(), target, weight.numpy(), 1e-4, ii.numpy(), jj.numpy(), kk.numpy(),
-              30, 40, iterations=2, dtype=np.float32)
-    dt = time.perf_counter() - t0
+    for _ in range(nstep):
+        coords = oracle.reproject(poses.numpy(), patches.numpy(), intr.numpy(), ii.numpy(), jj.numpy(), kk.numpy(), dtype=np.float32)
+        corr = oracle.corr_pyramid(g32, [a, b], coords, (kk % 3456).numpy(), (jj % 36).numpy(), dtype=np.float32)
+        inp = imap[kk % 3456]
+        _, delta, weight = update_ref.update_forward(sd, net, inp, torch.from_numpy(corr), ii, jj, kk)
+        target = coords[:, :, 1, 1] + delta.numpy().astype(np.float32)
+        oracle.ba(poses.numpy(), patches.numpy(), intr.numpy(), target, weight.numpy(), 1e-4, ii.numpy(), jj.numpy(), kk.numpy(),
+                  30, 40, iterations=2, dtype=np.float32)
+    dt = (time.perf_counter() - t0) / nstep
     return {"value": 1.0 / dt, "unit": "frames/sec", "cores": cores, "kind": "port",
-            "sample": f"1 hot-path step (reproject+corr+update+2 BA iters) at E={E} on the CPU oracle "
+            "sample": f"{nstep} hot-path steps (reproject+corr+update+2 BA iters) at E={E} on the CPU oracle "
                       f"(C/OpenMP f32 for corr/reproject/BA, torch-CPU for the update operator); encoders excluded; "
-                      f"{dt:.1f} s"}
+                      f"{dt:.1f} s per step"}
 
 
 def main():
