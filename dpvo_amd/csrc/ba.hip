@@ -207,10 +207,13 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
     if (tid < 36) rowS[tid / 6][6 * p + tid % 6] = s; else rowy[tid - 36] = s;
   }
   __syncthreads();
-  // Schur complement (ba_cuda.cu:557-558) + damping (:560): entries = 6 x n6 of S, then 6 of y; 4 lanes per entry, the
-  // partial sums of up to 8 entries per lane are accumulated in one pass so that their loads overlap.
-  const int nrow = 6 * n6 + 6;
-  constexpr int kIt = (6 * kMaxDim + 6 + 63) / 64;      // 12
+  // Schur complement (ba_cuda.cu:557-558) + damping (:560).  blockIdx.y = row ra of the pose's block row: its n6 entries of
+  // S and its entry of y, 4 lanes per entry; four partial matrices per trip so that their loads overlap (the adds keep
+  // the order b, b+4, ...).  (The B part above is recomputed by the six row-workgroups: it is a few LDS lookups, while
+  // the 69 partial matrices are a chain of dependent global round trips worth splitting six ways.)
+  const int ra = blockIdx.y;
+  const int nrow = n6 + 1;
+  constexpr int kIt = (kMaxDim + 1 + 63) / 64;          // 2
   const int sub = tid & 3;
   float sc[kIt];
   int gent[kIt];
@@ -218,10 +221,9 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
   for (int it = 0; it < kIt; ++it) {
     const int e4 = it * 64 + (tid >> 2);
     sc[it] = 0.f;
-    gent[it] = (e4 < 6 * n6) ? (6 * p + e4 / n6) * n6 + (e4 % n6) : n6 * n6 + 6 * p + (e4 - 6 * n6);
+    gent[it] = (e4 < n6) ? (6 * p + ra) * n6 + e4 : n6 * n6 + 6 * p + ra;
     if (e4 >= nrow) gent[it] = -1;
   }
-  // (four partial matrices per trip: their loads are independent and overlap; the adds keep the order b, b+4, ...)
   for (int b0 = sub; b0 < n_spart; b0 += 16) {
     float v[4][kIt];
 #pragma unroll
@@ -243,13 +245,12 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
     v += __shfl_xor(v, 2);
     const int e4 = it * 64 + (tid >> 2);
     if (e4 < nrow && sub == 0) {
-      if (e4 < 6 * n6) {
-        const int ra = e4 / n6, rb = e4 - ra * n6;
-        float sv = rowS[ra][rb] - v;
-        if (6 * p + ra == rb) sv += 1e-4f * sv + 1.0f;              // S += I * (1e-4 * S + 1.0)
+      if (e4 < n6) {
+        float sv = rowS[ra][e4] - v;
+        if (6 * p + ra == e4) sv += 1e-4f * sv + 1.0f;                // S += I * (1e-4 * S + 1.0)
         Sg[gent[it]] = sv;
       } else {
-        yg[6 * p + (e4 - 6 * n6)] = rowy[e4 - 6 * n6] - v;
+        yg[6 * p + ra] = rowy[ra] - v;
       }
     }
   }
@@ -571,7 +572,7 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
     hipLaunchKernelGGL(ba_patch_kernel, dim3(patch_blocks), dim3(256), 0, st, ii, jj, plan + PL.perm_k,
                        plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, np_h, spart);
     if (N > 0) {
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, spart,
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, spart,
                          (int)patch_blocks, t0, N, Sg, yg);
       if (6 * N <= 60)
         hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(64), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
