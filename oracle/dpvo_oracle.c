@@ -10,7 +10,9 @@
  * Parity status: the reference has no tests / golden vectors for this path;
  * native-kernel parity is therefore "unpinned" by reference tests.  What pins this file:
  * lietorch's algebraic identities (run_tests.py:16-52), goldens produced by importing the
- * reference's own Python (tests/golden/make_golden.py) and internal cross-checks.
+ * reference's own Python (tests/golden/make_golden.py: Update.forward, pops.transform, patchify
+ * glue, reduce_edges, and the independent Python bundle adjustment dpvo/ba.py:86-182 for orc_ba)
+ * and internal cross-checks.
  */
 #include <math.h>
 #include <stdint.h>

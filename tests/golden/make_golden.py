@@ -75,7 +75,23 @@ def install_stubs():
 
     lb.expm, lb.logm, lb.inv = wrap1(oracle.se3_exp), wrap1(oracle.se3_log), wrap1(oracle.se3_inv)
     lb.mul, lb.act4 = wrap2(oracle.se3_mul), wrap2(oracle.se3_act4)
-    for name in ("expm_backward", "logm_backward", "inv_backward", "mul_backward", "adj", "adj_backward", "adjT",
+
+    def adjT(gid, X, a):
+        """b = Adj(X)^T a, Adj = [[R, [t]x R], [0, R]] (lietorch/include/se3.h:58-67,84-86), float64 numpy"""
+        x, av = _np(X).astype(np.float64), _np(a).astype(np.float64)
+        t, q = x[:, :3], x[:, 3:] / np.linalg.norm(x[:, 3:], axis=1, keepdims=True)
+        qx, qy, qz, qw = q.T
+        R = np.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                      2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                      2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)], -1).reshape(-1, 3, 3)
+        z = np.zeros_like(qx)
+        tx = np.stack([z, -t[:, 2], t[:, 1], t[:, 2], z, -t[:, 0], -t[:, 1], t[:, 0], z], -1).reshape(-1, 3, 3)
+        Ad = np.zeros((x.shape[0], 6, 6))
+        Ad[:, :3, :3] = R; Ad[:, :3, 3:] = tx @ R; Ad[:, 3:, 3:] = R
+        return _t(np.einsum("nji,nj->ni", Ad, av), a)
+
+    lb.adjT = adjT
+    for name in ("expm_backward", "logm_backward", "inv_backward", "mul_backward", "adj", "adj_backward",
                  "adjT_backward", "act", "act_backward", "act4_backward", "Jinv", "as_matrix", "projector"):
         setattr(lb, name, None)
     sys.modules["lietorch_backends"] = lb
@@ -178,6 +194,41 @@ def main():
     es5 = rreduce(fm, ri, rj, 5, 1)
     out["reduce_edges"] = dict(flow=fm, ii=ri, jj=rj, edges=np.asarray(es, np.int64).reshape(-1, 2),
                                edges_cap5=np.asarray(es5, np.int64).reshape(-1, 2))
+
+    # ------------------------------------------------------------------ bundle adjustment: the reference's own PYTHON BA
+    # dpvo/ba.py:86-182 (pops.transform(jacobian=True) Jacobians, torch_scatter accumulation, Schur, Cholesky, retractions)
+    # is an implementation independent of ba_cuda.cu; with ep=1.0 (the CUDA damping S += I*(1e-4*S + 1), ba_cuda.cu:560),
+    # the CUDA bounds (-64, -64, 2cx+64, 2cy+64) (:305-306), fixedp = t0 and residuals < 128 px it is the same update.
+    from dpvo.ba import BA as rBA
+    ii3, jj3, kk3 = S.replay_graph(12, S.GraphCfg(M=6, REMOVAL_WINDOW=9, PATCH_LIFETIME=5))
+    poses3, patches3, intr3 = S.make_scene(12, M=6, ht=48, wd=64, seed=11)
+    g = torch.Generator().manual_seed(12)
+    patches3[5::9, 2] *= -1                                       # negative inverse depths (still Z > 0.2: they get updated)
+    patches3[40, 0] += 300.0                                      # projects outside the bounds: masked on both sides
+    patches3[47, 2] = 40.0                                        # very close point: Z < 0.2 in some target frames
+    co = oracle.reproject(poses3.numpy(), patches3.numpy(), intr3.numpy(), ii3.numpy(), jj3.numpy(), kk3.numpy())
+    tgt = torch.from_numpy(co[:, :, 1, 1]).double() + 1.5 * torch.randn(ii3.numel(), 2, generator=g).double()
+    tgt[3::50] += 400.0                                           # residual > 250 px (> 128 px): masked on both sides
+    wgt = torch.rand(ii3.numel(), 2, generator=g).double()
+    t0b = 5
+    cx, cy = float(intr3[0, 2]), float(intr3[0, 3])
+    bounds = [-64.0, -64.0, 2 * cx + 64.0, 2 * cy + 64.0]
+    Pb, pb_ = poses3.double()[None].clone(), patches3.double()[None].clone()
+    Gs, ps = RSE3(Pb), pb_
+    steps, tgts = [], [tgt]
+    for it in range(2):
+        Gs, ps = rBA(Gs, ps, intr3.double()[None], tgts[-1][None], wgt[None], 1e-4, ii3, jj3, kk3, bounds, ep=1.0, fixedp=t0b)
+        steps.append((Gs.data[0].numpy().copy(), ps[0].numpy().copy()))
+        # the second step starts from the first step's output with fresh targets around ITS projections, so that no
+        # residual falls between the CUDA (128 px) and the Python (250 px) outlier thresholds
+        co = oracle.reproject(steps[-1][0], steps[-1][1], intr3.numpy(), ii3.numpy(), jj3.numpy(), kk3.numpy())
+        t2 = torch.from_numpy(co[:, :, 1, 1]).double() + 1.5 * torch.randn(ii3.numel(), 2, generator=g).double()
+        t2[7::60] -= 500.0
+        tgts.append(t2)
+    out["ba"] = dict(poses=poses3.numpy(), patches=patches3.numpy(), intr=intr3.numpy(), target=tgt.numpy(), weight=wgt.numpy(),
+                     target2=tgts[1].numpy(),
+                     ii=ii3.numpy(), jj=jj3.numpy(), kk=kk3.numpy(), t0=np.int64(t0b), t1=np.int64(12),
+                     poses_it1=steps[0][0], patches_it1=steps[0][1], poses_it2=steps[1][0], patches_it2=steps[1][1])
 
     for name, d in out.items():
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **d)

@@ -1,6 +1,7 @@
 """Oracle (and, on the GPU box, the HIP kernels) against the golden fixtures under tests/golden/, which were produced
 by importing the REFERENCE'S OWN PYTHON (tests/golden/make_golden.py): Update.forward / SoftAgg / GatedResidual,
-pops.transform / flow_mag / point_cloud, altcorr.patchify's bilinear glue and reduce_edges.  The fixtures are f64
+pops.transform / flow_mag / point_cloud, altcorr.patchify's bilinear glue, reduce_edges and the Python bundle
+adjustment dpvo/ba.py (an implementation independent of ba_cuda.cu).  The fixtures are f64
 reference outputs, so the oracle must match them to ~1e-9 (f32 storage: 1e-5)."""
 import os
 
@@ -63,6 +64,56 @@ def test_update_golden(oracle):
         update_ref._h, update_ref._f = saved
     assert np.allclose(rn.numpy(), d["net_out"], atol=2e-5) and np.allclose(rd.numpy(), d["delta"], atol=2e-5)
     assert np.allclose(rw.numpy(), d["weight"], atol=2e-5)
+
+
+def _ba_steps():
+    """the two single Gauss-Newton steps of the fixture: (start poses, start patches, targets, golden poses, golden patches)"""
+    d = _load("ba")
+    return d, ((d["poses"].astype(np.float64), d["patches"].astype(np.float64), d["target"], d["poses_it1"], d["patches_it1"]),
+               (d["poses_it1"], d["patches_it1"], d["target2"], d["poses_it2"], d["patches_it2"]))
+
+
+def _ba_compare(P, pat, P0, pat0, gP, gpat, kk, atol, rtol, tag):
+    """The reference's Python BA (dpvo/ba.py:170-173) clamps EVERY inverse depth to [1e-3, 10]; cuda_ba touches only the
+    patches that have edges and applies max(d, 1e-4), d > 20 -> 1 (ba_cuda.cu:218-221).  Outside the clamps the two are
+    the same update, so: patches with edges and an unclamped golden depth must agree, the others must be untouched."""
+    kx = np.unique(kk)
+    rest = np.setdiff1d(np.arange(pat.shape[0]), kx)
+    gd = gpat[kx, 2, 1, 1]
+    inside = (gd > 1e-3) & (gd < 10.0)
+    assert inside.sum() >= 40
+    H.assert_close(P, gP, atol, rtol, f"poses vs the reference's Python BA [{tag}]")
+    H.assert_close(pat[kx][inside], gpat[kx][inside], atol, rtol, f"patches vs the reference's Python BA [{tag}]")
+    assert np.array_equal(pat[rest], pat0[rest].astype(pat.dtype)) and np.array_equal(pat[:, :2], pat0[:, :2].astype(pat.dtype))
+    assert np.abs(P - P0).max() > 5e-3, "the step must move the poses"
+
+
+def test_ba_golden(oracle):
+    """oracle.ba (restatement of cuda_ba, ba_cuda.cu:232-582) == the reference's independent Python BA (dpvo/ba.py:86-182 with
+    pops.transform's Jacobians, projective_ops.py:71-108) run with the CUDA path's damping and bounds, step by step"""
+    d, steps = _ba_steps()
+    for n, (P0, pat0, tgt, gP, gpat) in enumerate(steps):
+        P, pat, info, _ = oracle.ba(P0, pat0, d["intr"], tgt, d["weight"], 1e-4, d["ii"], d["jj"], d["kk"], int(d["t0"]),
+                                    int(d["t1"]), iterations=1)
+        assert info == 0
+        _ba_compare(P, pat.reshape(-1, 3, 3, 3), P0, pat0, gP, gpat, d["kk"], 1e-7, 1e-9, f"oracle f64, step {n + 1}")
+
+
+@pytest.mark.gpu
+def test_hip_ba_against_golden(dev):
+    """fastba.BA (HIP, f32) against the reference's Python BA on the fixture (f32 Schur solve: atol 2e-4, rtol 2e-3)"""
+    from dpvo_amd import fastba
+    d, steps = _ba_steps()
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)
+    i = lambda k: torch.from_numpy(d[k]).to(dev)
+    for n, (P0, pat0, tgt, gP, gpat) in enumerate(steps):
+        pd, ptd = f(P0), f(pat0)
+        st = (pd.cpu().numpy(), ptd.cpu().numpy())
+        ret = fastba.BA(pd.view(1, -1, 7), ptd.view(1, -1, 3, 3, 3), f(d["intr"]).view(1, -1, 4), f(tgt)[None], f(d["weight"])[None],
+                        torch.as_tensor([1e-4], device=dev), i("ii"), i("jj"), i("kk"), int(d["t0"]), int(d["t1"]), M=6,
+                        iterations=1, eff_impl=False)
+        assert ret == []
+        _ba_compare(pd.cpu().numpy(), ptd.cpu().numpy(), st[0], st[1], gP, gpat, d["kk"], 2e-4, 2e-3, f"HIP f32, step {n + 1}")
 
 
 @pytest.mark.gpu
