@@ -146,7 +146,7 @@ def main():
     cfg.BUFFER_SIZE = max(cfg.BUFFER_SIZE, total + 16)      # every frame stays a keyframe in this workload
     torch.manual_seed(1234 + rank)
     net = VONet()
-    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, defer_keyframe=True,      # decision of frame t resolved under frame t+1's encoders
+    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, defer_keyframe=bool(int(os.environ.get("DPVO_DEFER_KEYFRAME", "1"))),      # decision of frame t resolved under frame t+1's encoders
                 overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "1"))))   # ... on a second HIP stream
     slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
     n_img = 64
@@ -196,6 +196,14 @@ def main():
                        "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "parallelism": f"replicas x{world}"},
             "roofline": roof,
         }
+        if os.environ.get("DPVO_BENCH_DIAG"):              # state fingerprint + buffer addresses (run-to-run comparisons)
+            co = slam.reproject()[0, :, :, 1, 1]
+            inb = ((co[:, 0] > 0) & (co[:, 0] < wd / 4) & (co[:, 1] > 0) & (co[:, 1] < ht / 4)).float().mean().item()
+            out["diag"] = {"pose_sum": float(slam.pg.poses_[:slam.n].double().abs().sum().item()),
+                           "depth_sum": float(slam.pg.patches_[:slam.n, :, 2].double().abs().sum().item()),
+                           "net_sum": float(slam.pg.net.double().abs().sum().item()), "in_bounds": round(inb, 4),
+                           "ptr": {k: hex(getattr(slam, k).data_ptr()) for k in ("_fmap1_cl", "_fmap2_cl", "_gmap_cl", "imap_")},
+                           "corr_ms_minmax": [round(min(corr_ms), 4), round(max(corr_ms), 4)]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

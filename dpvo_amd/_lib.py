@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpvo_hip.so")
+LIB_PATH = os.environ.get("DPVO_HIP_LIB") or os.path.join(_HERE, "libdpvo_hip.so")      # (override: development builds)
 
 F16, F32 = 0, 1
 

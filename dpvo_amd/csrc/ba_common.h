@@ -174,10 +174,12 @@ __global__ __launch_bounds__(128) static void ba_pair_kernel(const float* __rest
           ce += live ? w * Jz * Jz : 0.f;
           ue += live ? w * r * Jz : 0.f;
         }
-        float* eb = edgebuf + (int64_t)e * kEdgeStride;
-        eb[0] = ce; eb[1] = ue;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { eb[2 + a] = Ei[a]; eb[8 + a] = Ej[a]; }
+        // four aligned 16-byte stores (the row is 64 B; 14 scalar stores get merged into 16-byte stores at 8-byte alignment)
+        f4* eb = reinterpret_cast<f4*>(edgebuf + (int64_t)e * kEdgeStride);
+        eb[0] = (f4){ce, ue, Ei[0], Ei[1]};
+        eb[1] = (f4){Ei[2], Ei[3], Ei[4], Ei[5]};
+        eb[2] = (f4){Ej[0], Ej[1], Ej[2], Ej[3]};
+        eb[3] = (f4){Ej[4], Ej[5], 0.f, 0.f};
       }
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2) {

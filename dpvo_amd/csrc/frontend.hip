@@ -272,23 +272,26 @@ __global__ __launch_bounds__(256) void frame_patches_kernel(
   const float x = coords ? coords[2 * m] : (float)xs[m], y = coords ? coords[2 * m + 1] : (float)ys[m];
   const int fi = fp_floor_int(y), fj = fp_floor_int(x);
   // gmap: 9 window positions x CF channels (channels fastest in both the NHWC source and the channels-last slot)
-  for (int e = t; e < 9 * CF; e += 256) {
+  // (every output group is optional: a null slot skips it, so the state stores and the feature gathers can be two launches)
+  for (int e = t; gmap_slot && e < 9 * CF; e += 256) {
     const int c = e % CF, ab = e / CF, a = ab / 3, b = ab - 3 * a;
     const float o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w,
                              [&](int i, int j) { return (float)fmap[((int64_t)i * w + j) * CF + c]; });
     gmap_slot[((int64_t)m * 9 + ab) * CF + c] = (_Float16)o;
   }
-  for (int c = t; c < CI; c += 256) {
+  for (int c = t; imap_slot && c < CI; c += 256) {
     const float o = fp_blend(x, y, fi, fj, h, w, [&](int i, int j) { return (float)imap[((int64_t)i * w + j) * CI + c]; });
     imap_slot[(int64_t)m * CI + c] = (_Float16)o;
   }
   if (t < 27) {
+    if (!patches_slot) return;
     const int pl = t / 9, ab = t - 9 * pl, a = ab / 3, b = ab - 3 * a;
     float o;
     if (pl == 2) o = depth[m];
     else o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w, [&](int i, int j) { return pl == 0 ? (float)j : (float)i; });
     patches_slot[(int64_t)m * 27 + t] = o;
   } else if (t >= 32 && t < 35) {
+    if (!colors_slot) return;
     const int c = t - 32, cs = 2 - c;                                            // clr[0,:,[2,1,0]]
     const float cx = 4.0f * (x + 0.5f), cy = 4.0f * (y + 0.5f);
     const float o = fp_blend(cx, cy, (int)floorf(cy), (int)floorf(cx), H, W, [&](int i, int j) {
@@ -393,7 +396,9 @@ extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void
   if (M < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || CF <= 0 || CI <= 0) return DPVO_E_INVALID;
   if (P != 3) return DPVO_E_UNSUPPORTED;
   if (M == 0) return DPVO_OK;
-  if (!fmap || !imap || !img_u8 || !depth || !gmap_slot || !imap_slot || !patches_slot || !colors_slot) return DPVO_E_INVALID;
+  // output groups are optional (null = skip); each needs its inputs
+  if (!gmap_slot && !imap_slot && !patches_slot && !colors_slot) return DPVO_E_INVALID;
+  if ((gmap_slot && !fmap) || (imap_slot && !imap) || (patches_slot && !depth) || (colors_slot && !img_u8)) return DPVO_E_INVALID;
   if (!coords && !(xs && ys)) return DPVO_E_INVALID;
   if (intrinsics_slot && !intrinsics) return DPVO_E_INVALID;
   hipLaunchKernelGGL(frame_patches_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const _Float16*)fmap,

@@ -261,7 +261,8 @@ int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* ii, const in
  * encoders' output), img_u8 [3,H,W]; coords [M,2] f32 OR the two randint draws xs, ys [M] int64 (net.py:132-133);
  * depth [M] f32.  Slots: gmap [M,3,3,CF] f16 (channels-last), imap [M,CI] f16, patches [M,3,3,3] f32, colours [M,3] u8,
  * intrinsics_slot [4] (may be NULL), index_row [M] = frame_next and *index_map = m_next (may be NULL), coords_out [M,2]
- * (may be NULL).  P must be 3. */
+ * (may be NULL).  P must be 3.  Each output group (gmap / imap / patches / colours) is skipped when its slot is NULL, so the
+ * state stores (which need no feature map) and the feature gathers can be issued as two launches around other work. */
 int dpvo_frame_patches(const void* fmap, const void* imap, const void* img_u8, const float* coords, const int64_t* xs,
                        const int64_t* ys, const float* depth, const float* intrinsics, float res, void* gmap_slot,
                        void* imap_slot, float* patches_slot, void* colors_slot, float* intrinsics_slot,

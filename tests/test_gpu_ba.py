@@ -122,3 +122,39 @@ def test_global_ba_vs_oracle(oracle, dev, case):
                   M=M, iterations=2, eff_impl=False)
         H.assert_close(pd.cpu().numpy(), pd2.cpu().numpy(), 1e-4, 1e-4, "dense vs block-sparse poses")
         H.assert_close(ptd.cpu().numpy()[:, 2], ptd2.cpu().numpy()[:, 2], 1e-4, 1e-3, "dense vs block-sparse depths")
+
+
+def test_ba_does_not_depend_on_other_streams(oracle, dev):
+    """Regression test for a code-generation hazard found on MI355X: built WITH packed-FP32 VALU instructions, ba_pair_kernel
+    intermittently returned different values in lanes 48-63 whenever kernels of another stream (the overlapped encoders)
+    shared its CUs (13 of 149 repetitions; csrc/Makefile NOPK).  The same BA step, repeated while a second stream runs
+    encoder forward passes, must give bit-identical results every time."""
+    from dpvo_amd.encoders import HipEncoders
+    from dpvo_amd.net import VONet
+    ii, jj, kk = S.replay_graph(40)
+    poses, patches, intr, target, weight = _problem(ii, jj, kk, 40, 96, oracle)
+    d = lambda t: t.to(dev)
+    ii, jj, kk, intr, target, weight, p0, pt0 = d(ii), d(jj), d(kk), d(intr), d(target), d(weight), d(poses), d(patches)
+    plan = GraphPlan(ii, jj, kk)
+    torch.manual_seed(0)
+    vo = VONet().to(dev)
+    enc = HipEncoders(vo.patchify.fnet, vo.patchify.inet)
+    img = (torch.randn(3, 480, 640, device=dev) / 2).half()
+    eo = (torch.empty(120, 160, 128, dtype=torch.float16, device=dev), torch.empty(120, 160, 384, dtype=torch.float16, device=dev))
+    side = torch.cuda.Stream(device=dev)
+    P, PT = p0.clone(), pt0.clone()
+    ref, bad = None, torch.zeros((), dtype=torch.int64, device=dev)
+    for r in range(100):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                enc(img, fmap_out=eo[0], imap_out=eo[1])
+        P.copy_(p0); PT.copy_(pt0)
+        fastba.BA(P.view(1, -1, 7), PT.view(1, -1, 3, 3, 3), intr.view(1, -1, 4), target[None], weight[None], 1e-4, ii, jj, kk,
+                  30, 40, M=96, iterations=2, plan=plan)
+        out = torch.cat([P.flatten(), PT.flatten()])
+        if ref is None:
+            ref = out.clone()
+        else:
+            bad += (out != ref).any()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, f"{int(bad)} of 99 repetitions differ from the first one"

@@ -133,3 +133,16 @@ def test_frame_patches_matches_patchifier_composition(dev, mode):
     assert torch.equal(patches, ref_patches) and torch.equal(colors, ref_clr)
     assert torch.equal(intr_o, intr / 4.0) and torch.equal(cout, coords[0])
     assert (idx_row == 7).all() and idx_map.item() == 7 * M
+    # the same as two launches (state stores first, feature gathers later): untouched groups stay untouched
+    gmap2 = torch.zeros_like(gmap); im2 = torch.zeros_like(im); patches2 = torch.zeros_like(patches); colors2 = torch.zeros_like(colors)
+    cc = L.ptr(None if use_xy else coords[0].contiguous())
+    xy = (L.ptr(xs if use_xy else None), L.ptr(ys if use_xy else None))
+    dims = (L.i32(M), L.i32(h), L.i32(w), L.i32(H), L.i32(W), L.i32(CF), L.i32(CI), L.i32(3), L.i64(7), L.i64(7 * M), L.stream())
+    nul = L.ptr(None)
+    L.check(L.lib().dpvo_frame_patches(nul, nul, L.ptr(img), cc, *xy, L.ptr(depth), L.ptr(intr), L.f32(4.0), nul, nul,
+                                       L.ptr(patches2), L.ptr(colors2), nul, nul, nul, nul, *dims), "dpvo_frame_patches")
+    assert torch.equal(patches2, ref_patches) and torch.equal(colors2, ref_clr) and not gmap2.any() and not im2.any()
+    L.check(L.lib().dpvo_frame_patches(L.ptr(fmap), L.ptr(imap), nul, cc, *xy, nul, nul, L.f32(4.0), L.ptr(gmap2), L.ptr(im2),
+                                       nul, nul, nul, nul, nul, nul, *dims), "dpvo_frame_patches")
+    assert torch.equal(gmap2, ref_gmap) and torch.equal(im2, ref_imap)
+    assert L.lib().dpvo_frame_patches(nul, nul, nul, cc, *xy, nul, nul, L.f32(4.0), nul, nul, nul, nul, nul, nul, nul, nul, *dims) < 0

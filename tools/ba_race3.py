@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""BA repeatability under concurrent encoders, three ways of providing the inputs.  Dev tool."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpvo_amd import fastba, synthetic as S, workspace
+from dpvo_amd import projective_ops as pops
+from dpvo_amd.encoders import HipEncoders
+from dpvo_amd.graph import GraphPlan
+from dpvo_amd.net import VONet
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+vo = VONet().to(dev)
+enc = HipEncoders(vo.patchify.fnet, vo.patchify.inet)
+img = (torch.randn(3, 480, 640, device=dev) / 2).half()
+eo = (torch.empty(120, 160, 128, dtype=torch.float16, device=dev), torch.empty(120, 160, 384, dtype=torch.float16, device=dev))
+side = torch.cuda.Stream(device=dev)
+ii, jj, kk = (t.to(dev) for t in S.replay_graph(40))
+E = ii.numel()
+poses, patches, intr = (t.to(dev) for t in S.make_scene(40))
+plan0 = GraphPlan(ii, jj, kk, n_frames=4096, n_patch_ids=4096 * 96)
+coords = pops.transform_coords(poses, patches, intr, ii, jj, kk)
+target = coords[0, :, :, 1, 1].contiguous() + 0.5 * torch.randn(E, 2, device=dev)
+weight = torch.rand(E, 2, device=dev)
+p0, pt0 = poses.clone(), patches.clone()
+reps = int(os.environ.get("REPS", "90"))
+for mode in sys.argv[1:] or ["copy", "copy_sync", "clone", "noenc"]:
+    ref = None; bad = 0
+    torch.cuda.synchronize()
+    for r in range(reps):
+        if "noenc" not in mode:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    enc(img, fmap_out=eo[0], imap_out=eo[1])
+        if "clone" in mode:
+            P, PT = p0.clone(), pt0.clone()
+        else:
+            poses.copy_(p0); patches.copy_(pt0); P, PT = poses, patches
+        if mode == "copy_sync":
+            torch.cuda.current_stream().synchronize()
+        fastba.BA(P, PT, intr, target, weight, 1e-4, ii, jj, kk, 30, 40, M=96, iterations=int(os.environ.get("ITERS", "1")), plan=plan0)
+        out = torch.cat([P.flatten(), PT.flatten()]).clone()
+        if ref is None:
+            ref = out; seen = [out]
+        else:
+            bad += int(not torch.equal(out, ref))
+            if not any(torch.equal(out, s) for s in seen) and len(seen) < 40:
+                seen.append(out)
+    torch.cuda.synchronize()
+    d = (seen[1] != seen[0]).nonzero().flatten() if len(seen) > 1 else []
+    print(f"{mode:12s} mismatching reps: {bad} / {reps - 1}; distinct results {len(seen)}; first diff idx {d[:6].tolist() if len(d) else []} of {len(d)} (poses occupy [0,{p0.numel()}))")
