@@ -196,9 +196,14 @@ def main():
                        "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "parallelism": f"replicas x{world}"},
             "roofline": roof,
         }
+        # the tracker state after the run: with random weights nothing guarantees that it stays sane, and a diverged state
+        # (NaN poses, every edge projecting out of bounds) would make the correlation kernel skip its work
+        co = slam.reproject()[0, :, :, 1, 1]
+        inb = ((co[:, 0] > 0) & (co[:, 0] < wd / 4) & (co[:, 1] > 0) & (co[:, 1] < ht / 4)).float().mean().item()
+        out["state"] = {"finite": bool(torch.isfinite(slam.pg.poses_[:slam.n]).all().item()), "edges_in_bounds": round(inb, 4)}
+        if not out["state"]["finite"] or inb < 0.5:
+            out["error"] = "tracker state diverged during the run: the timing above is not a valid measurement"
         if os.environ.get("DPVO_BENCH_DIAG"):              # state fingerprint + buffer addresses (run-to-run comparisons)
-            co = slam.reproject()[0, :, :, 1, 1]
-            inb = ((co[:, 0] > 0) & (co[:, 0] < wd / 4) & (co[:, 1] > 0) & (co[:, 1] < ht / 4)).float().mean().item()
             out["diag"] = {"pose_sum": float(slam.pg.poses_[:slam.n].double().abs().sum().item()),
                            "depth_sum": float(slam.pg.patches_[:slam.n, :, 2].double().abs().sum().item()),
                            "net_sum": float(slam.pg.net.double().abs().sum().item()), "in_bounds": round(inb, 4),

@@ -14,8 +14,9 @@
 //                         sum_k Q_k u_k e_k  -> spart[block].
 //   3. ba_assemble_kernel one thread per entry of S / y: B, v from pairbuf in a fixed order, minus the Schur
 //                         partials, plus the reference's damping S += I*(1e-4*S + 1)  -> Sg, yg.
-//   4. ba_solve_kernel    one workgroup: left-looking Cholesky of the <=120x120 system in LDS (one barrier per
-//                         column), column-oriented triangular solves -> dX.
+//   4. ba_solve60_kernel  n6 <= 60: one workgroup, 6x6-blocked right-looking Cholesky of [S; y^T] in LDS, blocked backward
+//                         substitution -> dX;  ba_solve_kernel (n6 <= 120): left-looking Cholesky in LDS (one barrier per
+//                         column), column-oriented triangular solves.
 //   5. ba_retr_kernel     dZ_k = Q_k (u_k - e_k . dX), depth retraction with the reference's clamps; pose
 //                         retraction Exp(dX)*T.
 #include "ba_common.h"
@@ -257,116 +258,153 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 4a. solve kernel for n6 <= 60 (the default window: N <= 10 free poses): ONE wave, lane t owns row t of the system
-//     IN REGISTERS.  Right-looking block Cholesky with 6x6 pose blocks: the diagonal block travels by v_readlane and
-//     is factorised redundantly by every lane, the 6-wide panel is published through LDS once per block step and the
-//     trailing update runs on registers -- 10 short dependent steps instead of 60 LDS round trips.  The system is
-//     padded with identity rows up to 60, so every loop bound is a compile-time constant.
+// 4a. solve kernel for n6 <= 60 (the default window: N <= 10 free poses): blocked right-looking Cholesky of the
+//     AUGMENTED matrix [S; y^T] in LDS with 6x6 pose blocks, one workgroup of 256 threads.  Per block step
+//       panel    (wave 0, one lane per remaining row, the y row included): the diagonal block is read by every lane
+//                and factorised redundantly, each row below solves  x L_bb^T = A[r][block]  in registers;
+//       trailing (all four waves): A[r][c] -= <A[r][block], A[c][block]> for the columns to the right.
+//     Carrying y along as row n6 makes the forward substitution part of the factorisation; the backward substitution is
+//     blocked the same way (lane c owns z[c]; a 6x6 triangular solve per block, then one rank-6 update of the lanes to
+//     the left).  ~3.5 k instructions on the longest wave and 2 barriers per block step, instead of one wave issuing
+//     9.5 k straight-line instructions (the previous register-resident version: 27 us, and 100 us on boxes whose
+//     shader clock stays low while a single wave runs).  Loops are rolled: the kernel is 4 KB of code.
 // ---------------------------------------------------------------------------------------------------
-#define RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+constexpr int kLd60 = 62;      // row stride of the 61 x 60 LDS matrix in floats (8-byte aligned rows)
 
-template <int B>
-__device__ __forceinline__ void chol_block_step(float (&row)[60], float (*Lp)[8], int t, int& bad) {
-  constexpr int o = 6 * B;
-  // 1. diagonal block (lower) from the lanes that own it
-  float D[6][6], Lb[6][6], inv[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) D[r][c] = RL(row[o + c], o + r);
-  // 2. its Cholesky factor, redundantly in every lane
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    float d = D[c][c];
-#pragma unroll
-    for (int k = 0; k < c; ++k) d -= Lb[c][k] * Lb[c][k];
-    if (!(d > 0.f) && bad == 0) bad = o + c + 1;
-    Lb[c][c] = sqrtf(d);
-    inv[c] = 1.0f / Lb[c][c];
-#pragma unroll
-    for (int r = c + 1; r < 6; ++r) {
-      float v = D[r][c];
-#pragma unroll
-      for (int k = 0; k < c; ++k) v -= Lb[r][k] * Lb[c][k];
-      Lb[r][c] = v * inv[c];
-    }
-  }
-  // 3. panel: rows at / below the block solve  x L_bb^T = row[o..o+5]
-  float x[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    float v = row[o + c];
-#pragma unroll
-    for (int k = 0; k < c; ++k) v -= x[k] * Lb[c][k];
-    x[c] = v * inv[c];
-  }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    if (t == o + c) x[c] = Lb[c][c];          // exact pivot on the diagonal lanes
-    row[o + c] = x[c];
-  }
-  if constexpr (B < 9) {
-    // 4. publish the panel, 5. trailing update of the columns to the right
-    *reinterpret_cast<f4*>(&Lp[t][0]) = (f4){x[0], x[1], x[2], x[3]};
-    Lp[t][4] = x[4]; Lp[t][5] = x[5];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int c2 = o + 6; c2 < 60; ++c2) {
-      const f4 l0 = *reinterpret_cast<const f4*>(&Lp[c2][0]);
-      const float l4 = Lp[c2][4], l5 = Lp[c2][5];
-      row[c2] -= x[0] * l0[0] + x[1] * l0[1] + x[2] * l0[2] + x[3] * l0[3] + x[4] * l4 + x[5] * l5;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-__global__ __launch_bounds__(64) void ba_solve60_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
-                                                        float* __restrict__ dX, int32_t* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) float Lp[64][8];
-  __shared__ float Lf[60][61];
-  const int n6 = 6 * N;
-  const int t = threadIdx.x;
-  float row[60];
-#pragma unroll
-  for (int c = 0; c < 60; ++c) row[c] = (t < n6 && c < n6) ? Sg[t * n6 + c] : ((t == c) ? 1.0f : 0.0f);
-  float bv = (t < n6) ? yg[t] : 0.0f;
-  int bad = 0;
-  chol_block_step<0>(row, Lp, t, bad); chol_block_step<1>(row, Lp, t, bad); chol_block_step<2>(row, Lp, t, bad);
-  chol_block_step<3>(row, Lp, t, bad); chol_block_step<4>(row, Lp, t, bad); chol_block_step<5>(row, Lp, t, bad);
-  chol_block_step<6>(row, Lp, t, bad); chol_block_step<7>(row, Lp, t, bad); chol_block_step<8>(row, Lp, t, bad);
-  chol_block_step<9>(row, Lp, t, bad);
-  // L[t][c] = row[c] (c <= t).  Forward substitution L z = y on registers.
-  float dinv = 1.0f;
-#pragma unroll
-  for (int c = 0; c < 60; ++c) dinv = (t == c) ? 1.0f / row[c] : dinv;
-#pragma unroll
-  for (int k = 0; k < 60; ++k) {
-    const float zk = RL(bv, k) * RL(dinv, k);
-    if (t == k) bv = zk;
-    if (t > k) bv -= row[k] * zk;
-  }
-  // transpose through LDS for the backward substitution L^T x = z
-  if (t < 60) {
-#pragma unroll
-    for (int c = 0; c < 60; ++c) Lf[t][c] = row[c];
-  }
+__device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (t < 60) {
-#pragma unroll
-    for (int k = 0; k < 60; ++k) row[k] = Lf[k][t];       // row[k] := L[k][t]
+}
+
+__global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
+                                                         float* __restrict__ dX, int32_t* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) float A[61 * kLd60];
+  __shared__ float Lbb[10][28];              // per block: L_bb (lower, packed by rows: 21) and 1 / diag (6)
+  __shared__ float zs[64];
+  __shared__ int s_bad;
+  const int n6 = 6 * N, tid = threadIdx.x;
+  // lower triangle of S and y as row n6
+  for (int r = tid >> 4; r <= n6; r += 16) {
+    const float* src = (r < n6) ? Sg + r * n6 : yg;
+    const int cend = (r < n6) ? r : n6 - 1;
+    for (int c = tid & 15; c <= cend; c += 16) A[r * kLd60 + c] = src[c];
   }
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  for (int B = 0; B < N; ++B) {
+    const int o = 6 * B;
+    const int r = o + tid;
+    if (r <= n6) {                             // panel: rows o..n6 (n6 - o + 1 <= 61 lanes of wave 0)
+      float Lb[6][6], inv[6];
+      int bad = 0;
 #pragma unroll
-  for (int k = 59; k >= 0; --k) {
-    const float xk = RL(bv, k) * RL(dinv, k);
-    if (t == k) bv = xk;
-    if (t < k) bv -= row[k] * xk;
+      for (int c = 0; c < 6; ++c) {
+        float d = A[(o + c) * kLd60 + o + c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) d -= Lb[c][k] * Lb[c][k];
+        if (!(d > 0.f) && bad == 0) bad = o + c + 1;
+        inv[c] = __builtin_amdgcn_rsqf(d);           // 1 ulp; the pivot itself is only needed as d * rsq(d)
+        Lb[c][c] = d * inv[c];
+#pragma unroll
+        for (int r2 = c + 1; r2 < 6; ++r2) {
+          float v = A[(o + r2) * kLd60 + o + c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= Lb[r2][k] * Lb[c][k];
+          Lb[r2][c] = v * inv[c];
+        }
+      }
+      if (r >= o + 6) {                        // rows below the block (nobody writes the block's own rows in this step)
+        float x[6];
+        float* ar = A + r * kLd60 + o;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          float v = ar[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= x[k] * Lb[c][k];
+          x[c] = v * inv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ar[c] = x[c];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+          for (int c = 0; c <= i; ++c) Lbb[B][i * (i + 1) / 2 + c] = Lb[i][c];
+          Lbb[B][21 + i] = inv[i];
+        }
+        if (bad && s_bad == 0) s_bad = bad;
+      }
+    }
+    __syncthreads();
+    // trailing update: rows rr (0..m, row m = y), columns cc <= min(rr, m - 1), relative to o + 6.  Thread (ty, tx) of a
+    // 16 x 16 grid owns the elements (ty + 16 i, tx + 16 j): all its operand rows are fetched first (independent LDS
+    // reads), then the <= 16 dot products, then the read-modify-writes.
+    const int m = n6 - o - 6;
+    if (m > 0) {
+      const float* base = A + (o + 6) * kLd60 + o;
+      const int ty = tid >> 4, tx = tid & 15;
+      float ar[4][6], ac[4][6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = ty + 16 * i, cc = tx + 16 * i;
+        const float* pr = base + (rr <= m ? rr : m) * kLd60;
+        const float* pc = base + (cc < m ? cc : m - 1) * kLd60;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ar[i][k] = pr[k]; ac[i][k] = pc[k]; }
+      }
+      float cur[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rr = ty + 16 * i, cc = tx + 16 * j;
+          const bool on = rr <= m && cc < m && cc <= rr;
+          cur[i][j] = on ? A[(o + 6 + rr) * kLd60 + o + 6 + cc] : 0.f;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rr = ty + 16 * i, cc = tx + 16 * j;
+          if (rr <= m && cc < m && cc <= rr) {
+            const float sum = ar[i][0] * ac[j][0] + ar[i][1] * ac[j][1] + ar[i][2] * ac[j][2] + ar[i][3] * ac[j][3] +
+                              ar[i][4] * ac[j][4] + ar[i][5] * ac[j][5];
+            A[(o + 6 + rr) * kLd60 + o + 6 + cc] = cur[i][j] - sum;
+          }
+        }
+    }
+    __syncthreads();
   }
-  if (t < n6) dX[t] = bv;
-  if (t == 0 && info) *info = bad;
+  // backward substitution L^T x = z (z = row n6), wave 0, lane c owns z[c]
+  if (tid < 64) {
+    float z = (tid < n6) ? A[n6 * kLd60 + tid] : 0.f;
+    float xv = 0.f;
+    for (int B = N - 1; B >= 0; --B) {
+      const int o = 6 * B;
+      zs[tid] = z;
+      wave_lds_sync();
+      const float* Lb = Lbb[B];
+      float x[6];
+#pragma unroll
+      for (int c = 5; c >= 0; --c) {
+        float v = zs[o + c];
+#pragma unroll
+        for (int k = c + 1; k < 6; ++k) v -= Lb[k * (k + 1) / 2 + c] * x[k];
+        x[c] = v * Lb[21 + c];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xv = (tid == o + k) ? x[k] : xv;
+      if (tid < o) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) z -= A[(o + k) * kLd60 + tid] * x[k];
+      }
+      wave_lds_sync();
+    }
+    if (tid < n6) dX[tid] = xv;
+    if (tid == 0 && info) *info = s_bad;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -575,7 +613,7 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, spart,
                          (int)patch_blocks, t0, N, Sg, yg);
       if (6 * N <= 60)
-        hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(64), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
+        hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
       else if (6 * N <= 64)
         hipLaunchKernelGGL(ba_solve_kernel<true>, dim3(1), dim3(64), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
       else

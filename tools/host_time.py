@@ -32,4 +32,4 @@ if len(sys.argv) > 1:
     with torch.no_grad():
         for t in range(105, 165): slam(float(t), frames[t % 64], intr)
     pr.disable(); slam.flush(); torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats(sys.argv[1] if sys.argv[1] in ("tottime", "cumulative") else "cumulative").print_stats(45)
