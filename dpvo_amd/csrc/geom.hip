@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void motionmag_kernel(const float* __restrict
   block_reduce4(s, red, out);
 }
 
-// plan variant: the two frame pairs are looked up in the plan's sorted pair list (binary search) and only their
+// plan variant: the two frame pairs are looked up in the plan's pair list and only their
 // ~2 x 96 edges are touched (the scan above reads all E index triples: 60 us at E = 47 712 vs ~6 us here)
 __global__ __launch_bounds__(256) void motionmag_plan_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
                                                              const float* __restrict__ intr, const int64_t* __restrict__ kk,
@@ -290,18 +290,23 @@ __global__ __launch_bounds__(256) void motionmag_plan_kernel(const float* __rest
                                                              const int32_t* __restrict__ n_pairs, int P, int qi, int qj,
                                                              float beta, float* __restrict__ out) {
   __shared__ float red[4][1024];
+  __shared__ int found[2];
   const int ng = *n_pairs;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
+  // both pairs located by ONE parallel scan of the pair list (a binary search is ~9 dependent global round trips per
+  // pair: 12 of this kernel's 21 us); pairs are unique, so at most one thread writes each slot
+  if (threadIdx.x < 2) found[threadIdx.x] = -1;
+  __syncthreads();
+  for (int g = threadIdx.x; g < ng; g += blockDim.x) {
+    const int pi = pair_ij[2 * g], pj = pair_ij[2 * g + 1];
+    if (pi == qi && pj == qj) found[0] = g;
+    if (pi == qj && pj == qi) found[1] = g;
+  }
+  __syncthreads();
 #pragma unroll
   for (int dir = 0; dir < 2; ++dir) {
     const int a = dir ? qj : qi, b = dir ? qi : qj;
-    int lo = 0, hi = ng - 1, g = -1;
-    while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
-      const int pi = pair_ij[2 * mid], pj = pair_ij[2 * mid + 1];
-      if (pi == a && pj == b) { g = mid; break; }
-      if (pi < a || (pi == a && pj < b)) lo = mid + 1; else hi = mid - 1;
-    }
+    const int g = found[dir];
     if (g >= 0) {
       for (int p = pair_off[g] + threadIdx.x; p < pair_off[g + 1]; p += blockDim.x) {
         float f, v;
