@@ -27,13 +27,24 @@ SYMBOLS = [
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges",
-    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches",
+    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_pool4_nhwc",
 ]
 
 
 class DPVOHipError(RuntimeError):
     pass
+
+
+class FrameState(ctypes.Structure):
+    """dpvo_frame_state_t"""
+    _fields_ = ([(k, ctypes.c_void_p) for k in (
+        "fmap", "imap", "img_u8", "coords", "xs", "ys", "depth", "intrinsics", "gmap_slot", "imap_slot", "patches_slot",
+        "colors_slot", "intrinsics_slot", "index_row", "index_map", "poses", "patches_all", "fmap2_slot", "ii", "jj", "kk",
+        "net", "ix")] +
+        [(k, ctypes.c_int64) for k in ("frame_next", "m_next", "E0", "n_new")] +
+        [(k, ctypes.c_float) for k in ("res", "mm_scale")] +
+        [(k, ctypes.c_int32) for k in ("M", "h", "w", "H", "W", "CF", "CI", "P", "mm_n", "md_n", "ap_n", "ap_r", "D")])
 
 
 class PlanLayout(ctypes.Structure):
@@ -75,6 +86,11 @@ def ptr(t):
     if t is None:
         return ctypes.c_void_p(0)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def row_ptr(t, i):
+    """device pointer of t[i] without creating the view tensor (hot host paths)"""
+    return ctypes.c_void_p(t.data_ptr() + int(i) * t.stride(0) * t.element_size())
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if not int(__import__("os").environ.get("DPVO_SLOW_STREAM", "0")) else None

@@ -409,6 +409,20 @@ extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void
   return DPVO_OK;
 }
 
+extern "C" int dpvo_frame_state(dpvo_frame_state_t* p, void* stream) {
+  if (!p) return DPVO_E_INVALID;
+  int rc = dpvo_frame_patches(p->fmap, p->imap, p->img_u8, p->coords, p->xs, p->ys, p->depth, p->intrinsics, p->res,
+                              p->gmap_slot, p->imap_slot, p->patches_slot, p->colors_slot, p->intrinsics_slot, p->index_row,
+                              p->index_map, nullptr, p->M, p->h, p->w, p->H, p->W, p->CF, p->CI, p->P, p->frame_next, p->m_next,
+                              stream);
+  if (rc == DPVO_OK && p->poses) rc = dpvo_motion_model(p->poses, p->mm_n, p->mm_scale, stream);
+  if (rc == DPVO_OK && p->patches_all) rc = dpvo_median_depth(p->patches_all, p->md_n, p->M, p->P, stream);
+  if (rc == DPVO_OK && p->fmap2_slot) rc = dpvo_pool4_nhwc(p->fmap, p->fmap2_slot, p->h, p->w, p->CF, stream);
+  if (rc == DPVO_OK && p->ii) rc = dpvo_append_edges(p->ii, p->jj, p->kk, p->net, p->ix, p->E0, p->ap_n, p->M, p->ap_r, p->D,
+                                                    &p->n_new, stream);
+  return rc;
+}
+
 extern "C" int dpvo_motion_model(float* poses, int n, float scale, void* stream) {
   if (!poses || n < 2) return DPVO_E_INVALID;
   hipLaunchKernelGGL(motion_model_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, poses, n, scale);

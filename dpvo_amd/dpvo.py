@@ -9,6 +9,8 @@ MI355X-first differences (results unchanged):
     BA, sharing ONE device-built graph plan per frame (instead of ~150 launches and ~10 host syncs);
   * the per-edge hidden state `pg.net` is float32 from the start.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -45,6 +47,7 @@ class DPVO:
         self.overlap_encoders = bool(overlap_encoders)
         self._enc_stream = None
         self._fp_done = None
+        self._fs = None             # dpvo_frame_state_t, reused
         self._kf_pending = None
         self._mm_host = None
         self.device = torch.device(device)
@@ -496,7 +499,8 @@ class DPVO:
         image_u8 = image.contiguous()
         H, W = image_u8.shape[-2:]
         hip_enc = self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM'
-        side = None
+        side = pre_rng = None
+        appended = False
         if hip_enc and self.overlap_encoders:
             if self._enc_stream is None:
                 self._enc_stream = torch.cuda.Stream(device=self.device)
@@ -518,6 +522,14 @@ class DPVO:
                     self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
                 self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
                 if side is not None:
+                    if patch_coords is None and depth_init is None and self.P == 3:
+                        # the frame's three random draws (same generator order as below) do not depend on anything either
+                        hh, ww = slot.shape[:2]
+                        pre_rng = (torch.randint(1, ww - 1, size=[1, self.M], device=self.device),
+                                   torch.randint(1, hh - 1, size=[1, self.M], device=self.device),
+                                   torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device))
+                        for t_ in pre_rng:
+                            t_.record_stream(main_stream)        # allocated on the side stream, read on the main one
                     enc_done = torch.cuda.Event()
                     enc_done.record(side)
         if hip_enc:
@@ -537,45 +549,84 @@ class DPVO:
             # draws are the reference's own, in its order: randint x, randint y (net.py:132-133), rand depth (dpvo.py:427)
             hh, ww = maps[0].shape[:2]
             xs = ys = cdev = None
-            if patch_coords is None:
-                xs = torch.randint(1, ww - 1, size=[1, self.M], device=self.device)
-                ys = torch.randint(1, hh - 1, size=[1, self.M], device=self.device)
+            if pre_rng is not None:
+                xs, ys, depth = pre_rng
             else:
-                cdev = patch_coords.reshape(self.M, 2).to(device=self.device, dtype=torch.float32).contiguous()
-            if depth_init is None:
-                depth = torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device)
-            else:
-                depth = depth_init.reshape(self.M).to(device=self.device, dtype=torch.float32).contiguous()
+                if patch_coords is None:
+                    xs = torch.randint(1, ww - 1, size=[1, self.M], device=self.device)
+                    ys = torch.randint(1, hh - 1, size=[1, self.M], device=self.device)
+                else:
+                    cdev = patch_coords.reshape(self.M, 2).to(device=self.device, dtype=torch.float32).contiguous()
+                if depth_init is None:
+                    depth = torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device)
+                else:
+                    depth = depth_init.reshape(self.M).to(device=self.device, dtype=torch.float32).contiguous()
             self.tlist.append(tstamp)
             self.pg.tstamps_[self.n] = self.counter
             intr_dev = intrinsics if (torch.is_tensor(intrinsics) and intrinsics.is_cuda and
                                       intrinsics.dtype == torch.float32 and intrinsics.is_contiguous()) else None
             if intr_dev is None:
                 self.pg.intrinsics_[self.n] = intrinsics / self.RES
-            L.check(L.lib().dpvo_frame_patches(
-                L.ptr(maps[0]), L.ptr(maps[1]), L.ptr(image_u8), L.ptr(cdev), L.ptr(xs), L.ptr(ys), L.ptr(depth),
-                L.ptr(intr_dev), L.f32(self.RES), L.ptr(self._gmap_cl[self.n % self.pmem]),
-                L.ptr(self.imap_[self.n % self.pmem]), L.ptr(self.pg.patches_[self.n]), L.ptr(self.pg.colors_[self.n]),
-                L.ptr(self.pg.intrinsics_[self.n]) if intr_dev is not None else L.ptr(None),
-                L.ptr(self.pg.index_[self.n + 1]), L.ptr(self.pg.index_map_[self.n + 1:self.n + 2]), L.ptr(None),
-                L.i32(self.M), L.i32(hh), L.i32(ww), L.i32(H), L.i32(W), L.i32(128), L.i32(self.DIM), L.i32(self.P),
-                L.i64(self.n + 1), L.i64(self.m + self.M), L.stream()), "dpvo_frame_patches")
-            if self.n > 1:
-                if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                    *_, a, b, c = [1] * 3 + self.tlist
-                    fac = (c - b) / (b - a)
-                    L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
-                                                      L.f32(self.cfg.MOTION_DAMPING * fac), L.stream()), "dpvo_motion_model")
-                else:
-                    self.pg.poses_[self.n] = self.poses[self.n - 1]
-            if self.is_initialized:
-                if 3 * self.M * self.P * self.P <= 4096:
-                    L.check(L.lib().dpvo_median_depth(L.ptr(self.pg.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.P),
-                                                      L.stream()), "dpvo_median_depth")
-                else:
-                    self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
-            L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.ptr(self._fmap2_cl[self.n % self.mem]), L.i32(hh), L.i32(ww),
-                                            L.i32(128), L.stream()), "dpvo_pool4_nhwc")
+            n = self.n
+            # steady state: patch gathers + state stores, motion model, depth median, pyramid level 1 and the new frame's
+            # edges as ONE C-ABI call (dpvo_frame_state); otherwise the same entries one by one
+            composite = (self.is_initialized and not self.cfg.LOOP_CLOSURE and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR'
+                         and n > 1 and 3 * self.M * self.P * self.P <= 4096)
+            fac = None
+            if n > 1 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
+                *_, a, b, c = [1] * 3 + self.tlist
+                fac = (c - b) / (b - a)
+            if composite:
+                es = self.pg.edges
+                total = es.frame_edge_count(n + 1, self.M, self.cfg.PATCH_LIFETIME)
+                es.reserve(total)
+                fs = self._fs
+                if fs is None:
+                    fs = self._fs = L.FrameState()
+                dp = lambda t: None if t is None else t.data_ptr()
+                rp = lambda t, i: t.data_ptr() + int(i) * t.stride(0) * t.element_size()
+                fs.fmap, fs.imap, fs.img_u8, fs.coords = dp(maps[0]), dp(maps[1]), dp(image_u8), dp(cdev)
+                fs.xs, fs.ys, fs.depth, fs.intrinsics = dp(xs), dp(ys), dp(depth), dp(intr_dev)
+                fs.gmap_slot, fs.imap_slot = rp(self._gmap_cl, n % self.pmem), rp(self.imap_, n % self.pmem)
+                fs.patches_slot, fs.colors_slot = rp(self.pg.patches_, n), rp(self.pg.colors_, n)
+                fs.intrinsics_slot = rp(self.pg.intrinsics_, n) if intr_dev is not None else None
+                fs.index_row, fs.index_map = rp(self.pg.index_, n + 1), rp(self.pg.index_map_, n + 1)
+                fs.poses, fs.mm_n, fs.mm_scale = dp(self.pg.poses_), n, self.cfg.MOTION_DAMPING * fac
+                fs.patches_all, fs.md_n = dp(self.pg.patches_), n
+                fs.fmap2_slot = rp(self._fmap2_cl, n % self.mem)
+                fs.ii, fs.jj, fs.kk, fs.net, fs.ix = dp(es.a["ii"]), dp(es.a["jj"]), dp(es.a["kk"]), dp(es.a["net"]), dp(self.ix)
+                fs.frame_next, fs.m_next, fs.E0, fs.n_new = n + 1, self.m + self.M, es.E, 0
+                fs.res = self.RES
+                fs.M, fs.h, fs.w, fs.H, fs.W, fs.CF, fs.CI, fs.P = self.M, hh, ww, H, W, 128, self.DIM, self.P
+                fs.ap_n, fs.ap_r, fs.D = n + 1, self.cfg.PATCH_LIFETIME, es.D
+                L.check(L.lib().dpvo_frame_state(ctypes.byref(fs), L.stream()), "dpvo_frame_state")
+                assert fs.n_new == total
+                es.appended_frame(n + 1, self.M, self.cfg.PATCH_LIFETIME, total)
+                self._plan = None
+                appended = True
+            else:
+                L.check(L.lib().dpvo_frame_patches(
+                    L.ptr(maps[0]), L.ptr(maps[1]), L.ptr(image_u8), L.ptr(cdev), L.ptr(xs), L.ptr(ys), L.ptr(depth),
+                    L.ptr(intr_dev), L.f32(self.RES), L.row_ptr(self._gmap_cl, n % self.pmem),
+                    L.row_ptr(self.imap_, n % self.pmem), L.row_ptr(self.pg.patches_, n), L.row_ptr(self.pg.colors_, n),
+                    L.row_ptr(self.pg.intrinsics_, n) if intr_dev is not None else L.ptr(None),
+                    L.row_ptr(self.pg.index_, n + 1), L.row_ptr(self.pg.index_map_, n + 1), L.ptr(None),
+                    L.i32(self.M), L.i32(hh), L.i32(ww), L.i32(H), L.i32(W), L.i32(128), L.i32(self.DIM), L.i32(self.P),
+                    L.i64(self.n + 1), L.i64(self.m + self.M), L.stream()), "dpvo_frame_patches")
+                if self.n > 1:
+                    if fac is not None:
+                        L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
+                                                          L.f32(self.cfg.MOTION_DAMPING * fac), L.stream()), "dpvo_motion_model")
+                    else:
+                        self.pg.poses_[self.n] = self.poses[self.n - 1]
+                if self.is_initialized:
+                    if 3 * self.M * self.P * self.P <= 4096:
+                        L.check(L.lib().dpvo_median_depth(L.ptr(self.pg.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.P),
+                                                          L.stream()), "dpvo_median_depth")
+                    else:
+                        self.pg.patches_[self.n, :, 2] = torch.median(self.pg.patches_[self.n - 3:self.n, :, 2])
+                L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.row_ptr(self._fmap2_cl, self.n % self.mem), L.i32(hh), L.i32(ww),
+                                                L.i32(128), L.stream()), "dpvo_pool4_nhwc")
             if self.overlap_encoders:
                 self._fp_done = torch.cuda.Event()
                 self._fp_done.record()
@@ -659,7 +710,8 @@ class DPVO:
                     self.append_factors(lii, ljj)
 
         # Add forward and backward factors
-        self.append_frame_factors()
+        if not appended:
+            self.append_frame_factors()
 
         if self.n == 8 and not self.is_initialized:
             self.is_initialized = True

@@ -22,15 +22,8 @@ class GraphPlan:
         self.E = E
         lay = L.plan_layout(E)
         self.buf = torch.empty(lay.total_ints, dtype=torch.int32, device=ii.device)
-        n = max(E, 1)
-        v = lambda off, cnt: self.buf[off:off + cnt]
-        self.perm_k, self.ku, self.kx = v(lay.perm_k, n), v(lay.ku, n), v(lay.kx, n)
-        self.patch_off = v(lay.patch_off, n + 1)
-        self.ix, self.jx = v(lay.ix, n), v(lay.jx, n)
-        self.perm_p, self.pu = v(lay.perm_p, n), v(lay.pu, n)
-        self.pair_off = v(lay.pair_off, n + 1)
-        self.pair_ij = v(lay.pair_ij, 2 * n)
-        self.counts = v(lay.counts, 4)
+        self._lay = lay         # the views (perm_k, ku, kx, patch_off, ix, jx, perm_p, pu, pair_off, pair_ij, counts) are
+        #                         created on first use: the hot path only hands `buf` to the C ABI
         ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
         self._keep = (ii, jj, kk)
         nbytes = L.lib().dpvo_plan_workspace_bytes(L.i64(E))
@@ -51,6 +44,22 @@ class GraphPlan:
             c = self.counts[:2].tolist()
             self.n_patches_host, self.n_pairs_host = int(c[0]), int(c[1])
             self.exact = True
+
+    _VIEWS = {"perm_k": 1, "ku": 1, "kx": 1, "patch_off": (1, 1), "ix": 1, "jx": 1, "perm_p": 1, "pu": 1, "pair_off": (1, 1),
+              "pair_ij": 2}
+
+    def __getattr__(self, name):
+        if name == "counts":
+            v = self.buf[self._lay.counts:self._lay.counts + 4]
+        elif name in GraphPlan._VIEWS:
+            n, mul = max(self.E, 1), GraphPlan._VIEWS[name]
+            cnt = n + 1 if isinstance(mul, tuple) else mul * n
+            off = getattr(self._lay, name)
+            v = self.buf[off:off + cnt]
+        else:
+            raise AttributeError(name)
+        setattr(self, name, v)
+        return v
 
     def n_patches(self):
         return self.n_patches_host if self.exact else int(self.counts[0].item())

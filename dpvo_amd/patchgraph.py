@@ -3,6 +3,8 @@
 Differences that do not change results: `net` is kept in float32 (the reference's torch.cat promotes it to
 float32 after the first update anyway, dpvo.py:220 + net.py:78); index tensors stay int64 on the device.
 `reduce_edges` (numba in the reference, loop_closure/optim_utils.py:23-60) is restated in plain numpy/Python."""
+import ctypes
+
 import numpy as np
 import torch
 
@@ -31,8 +33,10 @@ class EdgeStore:
         self._h = None if not mirror else {k: np.empty(cap, dtype=np.int32) for k in ("ii", "jj", "kk")}
         self._hE = 0
         self._log = []
-        self._stage = None          # pinned / device index staging buffers (ping-pong)
+        self._stage = None          # pinned / device index staging buffers (ring of 4) + their copy stream
         self._stage_flip = 0
+        self._staged = {}           # device staging buffer -> its copy event, between stage_indices and the gather that reads it
+        self._gathered = None       # recorded on the compute stream after a gather that read staged indices
 
     def _new(self, cap):
         d = {k: torch.empty(cap, dtype=torch.long, device=self.dev) for k in ("ii", "jj", "kk")}
@@ -109,17 +113,29 @@ class EdgeStore:
             self._h, self._log = None, []
 
     def stage_indices(self, idx_np):
-        """host int64 indices -> device tensor, through pinned memory, without blocking the host"""
+        """host int64 indices -> device tensor, through pinned memory, without blocking the host.  The copy is issued on a
+        dedicated copy stream, so it runs as soon as the host has the list (while the compute stream is still busy with the
+        current frame) instead of queueing behind it.  Ordering: the consumer (gather_into) waits for the copy's event if it
+        has not completed yet; the copy stream waits for the last compaction (`keep`) before it rewrites a staging buffer."""
         n = int(idx_np.size)
         if self._stage is None:
-            mk = lambda: (torch.empty(self.cap, dtype=torch.int64).pin_memory(),
-                          torch.empty(self.cap, dtype=torch.int64, device=self.dev))
+            mk = lambda: {"pin": torch.empty(self.cap, dtype=torch.int64).pin_memory(),
+                          "dev": torch.empty(self.cap, dtype=torch.int64, device=self.dev), "copied": torch.cuda.Event()}
             self._stage = [mk() for _ in range(4)]
-        pin, dev = self._stage[self._stage_flip]
+            self._copy_stream = torch.cuda.Stream(device=self.dev)
+            self._staged = {}
+        st = self._stage[self._stage_flip]
         self._stage_flip = (self._stage_flip + 1) % len(self._stage)
-        pin[:n].numpy()[:] = idx_np
-        dev[:n].copy_(pin[:n], non_blocking=True)
-        return dev[:n]
+        st["copied"].synchronize()                   # the previous copy out of this pinned buffer (two frames ago)
+        st["pin"][:n].numpy()[:] = idx_np
+        cs = self._copy_stream
+        if self._gathered is not None:
+            cs.wait_event(self._gathered)
+        with torch.cuda.stream(cs):
+            st["dev"][:n].copy_(st["pin"][:n], non_blocking=True)
+            st["copied"].record(cs)
+        self._staged[st["dev"].data_ptr()] = st["copied"]
+        return st["dev"][:n]
 
     def view(self, name):
         return self.a[name][:self.E]
@@ -133,20 +149,27 @@ class EdgeStore:
         if name in ("ii", "jj", "kk"):
             self.invalidate_host()
 
+    @staticmethod
+    def frame_edge_count(n, M, r):
+        """number of edges append_factors(edges_forw) + append_factors(edges_back) add for frame count n (dpvo.py:362-375)"""
+        return M * (max(n - 1, 0) - max(n - r, 0)) + M * (n - max(n - r, 0))
+
+    def appended_frame(self, n, M, r, total):
+        """bookkeeping after the kernel of append_frame has been issued (by append_frame or inside dpvo_frame_state)"""
+        if self._h is not None:
+            self._log.append(("frame", n, M, r))
+        self.E += total
+
     def append_frame(self, ix, n, M, r):
         """append_factors(edges_forw) + append_factors(edges_back) for frame count n: one kernel"""
-        import ctypes
-        nf = M * (max(n - 1, 0) - max(n - r, 0))
-        total = nf + M * (n - max(n - r, 0))
+        total = self.frame_edge_count(n, M, r)
         self.reserve(total)
         cnt = ctypes.c_int64(0)
         L.check(L.lib().dpvo_append_edges(L.ptr(self.a["ii"]), L.ptr(self.a["jj"]), L.ptr(self.a["kk"]),
                                           L.ptr(self.a["net"]), L.ptr(ix), L.i64(self.E), L.i32(n), L.i32(M), L.i32(r),
                                           L.i32(self.D), ctypes.byref(cnt), L.stream()), "dpvo_append_edges")
         assert cnt.value == total
-        if self._h is not None:
-            self._log.append(("frame", n, M, r))
-        self.E += total
+        self.appended_frame(n, M, r, total)
 
     def append(self, ii, jj, kk, net=None, target=None, weight=None):
         n = ii.numel()
@@ -170,13 +193,24 @@ class EdgeStore:
     def gather_into(self, idx, dst, dst_off):
         """dst arrays [dst_off : dst_off+len(idx)] = self arrays[idx] (one kernel)"""
         n = idx.numel()
-        o = lambda t: None if t is None else t[dst_off:]
+        copied = self._staged.pop(idx.data_ptr(), None) if (n and self._staged) else None
+        if copied is not None and not copied.query():
+            # indices staged by stage_indices whose copy has not finished yet (normally it finished a frame ago: a cross-
+            # stream wait costs ~15 us of queue time on this platform, so it is only inserted when needed)
+            torch.cuda.current_stream(self.dev).wait_event(copied)
+        # (raw pointer arithmetic instead of tensor slices: this call sits in the host-paced start of a frame)
+        vp = ctypes.c_void_p
+        src, has_net = self.a, dst.get("net") is not None
+        o = lambda t, row_bytes: vp(t.data_ptr() + dst_off * row_bytes)
         L.check(L.lib().dpvo_gather_edges(
-            L.ptr(idx), L.i64(n), L.ptr(self.a["ii"]), L.ptr(self.a["jj"]), L.ptr(self.a["kk"]),
-            L.ptr(self.a.get("net")) if dst.get("net") is not None else L.ptr(None), L.ptr(self.a["target"]),
-            L.ptr(self.a["weight"]), L.ptr(o(dst["ii"])), L.ptr(o(dst["jj"])), L.ptr(o(dst["kk"])),
-            L.ptr(o(dst.get("net"))), L.ptr(o(dst["target"])), L.ptr(o(dst["weight"])), L.i32(self.D), L.stream()),
-            "dpvo_gather_edges")
+            vp(idx.data_ptr()), ctypes.c_int64(n), vp(src["ii"].data_ptr()), vp(src["jj"].data_ptr()), vp(src["kk"].data_ptr()),
+            vp(src["net"].data_ptr()) if has_net else vp(0), vp(src["target"].data_ptr()), vp(src["weight"].data_ptr()),
+            o(dst["ii"], 8), o(dst["jj"], 8), o(dst["kk"], 8), o(dst["net"], 4 * self.D) if has_net else vp(0),
+            o(dst["target"], 8), o(dst["weight"], 8), ctypes.c_int(self.D), L.stream()), "dpvo_gather_edges")
+        if copied is not None:                       # the staging buffers may be rewritten once this gather has run
+            if self._gathered is None:
+                self._gathered = torch.cuda.Event()
+            self._gathered.record()
 
     def keep(self, idx, idx_host=None):
         """compact to the edges listed in idx (sorted ascending), ping-pong buffers.  idx_host: the same indices as a numpy

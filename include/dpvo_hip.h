@@ -273,6 +273,25 @@ int dpvo_motion_model(float* poses, int n, float scale, void* stream);
 /* depth initialisation (dpvo.py:430-432): patches[n][:,2] = torch.median(patches[n-3:n,:,2]) (lower median). */
 int dpvo_median_depth(float* patches, int n, int M, int P, void* stream);
 
+/* Everything a tracked frame does between the encoders and the plan, as ONE call (the launches are those of the entries
+ * named below, in this order; this part of a frame is paced by the host, so one marshalling instead of five matters):
+ *   dpvo_frame_patches (always) -> dpvo_motion_model (poses != NULL) -> dpvo_median_depth (patches_all != NULL)
+ *   -> dpvo_pool4_nhwc (fmap2_slot != NULL) -> dpvo_append_edges (ii != NULL; n_new receives the number of edges). */
+typedef struct {
+  const void *fmap, *imap, *img_u8;               /* dpvo_frame_patches */
+  const float* coords; const int64_t *xs, *ys; const float *depth, *intrinsics;
+  void *gmap_slot, *imap_slot; float* patches_slot; void* colors_slot; float* intrinsics_slot;
+  int64_t *index_row, *index_map;
+  float* poses;                                   /* dpvo_motion_model(poses, mm_n, mm_scale) */
+  float* patches_all;                             /* dpvo_median_depth(patches_all, md_n, M, P) */
+  void* fmap2_slot;                               /* dpvo_pool4_nhwc(fmap, fmap2_slot, h, w, CF) */
+  int64_t *ii, *jj, *kk; float* net; const int64_t* ix;   /* dpvo_append_edges(..., E0, ap_n, M, ap_r, D, &n_new) */
+  int64_t frame_next, m_next, E0, n_new;
+  float res, mm_scale;
+  int32_t M, h, w, H, W, CF, CI, P, mm_n, md_n, ap_n, ap_r, D;
+} dpvo_frame_state_t;
+int dpvo_frame_state(dpvo_frame_state_t* p, void* stream);
+
 /* The whole update operator (dpvo/net.py:74-92, Update.forward) as one call: exactly the launch sequence a host would
  * issue through dpvo_linear / dpvo_layernorm / dpvo_softagg / dpvo_gather_add / dpvo_heads_target.  Weight images (f16
  * unless noted; the host packs them once, see dpvo_amd/net.py:Update.pack):

@@ -146,3 +146,65 @@ def test_frame_patches_matches_patchifier_composition(dev, mode):
                                        nul, nul, nul, nul, nul, nul, *dims), "dpvo_frame_patches")
     assert torch.equal(gmap2, ref_gmap) and torch.equal(im2, ref_imap)
     assert L.lib().dpvo_frame_patches(nul, nul, nul, cc, *xy, nul, nul, L.f32(4.0), nul, nul, nul, nul, nul, nul, nul, nul, *dims) < 0
+
+
+def test_frame_state_composite_equals_separate_entries(dev):
+    """dpvo_frame_state == dpvo_frame_patches + dpvo_motion_model + dpvo_median_depth + dpvo_pool4_nhwc + dpvo_append_edges"""
+    import ctypes
+    g = torch.Generator().manual_seed(11)
+    H, W, M, CF, CI, n, r, D = 96, 128, 16, 128, 384, 9, 13, 384
+    h, w = H // 4, W // 4
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8).to(dev)
+    fmap = (torch.randn(h, w, CF, generator=g) / 2).half().to(dev)
+    imap = (torch.randn(h, w, CI, generator=g) / 2).half().to(dev)
+    xs = torch.randint(1, w - 1, (1, M), generator=g).to(dev); ys = torch.randint(1, h - 1, (1, M), generator=g).to(dev)
+    depth = torch.rand(M, generator=g).to(dev)
+    intr = torch.tensor([320.0, 321.0, 64.0, 48.0], device=dev)
+    poses0 = torch.randn(16, 7, generator=g); poses0[:, 3:] /= poses0[:, 3:].norm(dim=1, keepdim=True)
+    patches0 = torch.rand(16, M, 3, 3, 3, generator=g)
+    ix = (torch.arange(16 * M) // M).to(dev)
+    E0 = 37
+
+    def run(composite):
+        st = dict(gmap=torch.zeros(M, 3, 3, CF, dtype=torch.float16, device=dev), im=torch.zeros(M, CI, dtype=torch.float16, device=dev),
+                  colors=torch.zeros(M, 3, dtype=torch.uint8, device=dev), intr_o=torch.zeros(4, device=dev),
+                  idx_row=torch.zeros(M, dtype=torch.long, device=dev), idx_map=torch.zeros(1, dtype=torch.long, device=dev),
+                  poses=poses0.clone().to(dev), patches=patches0.clone().to(dev), f2=torch.zeros(h // 4, w // 4, CF, dtype=torch.float16, device=dev),
+                  ii=torch.zeros(4000, dtype=torch.long, device=dev), jj=torch.zeros(4000, dtype=torch.long, device=dev),
+                  kk=torch.zeros(4000, dtype=torch.long, device=dev), net=torch.ones(4000, D, device=dev))
+        if composite:
+            fs = L.FrameState()
+            dp = lambda t: t.data_ptr()
+            fs.fmap, fs.imap, fs.img_u8, fs.xs, fs.ys, fs.depth, fs.intrinsics = dp(fmap), dp(imap), dp(img), dp(xs), dp(ys), dp(depth), dp(intr)
+            fs.gmap_slot, fs.imap_slot, fs.patches_slot, fs.colors_slot = dp(st["gmap"]), dp(st["im"]), dp(st["patches"][n]), dp(st["colors"])
+            fs.intrinsics_slot, fs.index_row, fs.index_map = dp(st["intr_o"]), dp(st["idx_row"]), dp(st["idx_map"])
+            fs.poses, fs.mm_n, fs.mm_scale = dp(st["poses"]), n, 0.5
+            fs.patches_all, fs.md_n, fs.fmap2_slot = dp(st["patches"]), n, dp(st["f2"])
+            fs.ii, fs.jj, fs.kk, fs.net, fs.ix = dp(st["ii"]), dp(st["jj"]), dp(st["kk"]), dp(st["net"]), dp(ix)
+            fs.frame_next, fs.m_next, fs.E0, fs.res = n + 1, (n + 1) * M, E0, 4.0
+            fs.M, fs.h, fs.w, fs.H, fs.W, fs.CF, fs.CI, fs.P, fs.ap_n, fs.ap_r, fs.D = M, h, w, H, W, CF, CI, 3, n + 1, r, D
+            L.check(L.lib().dpvo_frame_state(ctypes.byref(fs), L.stream()), "dpvo_frame_state")
+            st["n_new"] = fs.n_new
+        else:
+            nul = L.ptr(None)
+            L.check(L.lib().dpvo_frame_patches(
+                L.ptr(fmap), L.ptr(imap), L.ptr(img), nul, L.ptr(xs), L.ptr(ys), L.ptr(depth), L.ptr(intr), L.f32(4.0), L.ptr(st["gmap"]),
+                L.ptr(st["im"]), L.ptr(st["patches"][n]), L.ptr(st["colors"]), L.ptr(st["intr_o"]), L.ptr(st["idx_row"]), L.ptr(st["idx_map"]),
+                nul, L.i32(M), L.i32(h), L.i32(w), L.i32(H), L.i32(W), L.i32(CF), L.i32(CI), L.i32(3), L.i64(n + 1), L.i64((n + 1) * M),
+                L.stream()), "dpvo_frame_patches")
+            L.check(L.lib().dpvo_motion_model(L.ptr(st["poses"]), L.i32(n), L.f32(0.5), L.stream()), "dpvo_motion_model")
+            L.check(L.lib().dpvo_median_depth(L.ptr(st["patches"]), L.i32(n), L.i32(M), L.i32(3), L.stream()), "dpvo_median_depth")
+            L.check(L.lib().dpvo_pool4_nhwc(L.ptr(fmap), L.ptr(st["f2"]), L.i32(h), L.i32(w), L.i32(CF), L.stream()), "dpvo_pool4_nhwc")
+            cnt = ctypes.c_int64(0)
+            L.check(L.lib().dpvo_append_edges(L.ptr(st["ii"]), L.ptr(st["jj"]), L.ptr(st["kk"]), L.ptr(st["net"]), L.ptr(ix), L.i64(E0),
+                                              L.i32(n + 1), L.i32(M), L.i32(r), L.i32(D), ctypes.byref(cnt), L.stream()), "dpvo_append_edges")
+            st["n_new"] = cnt.value
+        torch.cuda.synchronize()
+        return st
+
+    a, b = run(False), run(True)
+    assert a["n_new"] == b["n_new"] > 0
+    for k in a:
+        if k != "n_new":
+            assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["poses"][n].cpu(), poses0[n]) and not torch.equal(a["patches"][n].cpu(), patches0[n])
