@@ -26,7 +26,7 @@ SYMBOLS = [
     "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target", "dpvo_update_workspace_bytes", "dpvo_update_forward",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
-    "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges",
+    "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
     "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_pool4_nhwc",
 ]

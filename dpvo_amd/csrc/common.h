@@ -29,3 +29,29 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// F.avg_pool2d(fmap, 4, 4) on an NHWC f16 map, 8 channels per thread (shared by encoder.hip and the fused frame kernel)
+__device__ __forceinline__ void pool4_nhwc_body(const _Float16* __restrict__ in, _Float16* __restrict__ out, int h, int w, int C,
+                                                 int64_t bid, int64_t nblk) {
+  const int h4 = h / 4, w4 = w / 4, c8 = C / 8;
+  const int64_t total = (int64_t)h4 * w4 * c8;
+  for (int64_t q = bid * (int64_t)blockDim.x + threadIdx.x; q < total; q += nblk * blockDim.x) {
+    const int ch = (int)(q % c8);
+    const int64_t pix = q / c8;
+    const int px = (int)(pix % w4), py = (int)(pix / w4);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const h8 v = *reinterpret_cast<const h8*>(in + ((int64_t)(py * 4 + a) * w + px * 4 + b) * C + ch * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+      }
+    h8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] / 16.0f);
+    *reinterpret_cast<h8*>(out + pix * C + ch * 8) = o;
+  }
+}
+

@@ -380,26 +380,7 @@ int launch_conv(const EncArgs& a, int Hin, int Win, int Hout, int Wout, int n_pa
 
 // 4x4 average pooling of an NHWC map (dpvo.py:438: fmap2_ = F.avg_pool2d(fmap, 4, 4)), f32 accumulate, one rounding
 __global__ void pool4_nhwc_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int h, int w, int C) {
-  const int h4 = h / 4, w4 = w / 4, c8 = C / 8;
-  const int64_t total = (int64_t)h4 * w4 * c8;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(q % c8);
-    const int64_t pix = q / c8;
-    const int px = (int)(pix % w4), py = (int)(pix / w4);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const h8 v = *reinterpret_cast<const h8*>(in + ((int64_t)(py * 4 + a) * w + px * 4 + b) * C + ch * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
-      }
-    h8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] / 16.0f);
-    *reinterpret_cast<h8*>(out + pix * C + ch * 8) = o;
-  }
+  pool4_nhwc_body(in, out, h, w, C, blockIdx.x, gridDim.x);
 }
 
 }  // namespace

@@ -84,17 +84,17 @@ __global__ __launch_bounds__(256) void store_features_kernel(const T* __restrict
 
 // ---- new edges of a frame (append_factors(edges_forw) + append_factors(edges_back), dpvo.py:215-221,362-375,458-459):
 //      writes kk, jj, ii = ix[kk] for the n_forw + n_back new edges and zeroes their hidden state rows ---------------
-__global__ void append_edges_kernel(int64_t* __restrict__ ii, int64_t* __restrict__ jj, int64_t* __restrict__ kk,
-                                    float* __restrict__ net, const int64_t* __restrict__ ix, int64_t E0, int n, int M,
-                                    int r, int D) {
+__device__ __forceinline__ void append_edges_body(int64_t* __restrict__ ii, int64_t* __restrict__ jj, int64_t* __restrict__ kk,
+                                                  float* __restrict__ net, const int64_t* __restrict__ ix, int64_t E0, int n,
+                                                  int M, int r, int D, int64_t bid, int64_t nblk) {
   // forw: kk in [M*max(n-r,0), M*max(n-1,0)), jj = n-1 (kk-major);  back: kk in [M*(n-1), M*n) x jj in [max(n-r,0), n)
   const int64_t f0 = (int64_t)M * max(n - r, 0), f1 = (int64_t)M * max(n - 1, 0);
   const int64_t nf = f1 - f0;
   const int jlo = max(n - r, 0), nj = n - jlo;
   const int64_t nb = (int64_t)M * nj;
   const int64_t total = nf + nb;
-  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  for (int64_t e = gt; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t gt = bid * (int64_t)blockDim.x + threadIdx.x;
+  for (int64_t e = gt; e < total; e += nblk * blockDim.x) {
     int64_t k, j;
     if (e < nf) { k = f0 + e; j = n - 1; }
     else { const int64_t q = e - nf; k = (int64_t)M * max(n - 1, 0) + q / nj; j = jlo + q % nj; }
@@ -102,31 +102,47 @@ __global__ void append_edges_kernel(int64_t* __restrict__ ii, int64_t* __restric
   }
   const int64_t nn = total * (D / 4);
   f4* np = reinterpret_cast<f4*>(net + E0 * D);
-  for (int64_t q = gt; q < nn; q += (int64_t)gridDim.x * blockDim.x) np[q] = (f4)0.f;
+  for (int64_t q = gt; q < nn; q += nblk * blockDim.x) np[q] = (f4)0.f;
+}
+__global__ void append_edges_kernel(int64_t* __restrict__ ii, int64_t* __restrict__ jj, int64_t* __restrict__ kk,
+                                    float* __restrict__ net, const int64_t* __restrict__ ix, int64_t E0, int n, int M,
+                                    int r, int D) {
+  append_edges_body(ii, jj, kk, net, ix, E0, n, M, r, D, blockIdx.x, gridDim.x);
 }
 
 // ---- edge compaction: dst[t] = src[idx[t]] for the six per-edge arrays (remove_factors, dpvo.py:223-238) ----------
-__global__ void gather_edges_kernel(const int64_t* __restrict__ idx, int64_t n, const int64_t* __restrict__ ii,
-                                    const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
-                                    const float* __restrict__ net, const float* __restrict__ target,
-                                    const float* __restrict__ weight, int64_t* __restrict__ oii, int64_t* __restrict__ ojj,
-                                    int64_t* __restrict__ okk, float* __restrict__ onet, float* __restrict__ otarget,
-                                    float* __restrict__ oweight, int D) {
-  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+struct GatherArgs {
+  const int64_t* idx; int64_t n;
+  int64_t *oii, *ojj, *okk; float *onet, *otarget, *oweight;
+};
+__device__ __forceinline__ void gather_edges_body(const GatherArgs& G, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                                  const int64_t* __restrict__ kk, const float* __restrict__ net,
+                                                  const float* __restrict__ target, const float* __restrict__ weight, int D,
+                                                  int64_t bid, int64_t nblk) {
+  const int64_t gt = bid * (int64_t)blockDim.x + threadIdx.x, gs = nblk * blockDim.x;
+  const int64_t* __restrict__ idx = G.idx;
+  const int64_t n = G.n;
   for (int64_t t = gt; t < n; t += gs) {
     const int64_t s = idx[t];
-    oii[t] = ii[s]; ojj[t] = jj[s]; okk[t] = kk[s];
-    if (otarget) { otarget[2 * t] = target[2 * s]; otarget[2 * t + 1] = target[2 * s + 1]; }
-    if (oweight) { oweight[2 * t] = weight[2 * s]; oweight[2 * t + 1] = weight[2 * s + 1]; }
+    G.oii[t] = ii[s]; G.ojj[t] = jj[s]; G.okk[t] = kk[s];
+    if (G.otarget) { G.otarget[2 * t] = target[2 * s]; G.otarget[2 * t + 1] = target[2 * s + 1]; }
+    if (G.oweight) { G.oweight[2 * t] = weight[2 * s]; G.oweight[2 * t + 1] = weight[2 * s + 1]; }
   }
-  if (onet) {
+  if (G.onet) {
     const int dq = D / 4;
     for (int64_t q = gt; q < n * dq; q += gs) {
       const int64_t t = q / dq;
       const int c = (int)(q - t * dq);
-      reinterpret_cast<f4*>(onet)[t * dq + c] = reinterpret_cast<const f4*>(net)[idx[t] * dq + c];
+      reinterpret_cast<f4*>(G.onet)[t * dq + c] = reinterpret_cast<const f4*>(net)[idx[t] * dq + c];
     }
   }
+}
+// one or two gather jobs from the same source arrays in one launch (blocks [0, nblkA) do job A, the rest job B)
+__global__ void gather_edges_kernel(GatherArgs A, GatherArgs B, int nblkA, const int64_t* __restrict__ ii,
+                                    const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, const float* __restrict__ net,
+                                    const float* __restrict__ target, const float* __restrict__ weight, int D) {
+  if ((int)blockIdx.x < nblkA) gather_edges_body(A, ii, jj, kk, net, target, weight, D, blockIdx.x, nblkA);
+  else gather_edges_body(B, ii, jj, kk, net, target, weight, D, blockIdx.x - nblkA, gridDim.x - nblkA);
 }
 
 // ---- motion model (dpvo.py:410-421): poses[n] = Exp(damping*fac * Log(P1 * P2^-1)) * P1 --------------------------
@@ -147,8 +163,8 @@ __device__ __forceinline__ void hat3(const float* p, float* M) {
 __device__ __forceinline__ void mm3(const float* A, const float* B, float* C) {
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += A[3*i+k]*B[3*k+j]; C[3*i+j] = s; }
 }
-__global__ void motion_model_kernel(float* __restrict__ poses, int n, float scale) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void motion_model_body(float* __restrict__ poses, int n, float scale) {
+  if (threadIdx.x != 0) return;
   constexpr float kEps = 1e-6f;
   const float* p1 = poses + 7 * (int64_t)(n - 1);
   const float* p2 = poses + 7 * (int64_t)(n - 2);
@@ -189,12 +205,15 @@ __global__ void motion_model_kernel(float* __restrict__ poses, int n, float scal
   float* o = poses + 7 * (int64_t)n;
   o[0] = te[0]+to[0]; o[1] = te[1]+to[1]; o[2] = te[2]+to[2]; o[3] = qo.x; o[4] = qo.y; o[5] = qo.z; o[6] = qo.w;
 }
+__global__ void motion_model_kernel(float* __restrict__ poses, int n, float scale) {
+  if (blockIdx.x == 0) motion_model_body(poses, n, scale);
+}
 
 // ---- depth initialisation (dpvo.py:427-432): patches[n][:, 2] = median(patches[n-3:n, :, 2]) (torch.median = lower
 //      median of the flattened values).  Rank counting instead of a sort: element i is the lower median iff exactly
 //      (cnt-1)/2 elements precede it in the total order (value, index).  32 elements per block, 8 lanes per element each
 //      counting an eighth of the candidates (LDS, float4 reads); the one block that owns the median writes the new frame.
-__global__ __launch_bounds__(256) void median_depth_kernel(float* __restrict__ patches, int n, int M, int PP) {
+__device__ __forceinline__ void median_depth_body(float* __restrict__ patches, int n, int M, int PP, int bid) {
   __shared__ __attribute__((aligned(16))) float v[4096 + 32];
   __shared__ float med_s;
   __shared__ int found_s;
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(256) void median_depth_kernel(float* __restrict__ p
     v[i] = src[((int64_t)(f * M + m) * 3 + 2) * PP + p];
   }
   __syncthreads();
-  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+  const int i = bid * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
   const int chunk = (((cnt + 7) >> 3) + 3) & ~3;          // candidates per lane, a multiple of 4
   const int j0 = part * chunk, j1 = min(cnt, j0 + chunk);
   const float x = i < cnt ? v[i] : 0.f;
@@ -227,6 +246,9 @@ __global__ __launch_bounds__(256) void median_depth_kernel(float* __restrict__ p
   const float med = med_s;
   float* dst = patches + (int64_t)n * M * 3 * PP;
   for (int k = threadIdx.x; k < per; k += 256) { const int m = k / PP, p = k - m * PP; dst[((int64_t)m * 3 + 2) * PP + p] = med; }
+}
+__global__ __launch_bounds__(256) void median_depth_kernel(float* __restrict__ patches, int n, int M, int PP) {
+  median_depth_body(patches, n, M, PP, blockIdx.x);
 }
 
 // ---- everything a new frame contributes besides its feature maps, in one launch (Patchifier.forward's gathers
@@ -261,14 +283,20 @@ __device__ __forceinline__ float fp_blend(float x, float y, int i0, int j0, int 
   o += dy * dx * v[1][1];
   return o;
 }
-__global__ __launch_bounds__(256) void frame_patches_kernel(
-    const _Float16* __restrict__ fmap, const _Float16* __restrict__ imap, const uint8_t* __restrict__ img,
-    const float* __restrict__ coords, const int64_t* __restrict__ xs, const int64_t* __restrict__ ys,
-    const float* __restrict__ depth, const float* __restrict__ intr, float res, _Float16* __restrict__ gmap_slot,
-    _Float16* __restrict__ imap_slot, float* __restrict__ patches_slot, uint8_t* __restrict__ colors_slot,
-    float* __restrict__ intr_slot, int64_t* __restrict__ index_row, int64_t* __restrict__ index_map, float* __restrict__ coords_out,
-    int M, int h, int w, int H, int W, int CF, int CI, int64_t frame_next, int64_t m_next) {
-  const int m = blockIdx.x, t = threadIdx.x;
+struct FramePatchesArgs {
+  const _Float16 *fmap, *imap; const uint8_t* img; const float* coords; const int64_t *xs, *ys; const float *depth, *intr;
+  float res; _Float16 *gmap_slot, *imap_slot; float* patches_slot; uint8_t* colors_slot; float* intr_slot;
+  int64_t *index_row, *index_map; float* coords_out; int M, h, w, H, W, CF, CI; int64_t frame_next, m_next;
+  int skip_depth;          // the depth plane is written by someone else (the median of the previous frames)
+};
+__device__ __forceinline__ void frame_patches_body(const FramePatchesArgs& A, int m) {
+  const _Float16 *fmap = A.fmap, *imap = A.imap; const uint8_t* img = A.img; const float* coords = A.coords;
+  const int64_t *xs = A.xs, *ys = A.ys; const float *depth = A.depth, *intr = A.intr; const float res = A.res;
+  _Float16 *gmap_slot = A.gmap_slot, *imap_slot = A.imap_slot; float* patches_slot = A.patches_slot;
+  uint8_t* colors_slot = A.colors_slot; float* intr_slot = A.intr_slot; int64_t *index_row = A.index_row, *index_map = A.index_map;
+  float* coords_out = A.coords_out; const int h = A.h, w = A.w, H = A.H, W = A.W, CF = A.CF, CI = A.CI;
+  const int64_t frame_next = A.frame_next, m_next = A.m_next;
+  const int t = threadIdx.x;
   const float x = coords ? coords[2 * m] : (float)xs[m], y = coords ? coords[2 * m + 1] : (float)ys[m];
   const int fi = fp_floor_int(y), fj = fp_floor_int(x);
   // gmap: 9 window positions x CF channels (channels fastest in both the NHWC source and the channels-last slot)
@@ -287,7 +315,7 @@ __global__ __launch_bounds__(256) void frame_patches_kernel(
     if (!patches_slot) return;
     const int pl = t / 9, ab = t - 9 * pl, a = ab / 3, b = ab - 3 * a;
     float o;
-    if (pl == 2) o = depth[m];
+    if (pl == 2) { if (A.skip_depth) return; o = depth[m]; }
     else o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w, [&](int i, int j) { return pl == 0 ? (float)j : (float)i; });
     patches_slot[(int64_t)m * 27 + t] = o;
   } else if (t >= 32 && t < 35) {
@@ -307,6 +335,31 @@ __global__ __launch_bounds__(256) void frame_patches_kernel(
     if (t == 100 && index_map) *index_map = m_next;
   }
   if (index_row && t == 128) index_row[m] = frame_next;
+}
+__global__ __launch_bounds__(256) void frame_patches_kernel(FramePatchesArgs A) { frame_patches_body(A, blockIdx.x); }
+
+// dpvo_frame_state as ONE launch: the five jobs are independent of each other (the depth plane of the new frame belongs to
+// the median job when that one runs), so their workgroups share a grid and run side by side instead of as a chain of
+// five dependent launches.  Roles by block index: [0, M) patches | 1 motion model | n_med median | n_pool pyramid | rest edges.
+struct FrameStateArgs {
+  FramePatchesArgs fp;
+  float* poses; int mm_n; float mm_scale;
+  float* patches_all; int md_n, P;
+  _Float16* fmap2_slot;
+  int64_t *ii, *jj, *kk; float* net; const int64_t* ix; int64_t E0; int ap_n, ap_r, D;
+  int n_med, n_pool, n_app;
+};
+__global__ __launch_bounds__(256) void frame_state_kernel(FrameStateArgs S) {
+  int b = blockIdx.x;
+  if (b < S.fp.M) { frame_patches_body(S.fp, b); return; }
+  b -= S.fp.M;
+  if (b < 1) { if (S.poses) motion_model_body(S.poses, S.mm_n, S.mm_scale); return; }
+  b -= 1;
+  if (b < S.n_med) { median_depth_body(S.patches_all, S.md_n, S.fp.M, S.P * S.P, b); return; }
+  b -= S.n_med;
+  if (b < S.n_pool) { pool4_nhwc_body(S.fp.fmap, S.fmap2_slot, S.fp.h, S.fp.w, S.fp.CF, b, S.n_pool); return; }
+  b -= S.n_pool;
+  append_edges_body(S.ii, S.jj, S.kk, S.net, S.ix, S.E0, S.ap_n, S.fp.M, S.ap_r, S.D, b, S.n_app);
 }
 
 inline unsigned grid_for(int64_t n, int cap = 4096) {
@@ -381,8 +434,26 @@ extern "C" int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* i
   if (n < 0 || D <= 0 || (D % 4)) return DPVO_E_INVALID;
   if (n == 0) return DPVO_OK;
   if (!idx || !ii || !jj || !kk || !oii || !ojj || !okk) return DPVO_E_INVALID;
-  hipLaunchKernelGGL(gather_edges_kernel, dim3(grid_for(onet ? n * (D / 4) : n, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     idx, n, ii, jj, kk, net, target, weight, oii, ojj, okk, onet, otarget, oweight, D);
+  const GatherArgs A = {idx, n, oii, ojj, okk, onet, otarget, oweight};
+  const unsigned g = grid_for(onet ? n * (D / 4) : n, 2048);
+  hipLaunchKernelGGL(gather_edges_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, A, A, (int)g, ii, jj, kk, net, target, weight, D);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_gather_edges2(const int64_t* idx_a, int64_t n_a, int64_t* a_ii, int64_t* a_jj, int64_t* a_kk, float* a_net,
+                                  float* a_target, float* a_weight, const int64_t* idx_b, int64_t n_b, int64_t* b_ii,
+                                  int64_t* b_jj, int64_t* b_kk, float* b_net, float* b_target, float* b_weight,
+                                  const int64_t* ii, const int64_t* jj, const int64_t* kk, const float* net,
+                                  const float* target, const float* weight, int D, void* stream) {
+  if (n_a < 0 || n_b < 0 || D <= 0 || (D % 4)) return DPVO_E_INVALID;
+  if (n_a == 0) return dpvo_gather_edges(idx_b, n_b, ii, jj, kk, net, target, weight, b_ii, b_jj, b_kk, b_net, b_target, b_weight, D, stream);
+  if (n_b == 0) return dpvo_gather_edges(idx_a, n_a, ii, jj, kk, net, target, weight, a_ii, a_jj, a_kk, a_net, a_target, a_weight, D, stream);
+  if (!idx_a || !idx_b || !ii || !jj || !kk || !a_ii || !a_jj || !a_kk || !b_ii || !b_jj || !b_kk) return DPVO_E_INVALID;
+  const GatherArgs A = {idx_a, n_a, a_ii, a_jj, a_kk, a_net, a_target, a_weight}, B = {idx_b, n_b, b_ii, b_jj, b_kk, b_net, b_target, b_weight};
+  const unsigned ga = grid_for(a_net ? n_a * (D / 4) : n_a, 2048), gb = grid_for(b_net ? n_b * (D / 4) : n_b, 2048);
+  hipLaunchKernelGGL(gather_edges_kernel, dim3(ga + gb), dim3(256), 0, (hipStream_t)stream, A, B, (int)ga, ii, jj, kk, net, target,
+                     weight, D);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
@@ -401,16 +472,43 @@ extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void
   if ((gmap_slot && !fmap) || (imap_slot && !imap) || (patches_slot && !depth) || (colors_slot && !img_u8)) return DPVO_E_INVALID;
   if (!coords && !(xs && ys)) return DPVO_E_INVALID;
   if (intrinsics_slot && !intrinsics) return DPVO_E_INVALID;
-  hipLaunchKernelGGL(frame_patches_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const _Float16*)fmap,
-                     (const _Float16*)imap, (const uint8_t*)img_u8, coords, xs, ys, depth, intrinsics, res,
-                     (_Float16*)gmap_slot, (_Float16*)imap_slot, patches_slot, (uint8_t*)colors_slot, intrinsics_slot,
-                     index_row, index_map, coords_out, M, h, w, H, W, CF, CI, frame_next, m_next);
+  const FramePatchesArgs A = {(const _Float16*)fmap, (const _Float16*)imap, (const uint8_t*)img_u8, coords, xs, ys, depth, intrinsics,
+                              res, (_Float16*)gmap_slot, (_Float16*)imap_slot, patches_slot, (uint8_t*)colors_slot, intrinsics_slot,
+                              index_row, index_map, coords_out, M, h, w, H, W, CF, CI, frame_next, m_next, 0};
+  hipLaunchKernelGGL(frame_patches_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, A);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
 
 extern "C" int dpvo_frame_state(dpvo_frame_state_t* p, void* stream) {
   if (!p) return DPVO_E_INVALID;
+  const bool fused = p->poses && p->patches_all && p->fmap2_slot && p->ii && p->jj && p->kk && p->net && p->ix && p->fmap && p->imap &&
+                     p->img_u8 && p->gmap_slot && p->imap_slot && p->patches_slot && p->colors_slot && (p->coords || (p->xs && p->ys)) &&
+                     (!p->intrinsics_slot || p->intrinsics) && p->P == 3 && p->M > 0 && p->mm_n >= 2 && p->md_n >= 3 &&
+                     3 * p->M * 9 <= 4096 && p->h > 0 && p->w > 0 && !(p->h % 4) && !(p->w % 4) && !(p->CF % 8) && p->CI > 0 &&
+                     p->H > 0 && p->W > 0 && p->E0 >= 0 && p->ap_n >= 1 && p->ap_r >= 0 && p->D > 0 && !(p->D % 4);
+  if (fused) {
+    const int n = p->ap_n, r = p->ap_r, M = p->M;
+    const int jlo = n - r > 0 ? n - r : 0;
+    const int64_t total = (int64_t)M * ((n - 1 > 0 ? n - 1 : 0) - jlo) + (int64_t)M * (n - jlo);
+    p->n_new = total;
+    FrameStateArgs S;
+    S.fp = {(const _Float16*)p->fmap, (const _Float16*)p->imap, (const uint8_t*)p->img_u8, p->coords, p->xs, p->ys, p->depth,
+            p->intrinsics, p->res, (_Float16*)p->gmap_slot, (_Float16*)p->imap_slot, p->patches_slot, (uint8_t*)p->colors_slot,
+            p->intrinsics_slot, p->index_row, p->index_map, nullptr, M, p->h, p->w, p->H, p->W, p->CF, p->CI, p->frame_next,
+            p->m_next, 1};
+    S.poses = p->poses; S.mm_n = p->mm_n; S.mm_scale = p->mm_scale;
+    S.patches_all = p->patches_all; S.md_n = p->md_n; S.P = p->P;
+    S.fmap2_slot = (_Float16*)p->fmap2_slot;
+    S.ii = p->ii; S.jj = p->jj; S.kk = p->kk; S.net = p->net; S.ix = p->ix; S.E0 = p->E0; S.ap_n = n; S.ap_r = r; S.D = p->D;
+    S.n_med = (3 * M * 9 + 31) / 32;
+    S.n_pool = (int)(((int64_t)(p->h / 4) * (p->w / 4) * (p->CF / 8) + 255) / 256);
+    S.n_app = total > 0 ? (int)grid_for(total * (p->D / 4), 2048) : 0;
+    hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(M + 1 + S.n_med + S.n_pool + S.n_app)), dim3(256), 0, (hipStream_t)stream,
+                       S);
+    DPVO_LAUNCH_CHECK();
+    return DPVO_OK;
+  }
   int rc = dpvo_frame_patches(p->fmap, p->imap, p->img_u8, p->coords, p->xs, p->ys, p->depth, p->intrinsics, p->res,
                               p->gmap_slot, p->imap_slot, p->patches_slot, p->colors_slot, p->intrinsics_slot, p->index_row,
                               p->index_map, nullptr, p->M, p->h, p->w, p->H, p->W, p->CF, p->CI, p->P, p->frame_next, p->m_next,

@@ -290,11 +290,9 @@ class DPVO:
             rem = m.nonzero().squeeze(1) if store else None
             keep, keep_h = (~m).nonzero().squeeze(1), None
         if store and rem is not None and rem.numel():
-            dst = self.pg.edges_inac
-            dst.reserve(rem.numel())
-            es.gather_into(rem, dst.a, dst.E)
-            dst.E += rem.numel()
-        es.keep(keep, keep_h)
+            es.keep(keep, keep_h, also=(rem, self.pg.edges_inac))      # both gathers in one launch
+        else:
+            es.keep(keep, keep_h)
         self._plan = None
 
     def _removal_mask(self, h):

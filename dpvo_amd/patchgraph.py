@@ -193,11 +193,7 @@ class EdgeStore:
     def gather_into(self, idx, dst, dst_off):
         """dst arrays [dst_off : dst_off+len(idx)] = self arrays[idx] (one kernel)"""
         n = idx.numel()
-        copied = self._staged.pop(idx.data_ptr(), None) if (n and self._staged) else None
-        if copied is not None and not copied.query():
-            # indices staged by stage_indices whose copy has not finished yet (normally it finished a frame ago: a cross-
-            # stream wait costs ~15 us of queue time on this platform, so it is only inserted when needed)
-            torch.cuda.current_stream(self.dev).wait_event(copied)
+        copied = self._wait_staged(idx)
         # (raw pointer arithmetic instead of tensor slices: this call sits in the host-paced start of a frame)
         vp = ctypes.c_void_p
         src, has_net = self.a, dst.get("net") is not None
@@ -207,15 +203,47 @@ class EdgeStore:
             vp(src["net"].data_ptr()) if has_net else vp(0), vp(src["target"].data_ptr()), vp(src["weight"].data_ptr()),
             o(dst["ii"], 8), o(dst["jj"], 8), o(dst["kk"], 8), o(dst["net"], 4 * self.D) if has_net else vp(0),
             o(dst["target"], 8), o(dst["weight"], 8), ctypes.c_int(self.D), L.stream()), "dpvo_gather_edges")
-        if copied is not None:                       # the staging buffers may be rewritten once this gather has run
-            if self._gathered is None:
-                self._gathered = torch.cuda.Event()
-            self._gathered.record()
+        if copied:
+            self._mark_gathered()
 
-    def keep(self, idx, idx_host=None):
+    def _wait_staged(self, idx):
+        """indices staged by stage_indices: order the consumer after their copy.  Normally the copy finished a frame ago; a
+        cross-stream wait costs ~15 us of queue time on this platform, so it is only inserted when needed."""
+        copied = self._staged.pop(idx.data_ptr(), None) if (idx.numel() and self._staged) else None
+        if copied is not None and not copied.query():
+            torch.cuda.current_stream(self.dev).wait_event(copied)
+        return copied is not None
+
+    def _mark_gathered(self):
+        """the staging buffers may be rewritten once the gather just issued has run"""
+        if self._gathered is None:
+            self._gathered = torch.cuda.Event()
+        self._gathered.record()
+
+    def keep(self, idx, idx_host=None, also=None):
         """compact to the edges listed in idx (sorted ascending), ping-pong buffers.  idx_host: the same indices as a numpy
-        array, which keeps the host mirror alive (applied lazily)"""
-        self.gather_into(idx, self.b, 0)
+        array, which keeps the host mirror alive (applied lazily).  also = (idx2, dst_store): additionally append the edges
+        idx2 to another store (the inactive edges of remove_factors) -- both gathers in one launch."""
+        if also is None:
+            self.gather_into(idx, self.b, 0)
+        else:
+            idx2, dst = also
+            n2 = idx2.numel()
+            dst.reserve(n2)
+            self._wait_staged(idx); self._wait_staged(idx2)
+            vp = ctypes.c_void_p
+            src = self.a
+            o = lambda t, off, row_bytes: vp(0) if t is None else vp(t.data_ptr() + off * row_bytes)
+            L.check(L.lib().dpvo_gather_edges2(
+                vp(idx2.data_ptr()), ctypes.c_int64(n2), o(dst.a["ii"], dst.E, 8), o(dst.a["jj"], dst.E, 8), o(dst.a["kk"], dst.E, 8),
+                o(dst.a.get("net"), dst.E, 4 * self.D), o(dst.a["target"], dst.E, 8), o(dst.a["weight"], dst.E, 8),
+                vp(idx.data_ptr()), ctypes.c_int64(idx.numel()), o(self.b["ii"], 0, 8), o(self.b["jj"], 0, 8), o(self.b["kk"], 0, 8),
+                o(self.b.get("net"), 0, 4 * self.D), o(self.b["target"], 0, 8), o(self.b["weight"], 0, 8),
+                vp(src["ii"].data_ptr()), vp(src["jj"].data_ptr()), vp(src["kk"].data_ptr()),
+                vp(src["net"].data_ptr()) if "net" in src else vp(0), vp(src["target"].data_ptr()), vp(src["weight"].data_ptr()),
+                ctypes.c_int(self.D), L.stream()), "dpvo_gather_edges2")
+            self._mark_gathered()
+            dst.E += n2
         self.a, self.b = self.b, self.a
         if self._h is not None:
             if idx_host is None:

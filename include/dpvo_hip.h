@@ -254,6 +254,13 @@ int dpvo_append_edges(int64_t* ii, int64_t* jj, int64_t* kk, float* net, const i
 int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* ii, const int64_t* jj, const int64_t* kk,
                       const float* net, const float* target, const float* weight, int64_t* oii, int64_t* ojj,
                       int64_t* okk, float* onet, float* otarget, float* oweight, int D, void* stream);
+/* Two compactions from the same source arrays in ONE launch (remove_factors, dpvo.py:223-238: the removed edges go to the
+ * inactive store, the kept ones are compacted): job a = (idx_a, n_a -> a_*), job b = (idx_b, n_b -> b_*); net / target /
+ * weight outputs optional per job; the two output sets must not overlap each other or the sources. */
+int dpvo_gather_edges2(const int64_t* idx_a, int64_t n_a, int64_t* a_ii, int64_t* a_jj, int64_t* a_kk, float* a_net,
+                       float* a_target, float* a_weight, const int64_t* idx_b, int64_t n_b, int64_t* b_ii, int64_t* b_jj,
+                       int64_t* b_kk, float* b_net, float* b_target, float* b_weight, const int64_t* ii, const int64_t* jj,
+                       const int64_t* kk, const float* net, const float* target, const float* weight, int D, void* stream);
 /* Everything a new frame contributes besides its feature maps, in one launch: Patchifier.forward's gathers
  * (net.py:136-147: gmap = patchify(fmap, coords, 1), imap = patchify(imap, coords, 0), patches = patchify(grid, coords, 1),
  * clr = patchify(image, 4 (coords + 0.5), 0)) and the per-frame state stores of dpvo.py:401-438 (intrinsics / RES,
