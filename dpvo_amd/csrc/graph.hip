@@ -106,8 +106,205 @@ inline unsigned grid_for(int64_t n) {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-  size_t keys_a, keys_b, keys_out, vals_in, temp, temp_bytes, total;
+  size_t keys_a, keys_b, keys_out, vals_in, temp, temp_bytes, win, total;
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Windowed plan build (dpvo_plan_build_window): when the caller can bound the frame and patch ids of all edges by a small
+// window (the tracker can: source frames within REMOVAL_WINDOW, targets within PATCH_LIFETIME of them), both orderings
+// are ONE stable counting-sort pass each -- by patch (<= 4096 bins), then each patch's few edges ranked by (jj, edge) by
+// brute force; by frame pair (<= 2048 bins) -- sharing their launches: per-tile histograms, one scan, one scatter, then the
+// group structures straight from the bins (group index = number of non-empty bins before).  5 launches instead of 14 (two rocPRIM device radix sorts cost ~45 us each at
+// E = 47 k whatever the key width, almost all of it launch-to-launch latency).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kWinA = 4096, kWinB = 2048, kWinBins = kWinA + kWinB, kWinTile = 1024;
+
+struct WinArgs {
+  const int64_t *ii, *jj, *kk; int64_t E;
+  int frame_lo, nfw, patch_lo, npw;     // windows: frame ids in [frame_lo, frame_lo + nfw), patch ids in [patch_lo, patch_lo + npw)
+  int shift;                            // composite keys: (hi << shift) | jj, as in the radix path
+  int32_t* T;                           // [tiles][kWinBins] tile histograms -> exclusive offsets
+  int32_t* binstart;                    // [kWinBins + 2]: segment starts of the A bins ([0, npw]) and of the B bins (kWinA + [0, nfw*nfw])
+  int32_t* tot;                         // [kWinBins]: per-bin totals (zeroed before the histogram kernel)
+  uint32_t *tmp_key; int32_t* tmp_e;    // by-patch order before the in-patch ranking
+  int32_t *perm_k, *perm_p, *flag;      // flag: ids outside the window were seen (lives next to tot, copied to counts[3])
+  int32_t* gid;                         // [kWinBins]: number of non-empty bins before a bin = its group index
+  int32_t *ku, *kx, *patch_off, *ix, *jx, *pu, *pair_off, *pair_ij, *counts;
+};
+
+__device__ __forceinline__ void win_bins(const WinArgs& W, int64_t e, int& ba, int& bb, bool& bad) {
+  const int k = (int)(W.kk[e] - W.patch_lo), i = (int)(W.ii[e] - W.frame_lo), j = (int)(W.jj[e] - W.frame_lo);
+  bad = k < 0 || k >= W.npw || i < 0 || i >= W.nfw || j < 0 || j >= W.nfw;
+  ba = k < 0 ? 0 : (k >= W.npw ? W.npw - 1 : k);
+  const int ic = i < 0 ? 0 : (i >= W.nfw ? W.nfw - 1 : i), jc = j < 0 ? 0 : (j >= W.nfw ? W.nfw - 1 : j);
+  bb = ic * W.nfw + jc;
+}
+
+__global__ __launch_bounds__(1024) void win_hist_kernel(WinArgs W) {
+  __shared__ int32_t h[kWinBins];
+  const int nb_b = W.nfw * W.nfw;
+  for (int b = threadIdx.x; b < kWinBins; b += 1024) h[b] = 0;
+  __syncthreads();
+  const int64_t e = (int64_t)blockIdx.x * kWinTile + threadIdx.x;
+  if (e < W.E) {
+    int ba, bb; bool bad;
+    win_bins(W, e, ba, bb, bad);
+    if (bad) *W.flag = 1;
+    atomicAdd(&h[ba], 1);
+    atomicAdd(&h[kWinA + bb], 1);
+  }
+  __syncthreads();
+  int32_t* T = W.T + (int64_t)blockIdx.x * kWinBins;
+  for (int b = threadIdx.x; b < W.npw; b += 1024) { T[b] = h[b]; if (h[b]) atomicAdd(&W.tot[b], h[b]); }
+  for (int b = threadIdx.x; b < nb_b; b += 1024) { T[kWinA + b] = h[kWinA + b]; if (h[kWinA + b]) atomicAdd(&W.tot[kWinA + b], h[kWinA + b]); }
+}
+
+// T[tile][bin] -> exclusive prefix over the tiles, plus for every bin its segment start (binstart) and its group index
+// (gid = number of non-empty bins before it).  One workgroup per 1024 bins of an ordering (blockIdx.x < chunks_a: by-patch
+// bins, else pair bins); what lies before the chunk is summed from the per-bin totals the histogram kernel accumulated
+// (W.tot), so the workgroups do not wait for each other.  The last bin of each ordering also writes the group count and
+// the closing offset.
+__global__ __launch_bounds__(1024) void win_scan_kernel(WinArgs W, int tiles, int chunks_a) {
+  __shared__ int32_t wsum[16], wocc[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int part = (int)blockIdx.x >= chunks_a;
+  const int c0 = 1024 * (part ? (int)blockIdx.x - chunks_a : (int)blockIdx.x);
+  const int nb = part ? W.nfw * W.nfw : W.npw, b0 = part ? kWinA : 0;
+  // bins before this chunk
+  int32_t pre = 0, preo = 0;
+  for (int q = t; q < c0; q += 1024) { const int32_t v = W.tot[b0 + q]; pre += v; preo += v != 0; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); preo += __shfl_xor(preo, o); }
+  if (lane == 0) { wsum[wv] = pre; wocc[wv] = preo; }
+  __syncthreads();
+  int32_t carry = 0, carryo = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { carry += wsum[k]; carryo += wocc[k]; }
+  __syncthreads();
+  // own bin: prefix over the tiles (loads in independent batches of 8)
+  const int b = c0 + t;
+  int32_t tot = 0;
+  if (b < nb) {
+    int32_t* col = W.T + b0 + b;
+    for (int tl = 0; tl < tiles; tl += 8) {
+      int32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (tl + u < tiles) ? col[(int64_t)(tl + u) * kWinBins] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (tl + u < tiles) col[(int64_t)(tl + u) * kWinBins] = tot;
+        tot += v[u];
+      }
+    }
+  }
+  int32_t x = tot, xo = tot != 0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t y = __shfl_up(x, o), yo = __shfl_up(xo, o);
+    if (lane >= o) { x += y; xo += yo; }
+  }
+  if (lane == 63) { wsum[wv] = x; wocc[wv] = xo; }
+  __syncthreads();
+  int32_t wbase = 0, obase = 0;
+  for (int k = 0; k < wv; ++k) { wbase += wsum[k]; obase += wocc[k]; }
+  if (b < nb) {
+    W.binstart[b0 + b] = carry + wbase + x - tot;
+    W.gid[b0 + b] = carryo + obase + xo - (tot != 0);
+  }
+  if (b == nb - 1) {
+    const int32_t ng = carryo + obase + xo, E = carry + wbase + x;
+    W.binstart[b0 + nb] = E;
+    (part ? W.pair_off : W.patch_off)[ng] = E;
+    W.counts[part] = ng;
+    if (part) { W.counts[2] = 0; W.counts[3] = *W.flag; }
+  }
+}
+
+// rank of a lane among the lanes of its wave with the same bin (bits: width of the bin index), and the size of that group
+__device__ __forceinline__ void wave_match(int bin, bool valid, int bits, int lane, int& rank, int& cnt) {
+  unsigned long long m = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const unsigned long long bal = __ballot((bin >> b) & 1);
+    m &= ((bin >> b) & 1) ? bal : ~bal;
+  }
+  rank = __popcll(m & ((1ull << lane) - 1));
+  cnt = __popcll(m);
+}
+
+__global__ __launch_bounds__(1024) void win_scatter_kernel(WinArgs W) {
+  __shared__ int32_t run[kWinBins];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  for (int b = t; b < kWinBins; b += 1024) run[b] = 0;
+  const int64_t e = (int64_t)blockIdx.x * kWinTile + t;
+  const bool valid = e < W.E;
+  int ba = 0, bb = 0; bool bad;
+  if (valid) win_bins(W, e, ba, bb, bad);
+  int ra, ca, rb, cb;
+  wave_match(ba, valid, 12, lane, ra, ca);
+  wave_match(bb, valid, 11, lane, rb, cb);
+  int la = 0, lb = 0;
+  // the 16 waves of the tile take their turn in order: stable ranks inside the tile
+  for (int w = 0; w < 16; ++w) {
+    __syncthreads();
+    if (wv == w && valid) {
+      la = run[ba] + ra;
+      lb = run[kWinA + bb] + rb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wv == w && valid) {
+      if (ra == 0) run[ba] += ca;
+      if (rb == 0) run[kWinA + bb] += cb;
+    }
+  }
+  if (valid) {
+    const int32_t* T = W.T + (int64_t)blockIdx.x * kWinBins;
+    const int pa = W.binstart[ba] + T[ba] + la;
+    const int pb = W.binstart[kWinA + bb] + T[kWinA + bb] + lb;
+    W.tmp_key[pa] = ((uint32_t)W.kk[e] << W.shift) | ((uint32_t)W.jj[e] & ((1u << W.shift) - 1));
+    W.tmp_e[pa] = (int32_t)e;
+    W.perm_p[pb] = (int32_t)e;
+    // frame-pair group structures: the bins are in (i, j) order already
+    const int g = W.gid[kWinA + bb];
+    W.pu[e] = g;
+    if (pb == W.binstart[kWinA + bb]) {
+      W.pair_off[g] = pb;
+      W.pair_ij[2 * g] = (int32_t)W.ii[e];
+      W.pair_ij[2 * g + 1] = (int32_t)W.jj[e];
+    }
+  }
+}
+
+// by-patch order -> (patch, jj, edge) order: every element ranks itself inside its patch's segment and finds its
+// predecessor / successor there (fastba.neighbors); per-patch group structures from the bins
+__global__ void win_segsort_kernel(WinArgs W) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= W.E) return;
+  const uint32_t key = W.tmp_key[p];
+  const int32_t e = W.tmp_e[p];
+  int k = (int)(key >> W.shift) - W.patch_lo;
+  k = k < 0 ? 0 : (k >= W.npw ? W.npw - 1 : k);
+  const int s = W.binstart[k], t = W.binstart[k + 1];
+  int rank = 0;
+  uint32_t pk = 0, nk = 0xffffffffu; int32_t pe = -1, ne = -1;        // closest element below / above in (key, edge) order
+  for (int q = s; q < t; ++q) {
+    const uint32_t kq = W.tmp_key[q];
+    const int32_t eq = W.tmp_e[q];
+    const bool below = (kq < key) || (kq == key && eq < e);
+    const bool above = (kq > key) || (kq == key && eq > e);
+    rank += below;
+    if (below && (pe < 0 || kq > pk || (kq == pk && eq > pe))) { pk = kq; pe = eq; }
+    if (above && (ne < 0 || kq < nk || (kq == nk && eq < ne))) { nk = kq; ne = eq; }
+  }
+  int64_t pos = (int64_t)s + rank;
+  if (pos >= W.E) pos = W.E - 1;          // (only reachable with ids outside the promised window: stay inside the arrays)
+  W.perm_k[pos] = e;
+  W.ix[e] = pe; W.jx[e] = ne;
+  const int g = W.gid[k];
+  W.ku[e] = g;
+  if (rank == 0) { W.kx[g] = (int32_t)(key >> W.shift); W.patch_off[g] = s; }
+}
 
 // (sized for the 64-bit generic path; the 32-bit path uses a prefix of every buffer)
 int ws_layout(int64_t E, WsLayout* L) {
@@ -127,6 +324,8 @@ int ws_layout(int64_t E, WsLayout* L) {
   L->temp = o;
   L->temp_bytes = sort_bytes > sort_bytes32 ? sort_bytes : sort_bytes32;
   o += align256(L->temp_bytes);
+  L->win = o;                      // windowed path: tile histograms + bin starts (keys_* / vals_in are reused for its arrays)
+  o += align256((size_t)cdiv64((int64_t)n, kWinTile) * kWinBins * 4 + (size_t)(3 * kWinBins + 4) * 4 + 256);
   L->total = o;
   return 0;
 }
@@ -225,6 +424,50 @@ extern "C" int dpvo_plan_build_ranged(const int64_t* ii, const int64_t* jj, cons
     rc = build_plan<uint64_t>(ii, jj, kk, E, plan, P, (char*)ws, L, kKeyShift, 64, 64, 3, st);
   }
   if (rc) return rc;
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+                                      void* ws, size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
+                                      int64_t n_patches_win, void* stream) {
+  if (E < 0 || !plan || frame_lo < 0 || patch_lo < 0 || n_frames_win <= 0 || n_patches_win <= 0) return DPVO_E_INVALID;
+  if (n_frames_win * n_frames_win > kWinB || n_patches_win > kWinA || E >= (1 << 24)) return DPVO_E_UNSUPPORTED;
+  const int shift = bits_for(frame_lo + n_frames_win);
+  if (shift + bits_for(patch_lo + n_patches_win) > 32) return DPVO_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dpvo_plan_layout_t P;
+  dpvo_plan_layout(E, &P);
+  if (E == 0) {
+    hipError_t e = hipMemsetAsync(plan + P.counts, 0, 4 * sizeof(int32_t), st);
+    return e == hipSuccess ? DPVO_OK : (int)e;
+  }
+  if (!ii || !jj || !kk || !ws) return DPVO_E_INVALID;
+  WsLayout L;
+  int rc = ws_layout(E, &L);
+  if (rc) return rc;
+  if (ws_bytes < L.total) return DPVO_E_WORKSPACE;
+  char* w = (char*)ws;
+  const int tiles = (int)cdiv64(E, kWinTile);
+  WinArgs W;
+  W.ii = ii; W.jj = jj; W.kk = kk; W.E = E;
+  W.frame_lo = (int)frame_lo; W.nfw = (int)n_frames_win; W.patch_lo = (int)patch_lo; W.npw = (int)n_patches_win; W.shift = shift;
+  W.T = (int32_t*)(w + L.win);
+  W.binstart = W.T + (size_t)tiles * kWinBins;
+  W.tot = W.binstart + kWinBins + 2;
+  W.flag = W.tot + kWinBins;
+  W.gid = W.flag + 1;
+  hipError_t e0 = hipMemsetAsync(W.tot, 0, (kWinBins + 1) * sizeof(int32_t), st);      // totals + flag
+  if (e0 != hipSuccess) return (int)e0;
+  W.tmp_key = (uint32_t*)(w + L.keys_a); W.tmp_e = (int32_t*)(w + L.vals_in);
+  W.perm_k = plan + P.perm_k; W.perm_p = plan + P.perm_p;
+  W.ku = plan + P.ku; W.kx = plan + P.kx; W.patch_off = plan + P.patch_off; W.ix = plan + P.ix; W.jx = plan + P.jx;
+  W.pu = plan + P.pu; W.pair_off = plan + P.pair_off; W.pair_ij = plan + P.pair_ij; W.counts = plan + P.counts;
+  hipLaunchKernelGGL(win_hist_kernel, dim3(tiles), dim3(1024), 0, st, W);
+  const int chunks_a = (int)cdiv64(W.npw, 1024), chunks_b = (int)cdiv64((int64_t)W.nfw * W.nfw, 1024);
+  hipLaunchKernelGGL(win_scan_kernel, dim3(chunks_a + chunks_b), dim3(1024), 0, st, W, tiles, chunks_a);
+  hipLaunchKernelGGL(win_scatter_kernel, dim3(tiles), dim3(1024), 0, st, W);
+  hipLaunchKernelGGL(win_segsort_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, W);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

@@ -425,15 +425,19 @@ class DPVO:
 
     def plan(self):
         if self._plan is None or self._plan.E != self.pg.ii.numel():
-            ub_p = ub_g = None
+            ub_p = ub_g = window = None
             if not self.cfg.LOOP_CLOSURE and not _PLAN_SYNC:
                 # every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
                 # PATCH_LIFETIME frames of the source: bounds on #patches / #frame pairs, no device read-back needed
                 nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
                 ub_p = nf * self.M
                 ub_g = nf * (2 * self.cfg.PATCH_LIFETIME + 2)
+                # ... and every frame / patch id lies in a window of REMOVAL_WINDOW + PATCH_LIFETIME (+ slack) frames:
+                # counting-sort plan build (falls back to the radix build by itself when the window is too wide for it)
+                flo = max(0, self.n - (self.cfg.REMOVAL_WINDOW + self.cfg.PATCH_LIFETIME + 3))
+                window = (flo, self.n - flo, flo * self.M, (self.n - flo) * self.M)
             self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
-                                   n_frames=self.N, n_patch_ids=self.N * self.M)
+                                   n_frames=self.N, n_patch_ids=self.N * self.M, window=window)
         return self._plan
 
     def update(self):

@@ -14,7 +14,7 @@ class GraphPlan:
     """All views are int32 device tensors into one buffer; `counts` = [n_patches, n_pairs, 0, 0] stays on the
     device (no synchronisation); `n_patches()` / `n_pairs()` synchronise and are for tests / host logic only."""
 
-    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None, n_frames=0, n_patch_ids=0):
+    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None, n_frames=0, n_patch_ids=0, window=None):
         L.require_cuda(ii, jj, kk)
         assert ii.dtype == jj.dtype == kk.dtype == torch.long
         E = ii.numel()
@@ -28,10 +28,20 @@ class GraphPlan:
         self._keep = (ii, jj, kk)
         nbytes = L.lib().dpvo_plan_workspace_bytes(L.i64(E))
         ws = workspace.get(nbytes, ii.device, "plan")
+        # window = (frame_lo, n_frames_win, patch_lo, n_patches_win): the caller guarantees that all frame / patch ids lie in
+        # these windows -> counting-sort build (dpvo_plan_build_window); falls back when the windows are too large for it
+        rc = -2
+        if window is not None:
+            rc = L.lib().dpvo_plan_build_window(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
+                                                ctypes.c_size_t(ws.numel()), L.i64(window[0]), L.i64(window[1]), L.i64(window[2]),
+                                                L.i64(window[3]), L.stream())
+            if rc != -2:
+                L.check(rc, "dpvo_plan_build_window")
         # n_frames / n_patch_ids: optional bounds on the index values (BUFFER_SIZE, BUFFER_SIZE * PATCHES_PER_FRAME): 32-bit keys
-        L.check(L.lib().dpvo_plan_build_ranged(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
-                                               ctypes.c_size_t(ws.numel()), L.i64(n_frames), L.i64(n_patch_ids),
-                                               L.stream()), "dpvo_plan_build")
+        if rc == -2:
+            L.check(L.lib().dpvo_plan_build_ranged(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
+                                                   ctypes.c_size_t(ws.numel()), L.i64(n_frames), L.i64(n_patch_ids),
+                                                   L.stream()), "dpvo_plan_build")
 
         # Launch sizes of the group-level kernels.  Callers that can bound the group counts from their own bookkeeping
         # (DPVO: patches / frame pairs inside the removal window) pass upper bounds and NO host synchronisation happens:

@@ -79,8 +79,8 @@ def test_reproject_flow_points(oracle, dev):
     H.assert_close(co2[0].cpu().numpy()[(ok & front).numpy()], ref[(ok & front).numpy()], 5e-3, 1e-4, "cuda_ba.reproject")
 
 
-@pytest.mark.parametrize("ranged", [False, True])
-@pytest.mark.parametrize("case", ["replay40", "small", "shuffled", "single", "empty"])
+@pytest.mark.parametrize("ranged", [False, True, "window"])
+@pytest.mark.parametrize("case", ["replay40", "small", "shuffled", "single", "empty", "tiles"])
 def test_plan_bit_exact(oracle, dev, case, ranged):
     if case == "replay40":
         ii, jj, kk = S.replay_graph(40)
@@ -94,12 +94,25 @@ def test_plan_bit_exact(oracle, dev, case, ranged):
         ii = torch.cat([ii, ii[:500]]); jj = torch.cat([jj, jj[:500]]); kk = torch.cat([kk, kk[:500]])
     elif case == "single":
         ii, jj, kk = torch.tensor([3]), torch.tensor([5]), torch.tensor([300])
+    elif case == "tiles":               # exactly two 1024-edge tiles, shuffled, with duplicates
+        ii, jj, kk = S.replay_graph(12)
+        p = torch.randperm(ii.numel(), generator=torch.Generator().manual_seed(5))[:2048 - 300]
+        ii, jj, kk = ii[p], jj[p], kk[p]
+        ii = torch.cat([ii, ii[:300]]); jj = torch.cat([jj, jj[:300]]); kk = torch.cat([kk, kk[:300]])
     else:
         ii = jj = kk = torch.zeros(0, dtype=torch.long)
     E = ii.numel()
     # ranged: bounds on the index values -> 32-bit keys, partial-width radix sorts (dpvo_plan_build_ranged)
+    # window: all ids inside small windows -> counting-sort build (dpvo_plan_build_window), same plan bit for bit
     rng = dict(n_frames=4096, n_patch_ids=4096 * 96) if ranged else {}
+    if ranged == "window" and E:
+        flo = int(min(ii.min(), jj.min())); nfw = int(max(ii.max(), jj.max())) + 1 - flo
+        plo = int(kk.min()); npw = int(kk.max()) + 1 - plo
+        assert nfw * nfw <= 2048 and npw <= 4096, "test graphs are meant to fit the window path"
+        rng["window"] = (flo, nfw, plo, npw)
     plan = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), **rng)
+    if ranged == "window" and E:
+        assert plan.counts.cpu().tolist()[3] == 0
     if E == 0:
         assert plan.n_patches() == 0 and plan.n_pairs() == 0
         return
