@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void corr_pyramid_kernel(
     const _Float16* __restrict__ gmap, const _Float16* __restrict__ fmap0, const _Float16* __restrict__ fmap1,
     const float* __restrict__ coords, const int64_t* __restrict__ us, const int64_t* __restrict__ vs,
     const int32_t* __restrict__ order, _Float16* __restrict__ out, int64_t ld_out, int64_t E, int H0, int W0,
-    int H1, int W1) {
+    int H1, int W1, int N1, int N2) {
   __shared__ __attribute__((aligned(16))) float raw[CORR_NPIX * CORR_MAXPOS];
   __shared__ __attribute__((aligned(16))) _Float16 orow[2 * CORR_NOUT + 2];
   __shared__ int meta_i[32];
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64) void corr_pyramid_kernel(
       if (v >= E) continue;
       e = order[v];
     }
-    const int64_t u = us[e], v = vs[e];
+    // ring-buffer indices (dpvo.py:202-203: ii % (M * pmem), jj % mem), reduced here instead of by two elementwise launches
+    const int64_t u = (int)us[e] % N1, v = (int)vs[e] % N2;
     // A fragments: template pixel m = lane&15 (<9), channels [(4s+kg)*8, +8)
     h8 a[4];
     {
@@ -319,12 +320,12 @@ extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, co
   if (E < 0 || ld_out < 2 * CORR_NOUT || (ld_out & 1)) return DPVO_E_INVALID;
   if (E == 0) return DPVO_OK;
   if (!gmap || !fmap0 || !fmap1 || !coords || !us || !vs || !out) return DPVO_E_INVALID;
-  (void)N1; (void)N2;
+  if (N1 <= 0 || N2 <= 0 || N1 > 0x7fffffff || N2 > 0x7fffffff) return DPVO_E_INVALID;
   // with an order hint the grid is padded to 8 slices of ceil(E/8) so that the XCD remap is a bijection onto [0,E)
   const int64_t grid = order ? ((E + 7) >> 3) << 3 : E;
   hipLaunchKernelGGL(corr_pyramid_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
                      (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1);
+                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
@@ -336,7 +337,7 @@ extern "C" int dpvo_corr_forward(const void* fmap1, const int64_t* s1, const voi
   if (E < 0 || C <= 0 || P <= 0 || radius < 0 || !s1 || !s2) return DPVO_E_INVALID;
   if (E == 0) return DPVO_OK;
   if (!fmap1 || !fmap2 || !coords || !us || !vs || !out) return DPVO_E_INVALID;
-  (void)N1; (void)N2;
+  if (N1 <= 0 || N2 <= 0 || N1 > 0x7fffffff || N2 > 0x7fffffff) return DPVO_E_INVALID;
   const int Dm = 2 * radius + 1;
   const int64_t total = E * Dm * Dm * P * P;
   const int64_t grid = cdiv64(total, 256) < 65536 * 4 ? cdiv64(total, 256) : 65536 * 4;

@@ -244,13 +244,14 @@ class DPVO:
     def corr(self, coords, indicies=None):
         """ local correlation volume (dpvo.py:200-207): fused two-level MFMA kernel -> [1, E, 882] f16 """
         ii, jj = indicies if indicies is not None else (self.pg.kk, self.pg.jj)
-        ii1 = ii % (self.M * self.pmem)
-        jj1 = jj % (self.mem)
         E = ii.numel()
         if self._gmap_cl.dtype == torch.float16:
+            # (ii % (M * pmem), jj % mem: the fused kernel reduces the indices modulo the buffer sizes itself)
             out = altcorr.corr_pyramid(self._gmap_cl.view(self.pmem * self.M, self.P * self.P, 128), self._fmap1_cl,
-                                       self._fmap2_cl, coords, ii1, jj1, radius=3)
+                                       self._fmap2_cl, coords, ii, jj, radius=3)
             return out.unsqueeze(0)
+        ii1 = ii % (self.M * self.pmem)
+        jj1 = jj % (self.mem)
         corr1 = altcorr.corr(self.gmap, self.pyramid[0], coords / 1, ii1, jj1, 3)
         corr2 = altcorr.corr(self.gmap, self.pyramid[1], coords / 4, ii1, jj1, 3)
         return torch.stack([corr1, corr2], -1).view(1, E, -1)

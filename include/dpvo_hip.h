@@ -63,7 +63,8 @@ int dpvo_corr_forward(const void* fmap1, const int64_t* s1, const void* fmap2, c
  *   gmap   [N1, P*P, C]      f16 channels-last  (logical [N1,C,P,P])
  *   fmap0  [N2, H0, W0, C]   f16 channels-last  (logical [N2,C,H0,W0]), level 0 (coords/1)
  *   fmap1  [N2, H1, W1, C]   f16 channels-last, level 1 (coords/4)
- *   coords [E,2,P,P] f32; us,vs [E] int64 (already reduced modulo the ring sizes)
+ *   coords [E,2,P,P] f32; us,vs [E] int64, non-negative, < 2^31: template / frame indices, taken modulo N1 / N2 by the
+ *          kernel (the ring-buffer reduction of dpvo.py:202-203; already reduced indices are unchanged)
  *   order  [E] int32 or NULL: processing order of edges (an L2 / XCD locality hint; any permutation
  *          of 0..E-1; results do not depend on it)
  *   out    [E, ld_out] f16, ld_out >= 2*49*P*P, feature index ((((x*7+y)*P+i0)*P+j0)*2+level)
