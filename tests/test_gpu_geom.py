@@ -137,3 +137,21 @@ def test_plan_bit_exact(oracle, dev, case, ranged):
     for g in (0, plan.n_pairs() - 1):
         mem = perm_p[poff[g]:poff[g + 1]]
         assert (ii.numpy()[mem] == pij[g, 0]).all() and (jj.numpy()[mem] == pij[g, 1]).all()
+
+
+def test_plan_window_reports_ids_outside_the_window(dev):
+    """dpvo_plan_build_window: ids outside the promised window are clamped (no out-of-bounds access) and flagged in counts[3];
+    windows too wide for the counting sort fall back to the radix build by themselves"""
+    ii, jj, kk = S.replay_graph(20)
+    E = ii.numel()
+    flo, nfw, plo, npw = int(min(ii.min(), jj.min())), int(max(ii.max(), jj.max())) + 1, int(kk.min()), int(kk.max()) + 1
+    good = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), window=(flo, nfw - flo, plo, npw - plo))
+    assert good.counts.cpu().tolist()[3] == 0
+    bad = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), window=(flo + 2, nfw - flo - 2, plo + 50, npw - plo - 50))
+    torch.cuda.synchronize()
+    assert bad.counts.cpu().tolist()[3] == 1
+    assert int(bad.perm_k.min()) >= 0 and int(bad.perm_k.max()) < E and int(bad.perm_p.min()) >= 0 and int(bad.perm_p.max()) < E
+    wide = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), window=(0, 4096, 0, 4096 * 96))        # -> dpvo_plan_build_ranged
+    for name in ("perm_k", "ku", "ix", "jx", "perm_p", "pu"):
+        assert torch.equal(getattr(wide, name), getattr(good, name)), name
+    assert wide.counts.cpu().tolist()[:2] == good.counts.cpu().tolist()[:2]
