@@ -11,8 +11,10 @@
 //                         from an LDS row image -> pairbuf[g][16x16]; per-edge depth terms (c, u, Ei, Ej) -> edgebuf.
 //   2. ba_patch_kernel    a block owns 32 patches (CSR by patch), 8 lanes gather one patch's edges: builds the Schur
 //                         column e_k (6N) in LDS, stores Q, u, e_k, and the block's partial  sum_k Q_k e_k e_k^T,
-//                         sum_k Q_k u_k e_k  -> spart[block].
-//   3. ba_assemble_kernel one thread per entry of S / y: B, v from pairbuf in a fixed order, minus the Schur
+//                         sum_k Q_k u_k e_k  -> spart[block].  The same launch carries one extra block per free pose
+//                         that assembles its block row of B and v from pairbuf in a fixed order -> Bbuf (independent
+//                         work: it used to sit in front of the Schur subtraction in the next launch).
+//   3. ba_assemble_kernel six blocks per free pose, 4 lanes per entry of a row of S / y: B, v (Bbuf) minus the Schur
 //                         partials, plus the reference's damping S += I*(1e-4*S + 1)  -> Sg, yg.
 //   4. ba_solve60_kernel  n6 <= 60: one workgroup, 6x6-blocked right-looking Cholesky of [S; y^T] in LDS, blocked backward
 //                         substitution -> dX;  ba_solve_kernel (n6 <= 120): left-looking Cholesky in LDS (one barrier per
@@ -27,21 +29,17 @@ using namespace ba;
 // ---------------------------------------------------------------------------------------------------
 // 2. per-patch kernel: Schur columns + partial Schur products; block = 32 patches x 8 lanes
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
-                                                       const int32_t* __restrict__ perm_k,
-                                                       const int32_t* __restrict__ patch_off,
-                                                       const int32_t* __restrict__ n_patches,
-                                                       const float* __restrict__ edgebuf, float lmbda, int t0, int N,
-                                                       float* __restrict__ Qbuf, float* __restrict__ ubuf,
-                                                       float* __restrict__ Ecol, int64_t ldE,
-                                                       float* __restrict__ spart) {
+__device__ __forceinline__ void ba_patch_body(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                              const int32_t* __restrict__ perm_k, const int32_t* __restrict__ patch_off,
+                                              const int32_t* __restrict__ n_patches, const float* __restrict__ edgebuf,
+                                              float lmbda, int t0, int N, float* __restrict__ Qbuf, float* __restrict__ ubuf,
+                                              float* __restrict__ Ecol, int64_t ldE, float* __restrict__ spart, int ch) {
   __shared__ float col[kPatchChunk][kMaxDim + 1];
   __shared__ float qv[kPatchChunk], uv[kPatchChunk];
   const int n6 = 6 * N;
   const int np = *n_patches;
   const int tid = threadIdx.x;
   const int nent = n6 * n6 + n6;                       // S entries followed by y entries
-  const int ch = blockIdx.x;
   for (int a = tid; a < kPatchChunk * (kMaxDim + 1); a += 256) (&col[0][0])[a] = 0.f;
   __syncthreads();
   {
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
     if (k < np) Ecol[(int64_t)r * ldE + k] = col[pl][r];
   }
   // partial S and y of this block
-  float* sp = spart + (int64_t)blockIdx.x * kSEntries;
+  float* sp = spart + (int64_t)ch * kSEntries;
   for (int ent = tid; ent < nent; ent += 256) {
     float sum = 0.f;
     if (ent < n6 * n6) {
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3. assemble kernel: one block per free pose p = block row p of S (6 x n6) and y[6p..6p+5]
+// 2b. B part: one block per free pose p = block row p of B (6 x n6) and v[6p..6p+5]
 //    wave 0: diagonal block + y: lanes stride over the pairs, per-lane partial sums, fixed-order butterfly;
 //    waves 1..3: off-diagonal blocks (two binary searches in the LDS copy of the sorted pair list);
 //    then all threads: subtract the Schur partials (4 lanes per entry) and apply the damping.
@@ -132,11 +130,10 @@ __device__ __forceinline__ int find_pair(const int2* pl, int ng, int i, int j) {
   return -1;
 }
 
-__global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restrict__ pair_ij,
-                                                          const int32_t* __restrict__ n_pairs,
-                                                          const float* __restrict__ pairbuf,
-                                                          const float* __restrict__ spart, int n_spart, int t0, int N,
-                                                          float* __restrict__ Sg, float* __restrict__ yg) {
+// B part of block row p (and v of pose p) from the pair blocks, in a fixed order -> Bbuf[p][6][kMaxDim + 1] (column kMaxDim
+// holds v).  Independent of the per-patch kernel, whose launch it shares.
+__device__ __forceinline__ void ba_bpart_body(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
+                                              const float* __restrict__ pairbuf, int t0, int N, int p, float* __restrict__ Bbuf) {
   __shared__ int2 plist[kMaxPairsLds];
   __shared__ float rowS[6][kMaxDim];      // block row p of B (then S)
   __shared__ float rowy[6];
@@ -144,7 +141,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
   const int ng = *n_pairs;
   const int ngl = ng < kMaxPairsLds ? ng : kMaxPairsLds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = blockIdx.x, f = t0 + p;
+  const int f = t0 + p;
   const int2* pg = reinterpret_cast<const int2*>(pair_ij);
   for (int g = tid; g < ngl; g += 256) plist[g] = pg[g];
   for (int a = tid; a < 6 * kMaxDim; a += 256) (&rowS[0][0])[a] = 0.f;
@@ -208,10 +205,40 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
     if (tid < 36) rowS[tid / 6][6 * p + tid % 6] = s; else rowy[tid - 36] = s;
   }
   __syncthreads();
+  float* dst = Bbuf + (int64_t)p * 6 * (kMaxDim + 1);
+  for (int a = tid; a < 6 * n6; a += 256) { const int r = a / n6, c = a - r * n6; dst[r * (kMaxDim + 1) + c] = rowS[r][c]; }
+  if (tid < 6) dst[tid * (kMaxDim + 1) + kMaxDim] = rowy[tid];
+}
+
+__global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                                       const int32_t* __restrict__ perm_k,
+                                                       const int32_t* __restrict__ patch_off,
+                                                       const int32_t* __restrict__ n_patches,
+                                                       const float* __restrict__ edgebuf, float lmbda, int t0, int N,
+                                                       float* __restrict__ Qbuf, float* __restrict__ ubuf,
+                                                       float* __restrict__ Ecol, int64_t ldE, float* __restrict__ spart,
+                                                       int patch_blocks, const int32_t* __restrict__ pair_ij,
+                                                       const int32_t* __restrict__ n_pairs, const float* __restrict__ pairbuf,
+                                                       float* __restrict__ Bbuf) {
+  if ((int)blockIdx.x < patch_blocks)
+    ba_patch_body(ii, jj, perm_k, patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, ldE, spart, blockIdx.x);
+  else
+    ba_bpart_body(pair_ij, n_pairs, pairbuf, t0, N, (int)blockIdx.x - patch_blocks, Bbuf);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3. assemble kernel: block (p, ra) = row 6p + ra of S and y[6p + ra]: B (from Bbuf) minus the Schur partials, damping
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_assemble_kernel(const float* __restrict__ Bbuf, const float* __restrict__ spart,
+                                                          int n_spart, int N, float* __restrict__ Sg, float* __restrict__ yg) {
+  const int n6 = 6 * N;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  const float* brow = Bbuf + ((int64_t)p * 6 + blockIdx.y) * (kMaxDim + 1);
   // Schur complement (ba_cuda.cu:557-558) + damping (:560).  blockIdx.y = row ra of the pose's block row: its n6 entries of
   // S and its entry of y, 4 lanes per entry; four partial matrices per trip so that their loads overlap (the adds keep
-  // the order b, b+4, ...).  (The B part above is recomputed by the six row-workgroups: it is a few LDS lookups, while
-  // the 69 partial matrices are a chain of dependent global round trips worth splitting six ways.)
+  // the order b, b+4, ...).  (Six row-workgroups per pose: the 69 partial matrices are a chain of dependent global round
+  // trips worth splitting six ways.)
   const int ra = blockIdx.y;
   const int nrow = n6 + 1;
   constexpr int kIt = (kMaxDim + 1 + 63) / 64;          // 2
@@ -247,11 +274,11 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(const int32_t* __restr
     const int e4 = it * 64 + (tid >> 2);
     if (e4 < nrow && sub == 0) {
       if (e4 < n6) {
-        float sv = rowS[ra][e4] - v;
+        float sv = brow[e4] - v;
         if (6 * p + ra == e4) sv += 1e-4f * sv + 1.0f;                // S += I * (1e-4 * S + 1.0)
         Sg[gent[it]] = sv;
       } else {
-        yg[6 * p + ra] = rowy[ra] - v;
+        yg[6 * p + ra] = brow[kMaxDim] - v;
       }
     }
   }
@@ -540,7 +567,7 @@ __global__ void ba_retr_kernel(float* __restrict__ poses, float* __restrict__ pa
 }
 
 struct BaWs {
-  size_t pairbuf, edgebuf, Qbuf, ubuf, Ecol, spart, Sg, yg, dX, total;
+  size_t pairbuf, edgebuf, Qbuf, ubuf, Ecol, spart, Sg, yg, dX, Bbuf, total;
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -559,6 +586,7 @@ inline void ba_ws_layout(int64_t E, int N, BaWs* L) {
   L->Sg = o; o += al((size_t)kMaxDim * kMaxDim * 4);
   L->yg = o; o += al(kMaxDim * 4);
   L->dX = o; o += al(kMaxDim * 4);
+  L->Bbuf = o; o += al((size_t)kMaxN * 6 * (kMaxDim + 1) * 4);
   L->total = o;
 }
 
@@ -595,6 +623,7 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
   float* Sg = (float*)(w + L.Sg);
   float* yg = (float*)(w + L.yg);
   float* dX = (float*)(w + L.dX);
+  float* Bbuf = (float*)(w + L.Bbuf);
   hipStream_t st = (hipStream_t)stream;
   const int32_t* n_patches = plan + PL.counts + 0;
   const int32_t* n_pairs = plan + PL.counts + 1;
@@ -607,11 +636,12 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
   for (int itr = 0; itr < iterations; ++itr) {
     hipLaunchKernelGGL(ba_pair_kernel, dim3(pair_grid), dim3(128), 0, st, poses, patches, intrinsics, target, weight, kk,
                        plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, n_pairs, pairbuf, edgebuf, P);
-    hipLaunchKernelGGL(ba_patch_kernel, dim3(patch_blocks), dim3(256), 0, st, ii, jj, plan + PL.perm_k,
-                       plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, np_h, spart);
+    // per-patch blocks + (N > 0) one B-part block per free pose in the same launch: they are independent
+    hipLaunchKernelGGL(ba_patch_kernel, dim3(patch_blocks + (unsigned)N), dim3(256), 0, st, ii, jj, plan + PL.perm_k,
+                       plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, np_h, spart, (int)patch_blocks,
+                       plan + PL.pair_ij, n_pairs, pairbuf, Bbuf);
     if (N > 0) {
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, spart,
-                         (int)patch_blocks, t0, N, Sg, yg);
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(256), 0, st, Bbuf, spart, (int)patch_blocks, N, Sg, yg);
       if (6 * N <= 60)
         hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
       else if (6 * N <= 64)
