@@ -311,11 +311,26 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
   __shared__ float zs[64];
   __shared__ int s_bad;
   const int n6 = 6 * N, tid = threadIdx.x;
-  // lower triangle of S and y as row n6
-  for (int r = tid >> 4; r <= n6; r += 16) {
-    const float* src = (r < n6) ? Sg + r * n6 : yg;
-    const int cend = (r < n6) ? r : n6 - 1;
-    for (int c = tid & 15; c <= cend; c += 16) A[r * kLd60 + c] = src[c];
+  // lower triangle of S and y as row n6: thread (ty, tx) of a 16 x 16 grid owns the elements (ty + 16 i, tx + 16 j); all 16
+  // loads are issued before the first LDS store (as a nested loop they were 16 dependent global round trips)
+  {
+    const int ty = tid >> 4, tx = tid & 15;
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = ty + 16 * i, c = tx + 16 * j;
+        const bool on = r <= n6 && c < n6 && (c <= r);
+        v[i][j] = on ? (r < n6 ? Sg[r * n6 + c] : yg[c]) : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = ty + 16 * i, c = tx + 16 * j;
+        if (r <= n6 && c < n6 && c <= r) A[r * kLd60 + c] = v[i][j];
+      }
   }
   if (tid == 0) s_bad = 0;
   __syncthreads();
@@ -323,11 +338,22 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
     const int o = 6 * B;
     const int r = o + tid;
     if (r <= n6) {                             // panel: rows o..n6 (n6 - o + 1 <= 61 lanes of wave 0)
+      // every LDS operand first (27 independent reads), then the dependent arithmetic: interleaved, each read was a
+      // ~100-cycle round trip inside the factorisation chain
+      float D[6][6], x[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) D[i][c] = A[(o + i) * kLd60 + o + c];
+      float* ar = A + r * kLd60 + o;
+      const bool below = r >= o + 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x[c] = below ? ar[c] : 0.f;
       float Lb[6][6], inv[6];
       int bad = 0;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        float d = A[(o + c) * kLd60 + o + c];
+        float d = D[c][c];
 #pragma unroll
         for (int k = 0; k < c; ++k) d -= Lb[c][k] * Lb[c][k];
         if (!(d > 0.f) && bad == 0) bad = o + c + 1;
@@ -335,18 +361,16 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
         Lb[c][c] = d * inv[c];
 #pragma unroll
         for (int r2 = c + 1; r2 < 6; ++r2) {
-          float v = A[(o + r2) * kLd60 + o + c];
+          float v = D[r2][c];
 #pragma unroll
           for (int k = 0; k < c; ++k) v -= Lb[r2][k] * Lb[c][k];
           Lb[r2][c] = v * inv[c];
         }
       }
-      if (r >= o + 6) {                        // rows below the block (nobody writes the block's own rows in this step)
-        float x[6];
-        float* ar = A + r * kLd60 + o;
+      if (below) {                             // rows below the block (nobody writes the block's own rows in this step)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          float v = ar[c];
+          float v = x[c];
 #pragma unroll
           for (int k = 0; k < c; ++k) v -= x[k] * Lb[c][k];
           x[c] = v * inv[c];
@@ -412,21 +436,24 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
       const int o = 6 * B;
       zs[tid] = z;
       wave_lds_sync();
-      const float* Lb = Lbb[B];
+      // operands first (the block's factor, its right-hand side, this lane's column of the block rows), then the chain
+      float Lv[27], sv[6], col[6];
+#pragma unroll
+      for (int q = 0; q < 27; ++q) Lv[q] = Lbb[B][q];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { sv[c] = zs[o + c]; col[c] = (tid < o) ? A[(o + c) * kLd60 + tid] : 0.f; }
       float x[6];
 #pragma unroll
       for (int c = 5; c >= 0; --c) {
-        float v = zs[o + c];
+        float v = sv[c];
 #pragma unroll
-        for (int k = c + 1; k < 6; ++k) v -= Lb[k * (k + 1) / 2 + c] * x[k];
-        x[c] = v * Lb[21 + c];
+        for (int k = c + 1; k < 6; ++k) v -= Lv[k * (k + 1) / 2 + c] * x[k];
+        x[c] = v * Lv[21 + c];
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) xv = (tid == o + k) ? x[k] : xv;
-      if (tid < o) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) z -= A[(o + k) * kLd60 + tid] * x[k];
-      }
+      for (int k = 0; k < 6; ++k) z -= col[k] * x[k];
       wave_lds_sync();
     }
     if (tid < n6) dX[tid] = xv;
