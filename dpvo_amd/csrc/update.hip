@@ -897,27 +897,55 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(const void* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
-// SoftAgg: one 384-thread block per group, online softmax over the group's member rows.
+// SoftAgg: one 384-thread block per group.  Thread (q, cq): member slice q = t / 96 (members b + q, b + q + 4, ...) and
+// channels [4 cq, 4 cq + 4) -- 8-byte loads (with one channel per thread the kernel was bound by the NUMBER of 2-byte
+// vector loads: 96 members x 12 wave-loads for a frame-pair group) and a dependent online-softmax chain of a quarter of
+// the members; the four partial (max, sum, weighted sum) triples are merged through LDS in the fixed order q = 0..3.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(384) void softagg_kernel(const _Float16* __restrict__ fg, int64_t ldfg,
                                                       const int32_t* __restrict__ perm, const int32_t* __restrict__ off,
                                                       const int32_t* __restrict__ n_groups, _Float16* __restrict__ y,
                                                       int D) {
+  __shared__ float part[4][3][384];
   const int ng = *n_groups;
-  const int c = threadIdx.x;
+  const int q = threadIdx.x / 96, cq = threadIdx.x - 96 * q;
   for (int g = blockIdx.x; g < ng; g += gridDim.x) {
     const int b = off[g], e = off[g + 1];
-    float m = -INFINITY, s = 0.f, a = 0.f;
-    for (int p = b; p < e; ++p) {
-      const _Float16* rowp = fg + (int64_t)perm[p] * ldfg;
-      const float fx = (float)rowp[c], gx = (float)rowp[D + c];
-      const float mn = fmaxf(m, gx);
-      const float sc = __expf(m - mn), w = __expf(gx - mn);
-      s = s * sc + w;
-      a = a * sc + w * fx;
-      m = mn;
+    float m[4], s[4], a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; s[r] = 0.f; a[r] = 0.f; }
+    for (int p = b + q; p < e; p += 4) {
+      const _Float16* rowp = fg + (int64_t)perm[p] * ldfg + 4 * cq;
+      const h4 fx = *reinterpret_cast<const h4*>(rowp), gx = *reinterpret_cast<const h4*>(rowp + D);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float g_ = (float)gx[r];
+        const float mn = fmaxf(m[r], g_);
+        const float sc = __expf(m[r] - mn), w = __expf(g_ - mn);
+        s[r] = s[r] * sc + w;
+        a[r] = a[r] * sc + w * (float)fx[r];
+        m[r] = mn;
+      }
     }
-    y[(int64_t)g * D + c] = (_Float16)(a / s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[q][0][4 * cq + r] = m[r]; part[q][1][4 * cq + r] = s[r]; part[q][2][4 * cq + r] = a[r]; }
+    __syncthreads();
+    {
+      const int c = threadIdx.x;
+      float M = part[0][0][c];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) M = fmaxf(M, part[k][0][c]);
+      float S = 0.f, A = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mk = part[k][0][c];
+        const float sc = (mk == -INFINITY) ? 0.f : __expf(mk - M);      // an empty slice (fewer than 4 members) contributes nothing
+        S += part[k][1][c] * sc;
+        A += part[k][2][c] * sc;
+      }
+      y[(int64_t)g * D + c] = (_Float16)(A / S);
+    }
+    __syncthreads();
   }
 }
 
@@ -1074,7 +1102,7 @@ extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, c
                             const int32_t* n_groups, int64_t max_groups, void* y, int D, void* stream) {
   if (max_groups < 0) return DPVO_E_INVALID;
   if (max_groups == 0) return DPVO_OK;
-  if (D != 384) return DPVO_E_UNSUPPORTED;
+  if (D != 384 || (ldfg % 4) || ((uintptr_t)fg & 7)) return DPVO_E_UNSUPPORTED;      // 8-byte row loads
   if (!fg || !perm || !off || !n_groups || !y) return DPVO_E_INVALID;
   const unsigned grid = (unsigned)(max_groups < 8192 ? max_groups : 8192);
   hipLaunchKernelGGL(softagg_kernel, dim3(grid), dim3(384), 0, (hipStream_t)stream, (const _Float16*)fg, ldfg, perm, off,
