@@ -99,3 +99,30 @@ def test_reference_import_names_resolve():
             "from dpvo.lietorch import SE3; import dpvo_amd.dpvo as d; assert DPVO is d.DPVO; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """the ctypes mirrors of the header's structs (plan layout, update parameter table, frame state) have the C sizes and
+    field offsets: compiled from include/dpvo_hip.h with the host C compiler"""
+    import subprocess
+    from dpvo_amd import _lib as L
+    from dpvo_amd.net import _UpdParams
+    probes = {"dpvo_plan_layout_t": (L.PlanLayout, ["perm_k", "counts", "total_ints"]),
+              "dpvo_update_params_t": (_UpdParams, ["c0_w", "g1_b2", "w_b"]),
+              "dpvo_frame_state_t": (L.FrameState, ["fmap", "index_map", "poses", "ix", "frame_next", "n_new", "res", "mm_scale", "M",
+                                                    "P", "mm_n", "D"])}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dpvo_hip.h"', 'int main(void) {']
+    for cname, (_, fields) in probes.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, (cls, fields) in probes.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for f in fields:
+            assert int(out[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
