@@ -21,7 +21,10 @@ The JSON line also carries
                   inside the timed region, against the 8 TB/s HBM3E peak; `traffic` = bytes per launch seen by the
                   memory-side counters in the committed PMC pass (profiles/rNN_corr_pmc.json);
   cpu_baseline -- the CPU oracle ("port": oracle/liboracle.so + oracle/update_ref.py) timed on rank 0 at N = 1 on
-                  ONE full hot-path step (reproject, corr, update, 2 BA iterations at E = 45 312).
+                  two full hot-path steps (reproject, corr, update, 2 BA iterations at E = 45 312), ~10 s;
+  state        -- whether the tracker state after the run is sane (finite poses, fraction of edges that project in
+                  bounds): with random weights nothing guarantees that, and a diverged state would make the correlation
+                  kernel skip its work; such a run carries an "error" field.
 """
 import argparse
 import json
