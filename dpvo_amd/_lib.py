@@ -24,6 +24,7 @@ SYMBOLS = [
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
     "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target", "dpvo_update_workspace_bytes", "dpvo_update_forward",
+    "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
@@ -68,7 +69,8 @@ def lib():
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
         for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
-                  "dpvo_gba_workspace_bytes", "dpvo_encoders_workspace_bytes", "dpvo_update_workspace_bytes"):
+                  "dpvo_gba_workspace_bytes", "dpvo_encoders_workspace_bytes", "dpvo_update_workspace_bytes",
+                  "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
         _lib = L
     return _lib

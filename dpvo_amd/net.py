@@ -21,6 +21,9 @@ from .utils import coords_grid_with_index
 DIM = 384
 
 EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
+# Update.forward runs the fused row-tile kernels (update_fused.hip) unless told otherwise (DPVO_UPDATE_FUSED=0 selects the
+# launch-by-launch composite of update.hip; both stay tested against the oracle)
+FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
 
 
 # ------------------------------------------------------------------------------------------ kernels' Python face
@@ -89,6 +92,26 @@ class _UpdParams(ctypes.Structure):
         "akk_wfg", "akk_bfg", "akk_wh", "akk_bh", "aij_wfg", "aij_bfg", "aij_wh", "aij_bh",
         "g0_g", "g0_b", "g0_wrg", "g0_brg", "g0_w2", "g0_b2", "g1_g", "g1_b", "g1_wrg", "g1_brg", "g1_w2", "g1_b2",
         "d_w", "d_b", "w_w", "w_b")]
+
+
+UF_NLIN = 19          # DPVO_UF_* of include/dpvo_hip.h
+
+
+class _UpdFusedParams(ctypes.Structure):
+    """dpvo_update_fused_params_t"""
+    _fields_ = [("w", ctypes.c_void_p * UF_NLIN), ("b", ctypes.c_void_p * UF_NLIN), ("ln_g", ctypes.c_void_p * 4),
+                ("ln_b", ctypes.c_void_p * 4), ("d_w", ctypes.c_void_p), ("d_b", ctypes.c_void_p), ("w_w", ctypes.c_void_p),
+                ("w_b", ctypes.c_void_p)]
+
+
+def fused_pack(W, K=None, chained=True):
+    """dpvo_update_fused_pack: torch Linear weight [384, k] f16 -> the MFMA fragment image of update_fused.hip"""
+    assert W.dtype == torch.float16 and W.shape[0] == DIM and W.stride(1) == 1
+    K = K or W.shape[1]
+    out = torch.empty(DIM * K, dtype=torch.float16, device=W.device)
+    L.check(L.lib().dpvo_update_fused_pack(L.ptr(W), L.i64(W.stride(0)), L.i32(K), L.i32(W.shape[1]), L.i32(1 if chained else 0),
+                                           L.ptr(out), L.stream()), "dpvo_update_fused_pack")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ modules (reference tree)
@@ -167,6 +190,27 @@ class Update(nn.Module):
                P["norm"][0], P["norm"][1], *P["c1"], *P["c2n"], *P["akk"], *P["aij"], *P["g0"], *P["g1"], *P["d"], *P["w"]]
         assert len(tab) == len(_UpdParams._fields_)
         P["_params"] = _UpdParams(*[ctypes.c_void_p(t.data_ptr()) for t in tab])
+        if dev.type == "cuda":
+            # fragment images of the row-tile-resident kernels (update_fused.hip), order = DPVO_UF_* (include/dpvo_hip.h)
+            gr0, gr1 = self.gru[1], self.gru[3]
+            lins = [(self.corr[0], False), (self.corr[2], True), (self.corr[5], True),
+                    (self.c1[0], True), (self.c1[2], True), (self.c2[0], True), (self.c2[2], True),
+                    (self.agg_kk.f, True), (self.agg_kk.g, True), (self.agg_kk.h, True),
+                    (self.agg_ij.f, True), (self.agg_ij.g, True), (self.agg_ij.h, True),
+                    (gr0.gate[0], True), (gr0.res[0], True), (gr0.res[2], True),
+                    (gr1.gate[0], True), (gr1.res[0], True), (gr1.res[2], True)]
+            assert len(lins) == UF_NLIN
+            P["_fw"] = [fused_pack(h(m.weight), K=(self.kpad if not ch else DIM), chained=ch) for m, ch in lins]
+            P["_fb"] = [h(m.bias) for m, _ in lins]
+            fp = _UpdFusedParams()
+            for i in range(UF_NLIN):
+                fp.w[i] = P["_fw"][i].data_ptr()
+                fp.b[i] = P["_fb"][i].data_ptr()
+            for i, name in enumerate(("cln", "norm", "g0", "g1")):
+                fp.ln_g[i] = P[name][0].data_ptr()
+                fp.ln_b[i] = P[name][1].data_ptr()
+            fp.d_w, fp.d_b, fp.w_w, fp.w_b = (t.data_ptr() for t in (*P["d"], *P["w"]))
+            P["_fparams"] = fp
         self._packed = P
         return P
 
@@ -181,7 +225,7 @@ class Update(nn.Module):
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
-                out=None, coords=None, target_out=None, weight_out=None, composite=True):
+                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
         `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
@@ -225,6 +269,19 @@ class Update(nn.Module):
             if coords is not None:
                 assert coords.is_contiguous() and coords.dtype == torch.float32 and target_out is not None
             maxg = max(plan.n_patches_host, plan.n_pairs_host)
+            if fused is None:
+                fused = FUSED_DEFAULT
+            if fused:
+                # seven launches of row-tile-resident kernels (update_fused.hip)
+                nbytes = L.lib().dpvo_update_fused_workspace_bytes(L.i64(E), L.i64(maxg))
+                ws = workspace.get(nbytes, dev, "update_fused")
+                L.check(L.lib().dpvo_update_forward_fused(
+                    ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
+                    L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
+                    L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
+                    L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
+                    ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_update_forward_fused")
+                return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
             nbytes = L.lib().dpvo_update_workspace_bytes(L.i64(E), L.i64(maxg))
             ws = workspace.get(nbytes, dev, "update")
             L.check(L.lib().dpvo_update_forward(

@@ -336,6 +336,39 @@ int dpvo_update_forward(const dpvo_update_params_t* params, const float* net, co
                         int64_t n_pairs_ub, const float* coords, int P, float* net_out, float* delta, float* weight,
                         float* target, int64_t E, void* ws, size_t ws_bytes, void* stream);
 
+/* The same operator as SEVEN launches of row-tile-resident MFMA kernels (dpvo_amd/csrc/update_fused.hip): a workgroup keeps
+ * a tile of edge rows in LDS for a whole chain of Linear layers (LayerNorm, residual, gate and the heads in the epilogues),
+ * the weights stream from L2 as pre-packed MFMA fragments.  Same inputs, outputs and precision contract as
+ * dpvo_update_forward (results agree to f32 summation order: the k index of chained layers is permuted).
+ *   dpvo_update_fused_pack: W [384, ldw] f16 row-major (torch Linear weight) with K columns (a multiple of 16; columns
+ *     >= k_valid read as zero) -> the fragment image (dpvo_update_fused_pack_bytes(K) bytes) the kernels consume;
+ *     chained = 0 for the layer fed by the correlation rows (corr.0, K = 896), 1 for every other layer (K = 384).
+ *   w[i] / b[i]: packed image / f16 bias [384] of layer i (DPVO_UF_*); ln_g / ln_b: corr.3, norm, gru.0, gru.2 (f32);
+ *   d_w, w_w [2,384] and d_b, w_b [2] f16 (the heads, feature order). */
+enum {
+  DPVO_UF_C0 = 0, DPVO_UF_C2, DPVO_UF_C5,                       /* Update.corr.0 / .2 / .5          (net.py:51-59) */
+  DPVO_UF_C1_0, DPVO_UF_C1_2, DPVO_UF_C2N_0, DPVO_UF_C2N_2,     /* Update.c1.0 / .2, Update.c2.0 / .2 (net.py:31-39) */
+  DPVO_UF_AKK_F, DPVO_UF_AKK_G, DPVO_UF_AKK_H,                  /* Update.agg_kk.f / .g / .h        (blocks.py:36-38) */
+  DPVO_UF_AIJ_F, DPVO_UF_AIJ_G, DPVO_UF_AIJ_H,
+  DPVO_UF_G0_GATE, DPVO_UF_G0_RES0, DPVO_UF_G0_RES2,            /* Update.gru.1.gate.0 / .res.0 / .res.2 (blocks.py:19-26) */
+  DPVO_UF_G1_GATE, DPVO_UF_G1_RES0, DPVO_UF_G1_RES2,            /* Update.gru.3 ...                                 */
+  DPVO_UF_NLIN
+};
+typedef struct {
+  const void* w[DPVO_UF_NLIN];
+  const void* b[DPVO_UF_NLIN];
+  const float* ln_g[4];
+  const float* ln_b[4];
+  const void *d_w, *d_b, *w_w, *w_b;
+} dpvo_update_fused_params_t;
+size_t dpvo_update_fused_pack_bytes(int K);
+int dpvo_update_fused_pack(const void* W, int64_t ldw, int K, int k_valid, int chained, void* out, void* stream);
+size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups);
+int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const float* net, const void* inp,
+                              const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan,
+                              int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
+                              float* delta, float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * feature encoders  (Patchifier.fnet / .inet: dpvo/extractor.py:200-264, called at dpvo/net.py:116-117)
  * ---------------------------------------------------------------------------------------------- */

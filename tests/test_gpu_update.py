@@ -109,8 +109,9 @@ def test_layernorm_softagg_heads(dev):
     H.assert_close(w.cpu().numpy(), rw.numpy(), 2e-3, 2e-3, "head w")
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("first_call", [True, False])
-def test_update_forward_vs_oracle(oracle, dev, first_call):
+def test_update_forward_vs_oracle(oracle, dev, first_call, fused):
     from oracle import update_ref
     torch.manual_seed(1234)
     upd = N.Update(3)
@@ -129,7 +130,8 @@ def test_update_forward_vs_oracle(oracle, dev, first_call):
     rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=True)
     rn2, rd2, rw2 = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
     upd = upd.to(dev)
-    out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
+    out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev),
+                         fused=fused)
     assert out.shape == (1, E, 384) and out.dtype == torch.float32 and d.shape == (1, E, 2) and w.shape == (1, E, 2)
     for ref_n, ref_d, ref_w, tag in ((rn, rd, rw, "half-scatter"), (rn2, rd2, rw2, "exact-scatter")):
         H.assert_close(out[0].cpu().numpy(), ref_n.numpy(), 2e-2, 1e-2, f"net ({tag})")
@@ -143,9 +145,9 @@ def test_update_forward_vs_oracle(oracle, dev, first_call):
     buf = torch.zeros(E, 896, dtype=torch.float16); buf[:, :882] = corr
     bufd = buf.to(dev)
     out2, (d2, w2, _) = upd(net[None].to(dev), imap[None].to(dev), bufd[:, :882][None], None, ii.to(dev), jj.to(dev),
-                            kk.to(dev), inp_rows=rows.to(dev), inp_mod=40, corr_is_padded=True)
+                            kk.to(dev), inp_rows=rows.to(dev), inp_mod=40, corr_is_padded=True, fused=fused)
     out3, (d3, w3, _) = upd(net[None].to(dev), imap[rows % 40][None].to(dev), corr[None].to(dev), None, ii.to(dev),
-                            jj.to(dev), kk.to(dev))
+                            jj.to(dev), kk.to(dev), fused=fused)
     assert torch.equal(out2, out3) and torch.equal(d2, d3) and torch.equal(w2, w3)
 
 
@@ -191,8 +193,79 @@ def test_composite_entry_equals_launch_by_launch(dev, E_frames):
     for comp in (False, True):
         tgt = torch.zeros(E, 2, device=dev); wgt = torch.zeros(E, 2, device=dev)
         x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
-                           corr_is_padded=True, coords=coords, target_out=tgt, weight_out=wgt, composite=comp)
+                           corr_is_padded=True, coords=coords, target_out=tgt, weight_out=wgt, composite=comp, fused=False)
         res.append((x.clone(), d.clone(), w.clone(), tgt, wgt))
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert torch.equal(res[1][3], coords[0, :, :, 1, 1] + res[1][1][0])
+
+
+@pytest.mark.parametrize("E_frames", [14, 40])
+def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames):
+    """the row-tile-resident kernels (update_fused.hip) against the launch-by-launch kernels (update.hip): same rounding
+    points, different f32 summation order (the k index of chained layers is permuted, 32x32x16 instead of 16x16x32 MFMA),
+    so a Linear output may differ by one f16 ulp where the f32 sum sits on a rounding boundary; the fused target / weight
+    outputs and the imap gather are covered too.  Stated tolerance: |net| 1e-2 abs (a few f16 ulps of an O(1..4) state through
+    ~20 layers), RMS 5e-4; delta 1e-2 px; weight 4e-3."""
+    from dpvo_amd import synthetic as S
+    from dpvo_amd.graph import GraphPlan
+    torch.manual_seed(7)
+    upd = N.Update(3).to(dev)
+    with torch.no_grad():
+        for p in upd.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    ii, jj, kk = (t.to(dev) for t in S.replay_graph(E_frames))
+    E = ii.numel()
+    g = torch.Generator().manual_seed(5)
+    net = torch.randn(E, 384, generator=g).to(dev)
+    imap = torch.randn(3456, 384, generator=g).half().to(dev)
+    corr = torch.zeros(E, 896, dtype=torch.float16, device=dev)
+    corr[:, :882] = torch.randn(E, 882, generator=g).half().to(dev)
+    coords = (torch.rand(1, E, 2, 3, 3, generator=g) * 100).to(dev)
+    plan = GraphPlan(ii, jj, kk)
+    res = []
+    for fz in (False, True, True):
+        tgt = torch.zeros(E, 2, device=dev); wgt = torch.zeros(E, 2, device=dev)
+        x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
+                           corr_is_padded=True, coords=coords, target_out=tgt, weight_out=wgt, fused=fz)
+        res.append((x.clone(), d.clone(), w.clone(), tgt, wgt))
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b), "the fused path is deterministic"
+    (xa, da, wa, ta, ga), (xb, db, wb, tb, gb) = res[0], res[1]
+    assert torch.isfinite(xb).all()
+    dx = (xa - xb).abs()
+    print("fused vs unfused: net max %.2e rms %.2e, delta max %.2e, weight max %.2e" % (
+        dx.max().item(), (dx ** 2).mean().sqrt().item(), (da - db).abs().max().item(), (wa - wb).abs().max().item()))
+    assert dx.max().item() < 1e-2 and (dx ** 2).mean().sqrt().item() < 5e-4
+    assert (da - db).abs().max().item() < 1e-2 and (wa - wb).abs().max().item() < 4e-3
+    assert torch.equal(wb[0], gb) and torch.equal(tb, coords[0, :, :, 1, 1] + db[0])
+
+
+def test_update_full_size_vs_oracle(oracle, dev):
+    """E = 45 312 (BASELINE config 2): ONE full Update.forward of the fused kernels against oracle/update_ref.py on every
+    edge (f64 math with the autocast rounding points; ~20 s of CPU).  Same stated tolerances as the small cases."""
+    from oracle import update_ref
+    from dpvo_amd import synthetic as S
+    torch.manual_seed(1234)
+    upd = N.Update(3)
+    with torch.no_grad():
+        for p in upd.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    ii, jj, kk = S.replay_graph(40)
+    E = ii.numel()
+    assert E == 45312
+    g = torch.Generator().manual_seed(11)
+    net = torch.randn(E, 384, generator=g); inp = torch.randn(E, 384, generator=g).half()
+    corr = torch.randn(E, 882, generator=g).half()
+    sd = {k: v for k, v in upd.state_dict().items()}
+    rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
+    upd = upd.to(dev)
+    out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev),
+                         fused=True)
+    H.assert_close(out[0].cpu().numpy(), rn.numpy(), 2e-2, 1e-2, "net (full size)")
+    rms = float(((out[0].cpu().double() - rn) ** 2).mean().sqrt())
+    assert rms < 2e-3, rms
+    H.assert_close(d[0].cpu().numpy(), rd.numpy(), 1e-2, 1e-2, "delta (full size)")
+    H.assert_close(w[0].cpu().numpy(), rw.numpy(), 5e-3, 5e-3, "weight (full size)")
