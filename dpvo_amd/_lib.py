@@ -25,6 +25,7 @@ SYMBOLS = [
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
     "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target", "dpvo_update_workspace_bytes", "dpvo_update_forward",
     "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused",
+    "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
@@ -70,7 +71,7 @@ def lib():
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
         for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
                   "dpvo_gba_workspace_bytes", "dpvo_encoders_workspace_bytes", "dpvo_update_workspace_bytes",
-                  "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
+                  "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes", "dpvo_update_pm_workspace_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
         _lib = L
     return _lib

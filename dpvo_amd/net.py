@@ -24,6 +24,7 @@ EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 # Update.forward runs the fused row-tile kernels (update_fused.hip) unless told otherwise (DPVO_UPDATE_FUSED=0 selects the
 # launch-by-launch composite of update.hip; both stay tested against the oracle)
 FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
+PM_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_PM", "0")))      # patch-major (4 launches): opt-in, see DESIGN.md 3.4
 
 
 # ------------------------------------------------------------------------------------------ kernels' Python face
@@ -225,7 +226,7 @@ class Update(nn.Module):
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
-                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None):
+                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None, patch_edges_ub=None):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
         `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
@@ -271,6 +272,25 @@ class Update(nn.Module):
             maxg = max(plan.n_patches_host, plan.n_pairs_host)
             if fused is None:
                 fused = FUSED_DEFAULT
+            if fused == "pm" or (fused is True and PM_DEFAULT):
+                # four launches, edges in per-patch order (update_fused.hip, "patch-major"): needs an upper bound on the
+                # number of edges of one patch (DPVO passes 2 * PATCH_LIFETIME - 1; computed here, with a sync, otherwise)
+                ub = patch_edges_ub
+                if ub is None:
+                    ub = int(torch.bincount(kk.reshape(-1) - kk.min()).max().item())
+                if 0 < ub <= 96 and 2 * ((E + 95) // 96) + 48 <= 2048:
+                    nbytes = L.lib().dpvo_update_pm_workspace_bytes(L.i64(E), L.i64(maxg))
+                    ws = workspace.get(nbytes, dev, "update_pm")
+                    st = workspace.get(4, dev, "update_pm_status")
+                    L.check(L.lib().dpvo_update_forward_pm(
+                        ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
+                        L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(ub),
+                        L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
+                        L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
+                        ctypes.c_size_t(ws.numel()), L.ptr(st), L.stream()), "dpvo_update_forward_pm")
+                    self.pm_status = st          # device byte tensor: int32 1 = a patch exceeded the bound (checked by the caller)
+                    return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
+                fused = True                     # (does not fit the patch-major limits: the seven-launch path)
             if fused:
                 # seven launches of row-tile-resident kernels (update_fused.hip)
                 nbytes = L.lib().dpvo_update_fused_workspace_bytes(L.i64(E), L.i64(maxg))

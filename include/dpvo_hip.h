@@ -369,6 +369,18 @@ int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const fl
                               int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
                               float* delta, float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, void* stream);
 
+/* The same operator in FOUR launches, edges taken in the plan's per-patch order (perm_k): with tiles made of whole patches the
+ * neighbour rows of c1 / c2 (fastba.neighbors) are the adjacent rows of the tile and agg_kk is a segmented softmax inside it, so
+ * the corr MLP, norm, c1, c2, agg_kk and the f | g of agg_ij run in ONE kernel with the f32 state in registers; then the agg_ij
+ * softmax-sum, then agg_ij.h + gru + heads.  patch_edges_ub: the caller's upper bound on the number of edges of one patch
+ * (2 * PATCH_LIFETIME - 1 in DPVO); must be <= 96, and E <= ~46 000 * 2, else DPVO_E_UNSUPPORTED (use dpvo_update_forward_fused).
+ * status (device int32, may be NULL): set to 1 if a patch exceeded the bound (outputs then unspecified, memory safe). */
+size_t dpvo_update_pm_workspace_bytes(int64_t E, int64_t max_groups);
+int dpvo_update_forward_pm(const dpvo_update_fused_params_t* params, const float* net, const void* inp, const int64_t* inp_rows,
+                           int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan, int64_t n_patches_ub,
+                           int64_t n_pairs_ub, int64_t patch_edges_ub, const float* coords, int P, float* net_out, float* delta,
+                           float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, int32_t* status, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * feature encoders  (Patchifier.fnet / .inet: dpvo/extractor.py:200-264, called at dpvo/net.py:116-117)
  * ---------------------------------------------------------------------------------------------- */

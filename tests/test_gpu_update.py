@@ -109,7 +109,7 @@ def test_layernorm_softagg_heads(dev):
     H.assert_close(w.cpu().numpy(), rw.numpy(), 2e-3, 2e-3, "head w")
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", ["pm", "seven", False])
 @pytest.mark.parametrize("first_call", [True, False])
 def test_update_forward_vs_oracle(oracle, dev, first_call, fused):
     from oracle import update_ref
@@ -130,6 +130,8 @@ def test_update_forward_vs_oracle(oracle, dev, first_call, fused):
     rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=True)
     rn2, rd2, rw2 = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
     upd = upd.to(dev)
+    if fused == "seven":
+        fused = True
     out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev),
                          fused=fused)
     assert out.shape == (1, E, 384) and out.dtype == torch.float32 and d.shape == (1, E, 2) and w.shape == (1, E, 2)
@@ -200,8 +202,9 @@ def test_composite_entry_equals_launch_by_launch(dev, E_frames):
     assert torch.equal(res[1][3], coords[0, :, :, 1, 1] + res[1][1][0])
 
 
+@pytest.mark.parametrize("flavour", ["pm", "seven"])
 @pytest.mark.parametrize("E_frames", [14, 40])
-def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames):
+def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames, flavour):
     """the row-tile-resident kernels (update_fused.hip) against the launch-by-launch kernels (update.hip): same rounding
     points, different f32 summation order (the k index of chained layers is permuted, 32x32x16 instead of 16x16x32 MFMA),
     so a Linear output may differ by one f16 ulp where the f32 sum sits on a rounding boundary; the fused target / weight
@@ -225,10 +228,10 @@ def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames):
     coords = (torch.rand(1, E, 2, 3, 3, generator=g) * 100).to(dev)
     plan = GraphPlan(ii, jj, kk)
     res = []
-    for fz in (False, True, True):
+    for fz in (False, flavour, flavour):
         tgt = torch.zeros(E, 2, device=dev); wgt = torch.zeros(E, 2, device=dev)
         x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
-                           corr_is_padded=True, coords=coords, target_out=tgt, weight_out=wgt, fused=fz)
+                           corr_is_padded=True, coords=coords, target_out=tgt, weight_out=wgt, fused=(True if fz == "seven" else fz))
         res.append((x.clone(), d.clone(), w.clone(), tgt, wgt))
     for a, b in zip(res[1], res[2]):
         assert torch.equal(a, b), "the fused path is deterministic"
@@ -263,7 +266,8 @@ def test_update_full_size_vs_oracle(oracle, dev):
     rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
     upd = upd.to(dev)
     out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev),
-                         fused=True)
+                         fused="pm", patch_edges_ub=25)
+    assert int(upd.pm_status.view(torch.int32)[0].item()) == 0
     H.assert_close(out[0].cpu().numpy(), rn.numpy(), 2e-2, 1e-2, "net (full size)")
     rms = float(((out[0].cpu().double() - rn) ** 2).mean().sqrt())
     assert rms < 2e-3, rms

@@ -27,6 +27,11 @@ NAMES = {
                        "to_lds", "GEMM f", "f rows out", "GEMM g", "g rows out"]),
     3: ("K5 h + fg", ["gather issued", "gather landed", "-", "-", "GEMM h", "round + img add/store", "to_lds", "GEMM f",
                       "f rows out", "GEMM g", "g rows out"]),
+    5: ("KA (patch-major)", ["corr GEMM 896", "c2 + LN", "c5 + net/inp + LN", "c1, c2 (4 GEMMs)", "f, g of agg_kk", "softmax-sum",
+                             "h + expand", "f, g of agg_ij + rows out"]),
+    6: ("KB (patch-major)", ["y rows + GEMM h + img", "LN + gated residual 0", "LN + gated residual 1", "net out + heads"]),
+    7: ("KB gated residual 0, fine", ["LayerNorm", "W req + image store", "to_lds + barrier", "GEMM gate", "sigmoid + park", "GEMM res0",
+                                     "barrier + relu to_lds + barrier", "GEMM res2"]),
     4: ("K7 h + gru + heads", ["gather landed", "GEMM h", "img add + LN0", "W req + to_lds", "GEMM gate0", "park gate + GEMM res0",
                                "to_lds + GEMM res2", "gate*res + LN1", "W req + to_lds", "GEMM gate1", "park + GEMM res0",
                                "to_lds + GEMM res2", "gate*res", "net out + heads"]),
@@ -48,8 +53,10 @@ def main():
     imap = torch.randn(3456, 384, generator=g).half().to(dev)
     corr = torch.zeros(E, 896, dtype=torch.float16, device=dev); corr[:, :882] = torch.randn(E, 882, generator=g).half().to(dev)
     net = torch.randn(1, E, 384, generator=g).to(dev)
+    mode = os.environ.get("MODE", "pm")
+    N.PM_DEFAULT = False
     run = lambda: upd(net, imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True,
-                      fused=True)
+                      fused=("pm" if mode == "pm" else True), patch_edges_ub=25)
     for _ in range(3):
         run()
     buf = torch.zeros(8 * 1024 * 4 * 16, dtype=torch.int64, device=dev)
@@ -59,10 +66,20 @@ def main():
     torch.cuda.synchronize()
     L.lib().dpvo_debug_fu_trace_buffer(ctypes.c_void_p(0))
     t = buf.cpu().numpy().reshape(8, 1024, 4, 16).astype(np.int64)
+    kb = t[6, :256, 0]
+    ok = (kb[:, 13] > kb[:, 12]) & (kb[:, 4] > kb[:, 0])
+    if ok.any():
+        mhz = (kb[ok, 13] - kb[ok, 12]) / ((kb[ok, 4] - kb[ok, 0]) / 100.0)
+        print(f"shader clock during KB (s_memtime ticks per us of wall clock): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
+    t[6, :, :, 12:] = 0
     nb = (E + 95) // 96
     for k, (name, phases) in NAMES.items():
+        if k >= 5:
+            nb = 256                                   # persistent workgroups: the stamps are those of the LAST tile of each
         a = t[k, :nb]                                  # [block, wave, stamp]
         used = [i for i in range(16) if (a[:, 0, i] != 0).any()]
+        if not used:
+            continue
         t0 = a[:, :, 0][a[:, :, 0] > 0].min()
         start = (a[:, 0, 0] - t0) / 100.0             # us
         end = (a[:, 0, used[-1]] - t0) / 100.0
