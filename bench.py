@@ -4,22 +4,32 @@
     python bench.py --gpus N --steps K --warmup W
 
 One *step* = one `slam(t, image, intrinsics)` call on a synthetic 480x640 stream at the steady state of
-config/default.yaml (96 patches/frame, E = 45 312 active edges): patchify (torch/MIOpen encoders + HIP patch
+config/default.yaml (96 patches/frame, E = 45 312 active edges): patchify (HIP MFMA encoders + HIP patch
 gathers) -> edge bookkeeping -> reproject -> two-level correlation -> update operator -> 2 BA iterations ->
 keyframe test + edge removal.  Random-init weights (no dpvo.pth on disk), synthetic images; the two data-dependent
 gates that cannot behave sensibly with random weights are pinned so that the graph reaches and keeps the default
 steady state: the initialisation motion probe is accepted (dpvo.py:441-444) and no keyframe is dropped
 (KEYFRAME_THRESH = -1; the flow test itself, with its host read-backs, still runs every frame).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): replicas only -- every rank tracks its own sequence,
-RCCL is used for the start/stop barriers and the max-reduction of the elapsed time.  `value` is the
-whole-job frames/sec = N*K / max-over-ranks seconds; scaling is "weak".
+N > 1: replicas only -- every rank tracks its own sequence (one process per GPU), RCCL is used for the start/stop
+barriers and the gather of one small record per rank.  `value` is the whole-job frames/sec =
+N*K / max-over-ranks seconds; scaling is "weak".  Launched either by torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or plainly as `python bench.py --gpus N`, which re-executes itself under torch.distributed.run with N ranks
+on 127.0.0.1.  If the box shows fewer than N devices the ranks share them round-robin over gloo (a smoke mode for the
+launch path and the host-side cost, flagged in `config.parallelism`; not a scaling measurement).
+`per_rank` carries, for every rank, its seconds and the host CPU time it spent per frame (time.process_time).
 
 The JSON line also carries
-  roofline     -- the dominant kernel of the north-star path, corr_pyramid_kernel: ALGORITHMIC bytes per launch
-                  (E x 52 884 B) / its mean duration measured with HIP events on the launch stream
-                  inside the timed region, against the 8 TB/s HBM3E peak; `traffic` = bytes per launch seen by the
-                  memory-side counters in the committed PMC pass (profiles/rNN_corr_pmc.json);
+  roofline     -- the correlation kernel (corr_pyramid_kernel), mean launch duration from HIP events on the launch stream
+                  inside the timed region, against the 8 TB/s HBM3E peak, three ways:
+                    frac = frac_counter: bytes per launch seen by the memory-side counters (`traffic`, committed PMC pass
+                      profiles/rNN_corr_pmc.json, corrected as MI355X_MICROARCH.md prescribes) / duration / peak -- what the
+                      memory system actually moved (Infinity-Cache hits included);
+                    frac_streaming: SURVEY.md 8d's ALGORITHMIC bytes (E x 52 884 B, overlapping windows counted per edge) --
+                      exceeds 1 because the per-XCD L2s serve the overlap: it is NOT a utilisation;
+                    frac_compulsory: every byte touched once (live pyramid + templates + coords + indices + output);
+  roofline_update -- the update operator (net.py:74-92): reference FLOPs (5.40 MFLOP per edge) / mean duration
+                  of the whole operator (HIP events around it on the launch stream) against the 2.5 PFLOP/s dense f16 MFMA peak;
   cpu_baseline -- the CPU oracle ("port": oracle/liboracle.so + oracle/update_ref.py) timed on rank 0 at N = 1 on
                   two full hot-path steps (reproject, corr, update, 2 BA iterations at E = 45 312), ~10 s;
   state        -- whether the tracker state after the run is sane (finite poses, fraction of edges that project in
@@ -40,6 +50,8 @@ if ROOT not in sys.path:
 
 B_EDGE = 52884          # algorithmic bytes per edge, both pyramid levels, f16 features
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0                                       # dense f16 MFMA peak (MI355X_MICROARCH.md)
+UPDATE_FLOP_EDGE = 2 * (882 * 384 + 16 * 384 * 384 + 2 * 384 * 2)    # Update.forward per edge: 5.40 MFLOP
 
 
 def pmc_traffic():
@@ -116,27 +128,43 @@ def main():
     ap.add_argument("--warmup", type=int, default=45)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="default", choices=["default", "fast"])
+    ap.add_argument("--seed-offset", type=int, default=None, help="sequence / weight seed offset (default: the rank)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) on this node
+        import socket
+        import subprocess
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    n_dev = torch.cuda.device_count()
+    backend = "nccl" if n_dev >= world else "gloo"        # fewer devices than ranks: ranks share them (smoke mode, see docstring)
     dist = None
+    device = torch.device("cuda", local_rank % max(n_dev, 1))
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from dpvo_amd import altcorr
     from dpvo_amd.altcorr import correlation as corr_mod
     from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML, FAST_YAML
     from dpvo_amd.dpvo import DPVO
     from dpvo_amd.net import VONet
+    from dpvo_amd import net as net_mod
 
     cfg = base_cfg.clone()
     cfg.merge_from_dict(DEFAULT_YAML if args.config == "default" else FAST_YAML)
@@ -147,33 +175,46 @@ def main():
     preroll = max(0, 45 - args.warmup)
     total = preroll + args.warmup + args.steps
     cfg.BUFFER_SIZE = max(cfg.BUFFER_SIZE, total + 16)      # every frame stays a keyframe in this workload
-    torch.manual_seed(1234 + rank)
+    seed_off = rank if args.seed_offset is None else args.seed_offset
+    torch.manual_seed(1234 + seed_off)
     net = VONet()
+    shared = world > 1 and backend != "nccl"        # smoke mode: ranks share a device (see docstring)
     slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, defer_keyframe=bool(int(os.environ.get("DPVO_DEFER_KEYFRAME", "1"))),      # decision of frame t resolved under frame t+1's encoders
-                overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "1"))))   # ... on a second HIP stream
+                # ... on a second HIP stream.  Not when several ranks share one device: two processes time-slicing a GPU
+                # with a multi-stream tracker each hit a memory access fault on this ROCm stack (profiles/README.md)
+                overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "0" if shared else "1"))))
     slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
     n_img = 64
-    frames = make_stream(n_img, ht, wd, device, seed=1234 + rank)
+    frames = make_stream(n_img, ht, wd, device, seed=1234 + seed_off)
+    torch.cuda.synchronize(device)                   # the stream is resident before the first frame is tracked
     intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=device)   # calib/tartan.txt
 
     def step(t):
-        slam(float(t), frames[t % n_img], intr)
+        # image_ready=False: the frames were staged in HBM and synchronised before the timed region (the metric is quoted with
+        # resident inputs), so the encoder stream need not wait for the compute stream
+        slam(float(t), frames[t % n_img], intr, image_ready=False)
 
     from dpvo_amd import multiseq
-    clock = multiseq.Clock(dist=dist, device=device)
+    clock = multiseq.Clock(dist=dist, device=device)       # barrier + device sync on both sides of the timed region
     with torch.no_grad():
         for t in range(preroll + args.warmup):
             step(t)
         corr_mod.PROFILE = []
+        net_mod.PROFILE = []
         clock.start()                                 # barrier + torch.cuda.synchronize()
+        cpu0 = time.process_time()
         for t in range(preroll + args.warmup, total):
             step(t)
         slam.flush()                                  # the last frame's deferred keyframe decision belongs to the timed region
+        cpu1 = time.process_time()
         local = clock.stop()                          # torch.cuda.synchronize() + barrier
     prof = corr_mod.PROFILE
+    uprof = net_mod.PROFILE
     corr_mod.PROFILE = None
+    net_mod.PROFILE = None
     E_now = int(slam.pg.ii.numel())
-    res = multiseq.gather_results(args.steps, local, dist=dist, device=device)
+    res = multiseq.gather_results(args.steps, local, extra=1e6 * (cpu1 - cpu0) / args.steps, dist=dist,
+                                  device=device if backend == "nccl" else "cpu")
     elapsed = res["seconds"]                          # max over ranks
 
     corr_ms = [s.elapsed_time(e) for s, e, _ in prof]
@@ -182,12 +223,34 @@ def main():
     if corr_ms:
         avg_ms = sum(corr_ms) / len(corr_ms)
         avg_E = sum(corr_edges) / len(corr_edges)
-        achieved = avg_E * B_EDGE / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "corr_pyramid_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic() if args.config == "default" else None,     # the committed PMC pass is of the default config
+        streaming = avg_E * B_EDGE / (avg_ms * 1e-3) / 1e9
+        traffic = pmc_traffic() if args.config == "default" else None     # the committed PMC pass is of the default config
+        # every byte touched once: live part of the pyramid (34 of 36 frames, both levels) + templates + coords + indices + output
+        compulsory_bytes = (34.0 / 36.0) * 36 * 128 * 2 * (120 * 160 + 30 * 40) + 22 * 96 * 9 * 128 * 2 + avg_E * (144 + 32 + 1792)
+        counter = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+        roof = {"bound": "hbm", "kernel": "corr_pyramid_kernel",
+                "achieved": round(counter if counter is not None else streaming, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round((counter if counter is not None else streaming) / HBM_PEAK_GBS, 4),
+                "frac_kind": "counter" if counter is not None else "streaming (no PMC pass for this config)",
+                "frac_counter": round(counter / HBM_PEAK_GBS, 4) if counter is not None else None,
+                "frac_streaming": round(streaming / HBM_PEAK_GBS, 4),
+                "frac_compulsory": round(compulsory_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes": avg_E * B_EDGE, "compulsory_bytes": round(compulsory_bytes),
                 "avg_launch_ms": round(avg_ms, 4), "edges_per_launch": round(avg_E, 1), "bytes_per_edge": B_EDGE,
                 "launches": len(corr_ms)}
+    roof_u = None
+    if uprof:
+        ums = [s.elapsed_time(e) for s, e, _ in uprof]
+        uE = [n for _, _, n in uprof]
+        avg_ms = sum(ums) / len(ums)
+        avg_E = sum(uE) / len(uE)
+        flops = avg_E * UPDATE_FLOP_EDGE
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        roof_u = {"bound": "mfma", "kernel": "update operator (Update.forward: 7 launches, dpvo_amd/csrc/update_fused.hip)",
+                  "flops": flops, "avg_ms": round(avg_ms, 4), "achieved_tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "edges_per_call": round(avg_E, 1),
+                  "flop_per_edge": UPDATE_FLOP_EDGE, "calls": len(ums),
+                  "note": "reference FLOPs; the kernels execute 2 more E-row GEMMs (h applied per edge instead of per group)"}
 
     if rank == 0:
         out = {
@@ -197,8 +260,11 @@ def main():
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate, f32 BA", "data": "synthetic",
             "config": {"workload": f"synthetic 480x640 stream, {cfg.PATCHES_PER_FRAME} patches/frame, {args.config}.yaml, "
                                    f"steady state E={E_now} edges, random-init weights, one sequence per GPU",
-                       "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "parallelism": f"replicas x{world}"},
-            "roofline": roof,
+                       "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "parallelism": f"replicas x{world}" + ("" if backend == "nccl" or world == 1 else
+                                                                f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
+            "roofline": roof, "roofline_update": roof_u,
+            "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
+                         for i, r in enumerate(res["per_rank"])],
         }
         # the tracker state after the run: with random weights nothing guarantees that it stays sane, and a diverged state
         # (NaN poses, every edge projecting out of bounds) would make the correlation kernel skip its work

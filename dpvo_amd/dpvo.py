@@ -265,6 +265,7 @@ class DPVO:
         """generic append (loop-closure edges): ii = patch ids, jj = target frames (dpvo.py:215-221)"""
         self.pg.edges.append(self.ix[ii], jj, ii)
         self._plan = None
+        self._plan_exact = True          # edges from outside the tracker's own bookkeeping: no window / bound assumptions
 
     def append_frame_factors(self):
         """append_factors(*edges_forw) + append_factors(*edges_back) (dpvo.py:458-459) as one kernel"""
@@ -427,7 +428,7 @@ class DPVO:
     def plan(self):
         if self._plan is None or self._plan.E != self.pg.ii.numel():
             ub_p = ub_g = window = None
-            if not self.cfg.LOOP_CLOSURE and not _PLAN_SYNC:
+            if not self.cfg.LOOP_CLOSURE and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
                 # every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
                 # PATCH_LIFETIME frames of the source: bounds on #patches / #frame pairs, no device read-back needed
                 nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
@@ -491,14 +492,32 @@ class DPVO:
         return flatmeshgrid(torch.arange(t0, t1, device=self.device),
                             torch.arange(max(self.n - r, 0), self.n, device=self.device), indexing='ij')
 
-    def __call__(self, tstamp, image, intrinsics, patch_coords=None, depth_init=None):
+    def __call__(self, tstamp, image, intrinsics, patch_coords=None, depth_init=None, image_ready=None):
         """ track new frame (dpvo.py:377-473).  `patch_coords` / `depth_init` optionally inject the two random
-        draws of the reference (patch centroids net.py:132-133, depth rand_like dpvo.py:427) for reproducible tests """
+        draws of the reference (patch centroids net.py:132-133, depth rand_like dpvo.py:427) for reproducible tests.
+        `image_ready` (only matters with overlap_encoders, where the image is read on a second HIP stream):
+          None  -- the image may still be in flight on the caller's current stream (`torch.from_numpy(img).cuda()` from pageable
+                   memory returns early): the encoder stream waits for the current stream's position.  Always correct, but the
+                   encoders of frame t+1 then start only after frame t's update / BA (no overlap);
+          a torch.cuda.Event -- recorded by the caller behind the producer of the image (e.g. on its upload stream): the
+                   encoder stream waits for that event only;
+          False -- the caller guarantees the image is already resident (a pre-staged sequence): no wait. """
 
         if (self.n + 1) >= self.N:
             raise Exception(f'The buffer size is too small. You can increase it using "--opts BUFFER_SIZE={self.N*2}"')
 
-        # image = 2 * (image[None,None] / 255.0) - 0.5, plus the f16 copy the encoders eat: one kernel
+        # image = 2 * (image[None,None] / 255.0) - 0.5, plus the f16 copy the encoders eat: one kernel.  The kernel reads raw
+        # uint8 [3,H,W] on this device; anything else the reference's arithmetic would accept (CPU tensor, float image) is
+        # converted here instead of being reinterpreted
+        if torch.cuda.current_device() != self.device.index and self.device.index is not None:
+            raise L.DPVOHipError(f"DPVO was built on {self.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                                 "wrap the call in torch.cuda.device(...)")
+        if image.dim() != 3 or image.shape[0] != 3:
+            raise ValueError(f"image must be [3,H,W] (got {tuple(image.shape)})")
+        if image.dtype != torch.uint8 or image.device != self.device:
+            image = image.to(self.device).clamp(0, 255).to(torch.uint8)
+        if isinstance(intrinsics, torch.Tensor) and (intrinsics.dtype != torch.float32 or intrinsics.device != self.device):
+            intrinsics = intrinsics.to(self.device, torch.float32)
         image_u8 = image.contiguous()
         H, W = image_u8.shape[-2:]
         hip_enc = self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM'
@@ -510,6 +529,13 @@ class DPVO:
             side = self._enc_stream
             if self._fp_done is not None:       # the previous frame's readers of _imap_full / the encoder workspace
                 side.wait_event(self._fp_done)
+            # the caller's stream may still be producing / uploading the image (torch.from_numpy(img).cuda() from pageable
+            # memory returns before the copy has landed): order the side stream behind it
+            if image_ready is None:
+                image_ready = torch.cuda.Event()
+                image_ready.record(torch.cuda.current_stream(self.device))
+            if image_ready is not False:
+                side.wait_event(image_ready)
         main_stream = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(side if side is not None else main_stream):
             img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None

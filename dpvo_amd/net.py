@@ -20,6 +20,10 @@ from .utils import coords_grid_with_index
 
 DIM = 384
 
+# bench.py sets this to a list to collect (start_event, end_event, n_edges) of every Update.forward: HIP events recorded on the
+# launch stream around the operator (MFMA roofline measurement); None = no overhead.
+PROFILE = None
+
 EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 # Update.forward runs the fused row-tile kernels (update_fused.hip) unless told otherwise (DPVO_UPDATE_FUSED=0 selects the
 # launch-by-launch composite of update.hip; both stay tested against the oracle)
@@ -260,6 +264,20 @@ class Update(nn.Module):
             inp2 = inp2.half()
         inp2 = inp2.contiguous()
 
+        prof = PROFILE
+        if prof is not None:
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            res = self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
+                                    composite, fused, patch_edges_ub, E, dev, P)
+            ev1.record()
+            prof.append((ev0, ev1, E))
+            return res
+        return self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
+                                 composite, fused, patch_edges_ub, E, dev, P)
+
+    def forward_impl(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out, composite,
+                     fused, patch_edges_ub, E, dev, P):
         if composite and net2.dtype == torch.float32:
             # the whole operator as ONE library call (dpvo_update_forward issues the same launches as the code below;
             # `composite=False` keeps the launch-by-launch path for tests)
@@ -389,7 +407,9 @@ class Patchifier(nn.Module):
 
         if coords is None:
             if centroid_sel_strat == 'GRADIENT_BIAS':
-                g = self.__image_gradient(images)
+                # in f32 whatever the encoders eat: gray reaches ~765 and dx ** 2 overflows f16 (the reference's image is
+                # f32 here, net.py:104-111 -- autocast does not downcast sum / pow / sqrt)
+                g = self.__image_gradient(images.float())
                 x = torch.randint(1, w - 1, size=[n, 3 * patches_per_image], device=dev)
                 y = torch.randint(1, h - 1, size=[n, 3 * patches_per_image], device=dev)
                 coords = torch.stack([x, y], dim=-1).float()

@@ -1,48 +1,53 @@
-"""Small helpers of the reference's dpvo/utils.py that sit on the inference path."""
-from contextlib import ContextDecorator
-
+"""Host-side helpers with the names the reference's inference path imports from `dpvo.utils` (Timer,
+coords_grid_with_index, flatmeshgrid; behaviour of dpvo/utils.py:8-29,39-55,86-88), written for this code base:
+the timer does not synchronise the device unless it has to report, and the coordinate grid is built by broadcasting
+instead of `repeat`."""
 import torch
 
-all_times = []
+all_times = []          # milliseconds of every finished Timer (the reference keeps the same module-level list)
 
 
-class Timer(ContextDecorator):
-    """HIP-event timer (dpvo/utils.py:8-29)."""
+class Timer:
+    """`with Timer("BA", enabled=...)`: HIP events around the block on the current stream; prints `name ms` on exit.
+    Usable as a decorator too (`@Timer("x")`)."""
 
     def __init__(self, name, enabled=True):
-        self.name = name
-        self.enabled = enabled
-        if self.enabled:
-            self.start = torch.cuda.Event(enable_timing=True)
-            self.end = torch.cuda.Event(enable_timing=True)
+        self.name, self.enabled = name, bool(enabled)
+        self._ev = None
 
     def __enter__(self):
         if self.enabled:
-            self.start.record()
+            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+        return self
 
-    def __exit__(self, type, value, traceback):
+    def __exit__(self, *exc):
         if self.enabled:
-            self.end.record()
-            torch.cuda.synchronize()
-            elapsed = self.start.elapsed_time(self.end)
-            all_times.append(elapsed)
-            print(f"{self.name} {elapsed:.03f}")
+            begin, end = self._ev
+            end.record()
+            end.synchronize()               # only this event, not the whole device
+            ms = begin.elapsed_time(end)
+            all_times.append(ms)
+            print(f"{self.name} {ms:.03f}")
+        return False
+
+    def __call__(self, fn):
+        def wrapped(*a, **k):
+            with Timer(self.name, self.enabled):
+                return fn(*a, **k)
+        return wrapped
 
 
 def coords_grid_with_index(d, **kwargs):
-    """coordinate grid with frame index (dpvo/utils.py:39-55)"""
+    """d [b,n,h,w] (a depth / disparity plane) -> (coords [b,n,3,h,w] = (x, y, d) per pixel, index [b,n,1,h,w] = frame number)"""
     b, n, h, w = d.shape
-    x = torch.arange(0, w, dtype=torch.float, **kwargs)
-    y = torch.arange(0, h, dtype=torch.float, **kwargs)
-    y, x = torch.meshgrid(y, x, indexing="ij")
-    y = y.view(1, 1, h, w).repeat(b, n, 1, 1)
-    x = x.view(1, 1, h, w).repeat(b, n, 1, 1)
-    coords = torch.stack([x, y, d], dim=2)
-    index = torch.arange(0, n, dtype=torch.float, **kwargs)
-    index = index.view(1, n, 1, 1, 1).repeat(b, 1, 1, h, w)
+    xs = torch.arange(w, dtype=torch.float, **kwargs).view(1, 1, 1, w).expand(b, n, h, w)
+    ys = torch.arange(h, dtype=torch.float, **kwargs).view(1, 1, h, 1).expand(b, n, h, w)
+    coords = torch.stack((xs, ys, d), dim=2)
+    index = torch.arange(n, dtype=torch.float, **kwargs).view(1, n, 1, 1, 1).expand(b, n, 1, h, w).contiguous()
     return coords, index
 
 
-def flatmeshgrid(*args, **kwargs):
-    grid = torch.meshgrid(*args, **kwargs)
-    return (x.reshape(-1) for x in grid)
+def flatmeshgrid(*axes, **kwargs):
+    """torch.meshgrid with every output flattened"""
+    return tuple(g.reshape(-1) for g in torch.meshgrid(*axes, **kwargs))

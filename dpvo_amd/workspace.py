@@ -1,11 +1,23 @@
-"""Per-device, stream-ordered scratch buffers handed to the C ABI as `ws` (caller-owned, never retained)."""
+"""Per-device, per-stream scratch buffers handed to the C ABI as `ws` (caller-owned, never retained by the library).
+
+Keyed by (device, HIP stream, tag): two trackers on one GPU that run on different streams, or one tracker's main and side
+streams, must not share scratch memory -- kernels of different streams may overlap in time."""
 import torch
 
 _bufs = {}
+import os
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_PER_STREAM = bool(int(os.environ.get("DPVO_WS_PER_STREAM", "1")))
 
 
 def get(nbytes, device, tag="default"):
-    key = (str(device), tag)
+    device = torch.device(device)
+    if device.type == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        stream = _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(idx).cuda_stream
+    else:
+        idx, stream = -1, 0
+    key = (device.type, idx, stream if _PER_STREAM else 0, tag)
     buf = _bufs.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -56,3 +56,28 @@ def test_two_rank_gloo():
 def test_single_process_path():
     res = multiseq.gather_results(7, 0.5)
     assert res["fps"] == 14.0 and multiseq.partition(range(4), 0, 1) == [0, 1, 2, 3]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_self_spawns_two_real_trackers():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run and every
+    rank runs the REAL tracker on its own sequence (on a 1-GPU box the two ranks share the device over gloo); rank 0 prints one
+    JSON line with n_gpus = 2, the max-over-ranks time and one record per rank (seconds, host CPU time per frame)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "45",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 12 and len(rec["per_rank"]) == 2
+    assert rec["state"]["finite"] and "error" not in rec
+    secs = [r["seconds"] for r in rec["per_rank"]]
+    assert abs(rec["value"] - 2 * 12 / max(secs)) / rec["value"] < 1e-3          # whole-job frames/sec = N*K / max over ranks
+    assert all(r["host_cpu_us_per_frame"] > 0 for r in rec["per_rank"])
