@@ -158,11 +158,33 @@ def corr_forward(fmap1, fmap2, coords, us, vs, radius, dtype=np.float64):
     return out.transpose(0, 2, 1, 3, 4)
 
 
-def corr_pyramid(gmap, pyramid, coords, ii1, jj1, radius=3, levels=(1, 4), dtype=np.float64):
-    """DPVO.corr (dpvo.py:200-207): two levels stacked on the last axis and flattened -> [E, 2*49*P*P]."""
+def corr_forward_h16(fmap1, fmap2, coords, us, vs, radius):
+    """cuda_corr.forward on HALF features in the reference's own arithmetic (every product, partial sum and blend step
+    rounded to f16: correlation_kernel.cu:121-131,221-230).  Inputs are rounded to f16 first; returns float32 values that
+    are f16-representable, reference layout [E, D-1 (x), D-1 (y), P, P]."""
+    f1 = _c(np.asarray(fmap1, np.float16), np.float32); f2 = _c(np.asarray(fmap2, np.float16), np.float32)
+    co = _c(coords, np.float32)
+    us, vs = _i64(us), _i64(vs)
+    E = us.size
+    C, P = f1.shape[1], f1.shape[2]
+    H2, W2 = f2.shape[2], f2.shape[3]
+    D = 2 * radius + 2
+    out = np.empty((E, D - 1, D - 1, P, P), np.float32)
+    lib().orc_corr_forward_h16(_p(f1), _p(f2), _p(co), _p(us), _p(vs), ctypes.c_int64(E), ctypes.c_int(C), ctypes.c_int(P),
+                               ctypes.c_int(H2), ctypes.c_int(W2), ctypes.c_int(radius), _p(out))
+    return out.transpose(0, 2, 1, 3, 4)
+
+
+def corr_pyramid(gmap, pyramid, coords, ii1, jj1, radius=3, levels=(1, 4), dtype=np.float64, emulate_f16=False):
+    """DPVO.corr (dpvo.py:200-207): two levels stacked on the last axis and flattened -> [E, 2*49*P*P].
+    emulate_f16: the reference's half arithmetic (corr_forward_h16); the level-1 coordinates are coords / 4 in f32 as at
+    dpvo.py:206."""
     outs = []
     for f2, lvl in zip(pyramid, levels):
-        outs.append(corr_forward(gmap, f2, np.asarray(coords, dtype) / lvl, ii1, jj1, radius, dtype))
+        if emulate_f16:
+            outs.append(corr_forward_h16(gmap, f2, np.asarray(coords, np.float32) / np.float32(lvl), ii1, jj1, radius))
+        else:
+            outs.append(corr_forward(gmap, f2, np.asarray(coords, dtype) / lvl, ii1, jj1, radius, dtype))
     return np.stack(outs, -1).reshape(len(ii1), -1)
 
 

@@ -55,6 +55,93 @@
 #undef FABS
 #undef FLOOR
 
+
+/* ---------------------------------------------------------------------------------------------
+ * altcorr in the REFERENCE'S OWN ARITHMETIC for half features (scalar_t = c10::Half):
+ *   corr_forward_kernel (correlation_kernel.cu:121-131): `scalar_t s = 0; ... s += f1[j] * f2[j];` over the channels in
+ *   order -- c10::Half operators compute in float and round the result to half (c10/util/Half-inl.h), so every product
+ *   and every partial sum is rounded to f16;
+ *   the ATen blend (:221-230): dx, dy = (x - floor(x)).to(half); every elementwise op on half tensors computes in float
+ *   and rounds its result to half: (1 - dx), (1 - dx) * (1 - dy), (.) * corr, out += (.), left to right.
+ * Inputs: features as float arrays holding f16-representable values; coords float.  Output float (f16-representable),
+ * layout of orc_corr_forward (before the final permute).  This is the "fp16-rounding emulation" of SURVEY.md 8c: what the
+ * reference CUDA kernels return bit for bit, up to double rounding in the float -> half conversions (the float result of a
+ * two-half sum can itself be inexact when the exponents differ by more than 13: a tie can then round the other way).
+ * ------------------------------------------------------------------------------------------- */
+static inline float orc_h16(float f) {
+  /* round to nearest even to IEEE binary16, return the value as float (overflow -> inf, subnormals handled) */
+  union { float f; uint32_t u; } v; v.f = f;
+  const uint32_t sign = v.u & 0x80000000u;
+  uint32_t a = v.u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return f;                              /* inf / nan */
+  if (a >= 0x477ff000u) {                                      /* >= 65520: rounds to inf */
+    v.u = sign | 0x7f800000u; return v.f;
+  }
+  if (a < 0x38800000u) {                                       /* < 2^-14: half subnormal, quantum 2^-24 */
+    v.u = a;
+    float q = v.f * 16777216.0f;                               /* exact scaling by 2^24 */
+    q = nearbyintf(q);                                         /* RNE in the default rounding mode */
+    q *= 5.9604644775390625e-8f;                               /* 2^-24 */
+    v.f = q; v.u |= sign; return v.f;
+  }
+  /* normal: keep 10 mantissa bits, RNE on the 13 dropped bits */
+  const uint32_t lsb = (a >> 13) & 1u;
+  a += 0x0fffu + lsb;
+  a &= ~0x1fffu;
+  v.u = sign | a; return v.f;
+}
+
+/* the rounding itself, exported so that tests can pin it against numpy's float16 conversion */
+void orc_round_h16(const float* x, int64_t n, float* y) { for (int64_t i = 0; i < n; i++) y[i] = orc_h16(x[i]); }
+
+void orc_corr_forward_h16(const float* fmap1, const float* fmap2, const float* coords, const int64_t* us,
+                          const int64_t* vs, int64_t E, int C, int P, int H2, int W2, int radius, float* out) {
+  const int D = 2 * radius + 2;
+#pragma omp parallel for schedule(static)
+  for (int64_t m = 0; m < E; m++) {
+    float* raw = (float*)malloc(sizeof(float) * (size_t)D * D * P * P);
+    const float* f1 = fmap1 + (int64_t)us[m] * C * P * P;
+    const float* f2 = fmap2 + (int64_t)vs[m] * C * H2 * W2;
+    for (int i0 = 0; i0 < P; i0++)
+      for (int j0 = 0; j0 < P; j0++) {
+        float x = coords[((m * 2 + 0) * P + i0) * P + j0];
+        float y = coords[((m * 2 + 1) * P + i0) * P + j0];
+        float fx = floorf(x), fy = floorf(y);
+        for (int a = 0; a < D; a++)
+          for (int b = 0; b < D; b++) {
+            float s = 0;
+            if (fx == fx && fy == fy && fabsf(fx) < 1e9f && fabsf(fy) < 1e9f) {
+              long i1 = (long)fy + (a - radius);
+              long j1 = (long)fx + (b - radius);
+              if (i1 >= 0 && i1 < H2 && j1 >= 0 && j1 < W2)
+                for (int c = 0; c < C; c++) {
+                  const float pr = orc_h16(f1[(c * P + i0) * P + j0] * f2[((int64_t)c * H2 + i1) * W2 + j1]);
+                  s = orc_h16(s + pr);
+                }
+            }
+            raw[((a * D + b) * P + i0) * P + j0] = s;
+          }
+      }
+    for (int a = 0; a < D - 1; a++)
+      for (int b = 0; b < D - 1; b++)
+        for (int i0 = 0; i0 < P; i0++)
+          for (int j0 = 0; j0 < P; j0++) {
+            float x = coords[((m * 2 + 0) * P + i0) * P + j0];
+            float y = coords[((m * 2 + 1) * P + i0) * P + j0];
+            const float dx = orc_h16(x - floorf(x)), dy = orc_h16(y - floorf(y));
+            const float mx = orc_h16(1.0f - dx), my = orc_h16(1.0f - dy);
+#define RAW(aa, bb) raw[(((aa) * D + (bb)) * P + i0) * P + j0]
+            float o = orc_h16(orc_h16(mx * my) * RAW(a, b));
+            o = orc_h16(o + orc_h16(orc_h16(dx * my) * RAW(a, b + 1)));
+            o = orc_h16(o + orc_h16(orc_h16(mx * dy) * RAW(a + 1, b)));
+            o = orc_h16(o + orc_h16(orc_h16(dx * dy) * RAW(a + 1, b + 1)));
+#undef RAW
+            out[(((m * (D - 1) + a) * (D - 1) + b) * P + i0) * P + j0] = o;
+          }
+    free(raw);
+  }
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Integer bookkeeping (bit-exact contract).
  * ------------------------------------------------------------------------------------------- */

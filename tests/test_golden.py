@@ -137,3 +137,54 @@ def test_hip_against_golden(dev):
     H.assert_close(out[0].cpu().numpy(), d2["net_out"], 3e-2, 2e-2, "update net vs reference golden")
     H.assert_close(dl[0].cpu().numpy(), d2["delta"], 2e-2, 2e-2, "update delta vs reference golden")
     H.assert_close(w[0].cpu().numpy(), d2["weight"], 1e-2, 1e-2, "update weight vs reference golden")
+
+
+def _graph_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph.npz"))
+
+
+def test_graph_oracle_matches_reference_dpvo_bookkeeping():
+    """oracle/graph_ref.py (the integer restatement the GPU tracker is compared with bit for bit) against the state the
+    REFERENCE'S OWN DPVO class produced (tests/golden/make_golden_graph.py: dpvo/dpvo.py:215-238,266-310,362-375,377-473 run on
+    the CPU with the float pipeline replaced by the same scripted decisions): n, m, counter, the active and inactive edge lists
+    and the timestamps after every one of the 46 frames, and the removed-frame links."""
+    from oracle.graph_ref import GraphRef
+    g = _graph_golden()
+    M = int(g["dpvo_M"])
+    ref = GraphRef(M=M, PATCH_LIFETIME=13, REMOVAL_WINDOW=22, BUFFER_SIZE=256)
+    o = {k: 0 for k in ("E", "E_inac", "t")}
+    for t, (accept, drop) in enumerate(g["dpvo_decisions"]):
+        ref.frame(bool(accept), bool(drop))
+        E, Ei, n = int(g["dpvo_E"][t]), int(g["dpvo_E_inac"][t]), int(g["dpvo_n"][t])
+        assert (ref.n, ref.m, ref.counter) == (n, int(g["dpvo_m"][t]), int(g["dpvo_counter"][t])), t
+        for k in ("ii", "jj", "kk"):
+            assert np.array_equal(getattr(ref, k), g["dpvo_" + k][o["E"]:o["E"] + E]), (t, k)
+            assert np.array_equal(getattr(ref, k + "_inac"), g["dpvo_" + k + "_inac"][o["E_inac"]:o["E_inac"] + Ei]), (t, k)
+        assert np.array_equal(ref.tstamps_[:n], g["dpvo_tstamps"][o["t"]:o["t"] + n]), t
+        o["E"] += E; o["E_inac"] += Ei; o["t"] += n
+    assert sorted(ref.delta.keys()) == g["dpvo_delta_keys"].tolist()
+    assert [ref.delta[k] for k in sorted(ref.delta.keys())] == g["dpvo_delta_t0"].tolist()
+
+
+def _encoder_golden():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder.npz"))
+    sd = {"fnet": {}, "inet": {}}
+    for k in g.files:
+        if k.startswith(("fnet.", "inet.")):
+            sd[k[:4]][k[5:]] = torch.from_numpy(g[k].astype(np.float32))
+    return g, sd
+
+
+def test_extractor_module_is_the_reference_architecture():
+    """dpvo_amd.extractor.BasicEncoder4 loads the state dicts of the REFERENCE'S BasicEncoder4 (extractor.py:200-264; golden made by
+    tests/golden/make_golden_encoder.py from the imported reference file) strictly -- same keys, same shapes -- and reproduces the
+    reference's outputs in f32 on the CPU: the module the HIP encoders are tested against IS the reference architecture."""
+    from dpvo_amd.extractor import BasicEncoder4
+    g, sd = _encoder_golden()
+    img = torch.from_numpy(g["image"].astype(np.float32))
+    for name, dim, norm in (("fnet", 128, "instance"), ("inet", 384, "none")):
+        m = BasicEncoder4(output_dim=dim, norm_fn=norm).eval()
+        m.load_state_dict(sd[name], strict=True)
+        with torch.no_grad():
+            out = (m(img[None, None]) / 4.0)[0, 0].numpy()
+        H.assert_close(out, g["fmap" if name == "fnet" else "imap"], 2e-5, 2e-5, name)

@@ -118,8 +118,36 @@ def test_full_size_properties(oracle, dev):
     # (3) fully out-of-bounds edges give exact zeros
     oob = (coords[:, 0, 1, 1] > 5000)
     assert oob.sum() > 100 and (out[oob.to(dev)] == 0).all()
-    # (4) oracle on a seeded sample of 128 edges
-    idx = torch.randperm(E, generator=torch.Generator().manual_seed(0))[:128]
-    ref = oracle.corr_pyramid(gmap.float().numpy(), [f0.float().numpy(), f1.float().numpy()], coords[idx].numpy(),
-                              us[idx].numpy(), vs[idx].numpy())
-    H.assert_close(out[idx.to(dev)].float().cpu().numpy(), ref, 2e-3, 2e-3, "full-size sample")
+    # (4) the oracle on EVERY edge (f32 restatement, OpenMP over edges: a few seconds)
+    ref = oracle.corr_pyramid(gmap.float().numpy(), [f0.float().numpy(), f1.float().numpy()], coords.numpy(), us.numpy(),
+                              vs.numpy(), dtype=np.float32)
+    H.assert_close(out.float().cpu().numpy(), ref, 2e-3, 2e-3, "full size, all 45 312 edges")
+
+
+def test_distance_to_the_reference_arithmetic(oracle, dev):
+    """north_star asks for a tolerance against the reference CUDA kernels, which accumulate and blend in f16
+    (correlation_kernel.cu:121-131,223-230); the HIP kernel accumulates in f32 and rounds once.  With the oracle's emulation of
+    the reference's arithmetic (oracle.corr_forward_h16, rounding pinned against numpy in tests/test_oracle.py) the three
+    distances are measured on 4 096 edges of the full-size workload and bounded:
+        |HIP - exact|           <= 1.5e-3   (one f16 rounding of an |x| <= ~3 value)
+        |reference-emulated - exact| <= 2.5e-2   (128 f16-rounded partial sums + 7 rounded blend steps)
+        |HIP - reference-emulated|   <= 2.5e-2   = the stated tolerance of this kernel against the reference's output."""
+    from dpvo_amd import synthetic as S
+    ii, jj, kk = S.replay_graph(40)
+    E = ii.numel()
+    gmap, f0, f1, _ = S.make_features()
+    coords = S.make_coords(E)
+    us = (kk % 3456); vs = (jj % 36)
+    idx = torch.randperm(E, generator=torch.Generator().manual_seed(1))[:4096]
+    g, a, b = H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev)
+    out = altcorr.corr_pyramid(g, a, b, coords[idx].to(dev), us[idx].to(dev), vs[idx].to(dev)).float().cpu().numpy()
+    args = (gmap.float().numpy(), [f0.float().numpy(), f1.float().numpy()], coords[idx].numpy(), us[idx].numpy(), vs[idx].numpy())
+    exact = oracle.corr_pyramid(*args, dtype=np.float64)
+    emu = oracle.corr_pyramid(*args, emulate_f16=True)
+    fin = np.isfinite(emu) & np.isfinite(exact)
+    d_he = np.abs(out - exact)[fin]; d_re = np.abs(emu - exact)[fin]; d_hr = np.abs(out - emu)[fin]
+    print("corr: |HIP-exact| max %.2e rms %.2e; |ref_f16-exact| max %.2e rms %.2e; |HIP-ref_f16| max %.2e rms %.2e; |corr| rms %.2f"
+          % (d_he.max(), np.sqrt((d_he ** 2).mean()), d_re.max(), np.sqrt((d_re ** 2).mean()), d_hr.max(),
+             np.sqrt((d_hr ** 2).mean()), np.sqrt((exact[fin] ** 2).mean())))
+    assert d_he.max() <= 1.5e-3 and d_re.max() <= 2.5e-2 and d_hr.max() <= 2.5e-2
+    assert np.sqrt((d_he ** 2).mean()) * 5 < np.sqrt((d_re ** 2).mean())      # the HIP kernel is the more accurate of the two

@@ -135,3 +135,84 @@ def test_loop_closure_global_ba_path(dev):
     assert (slam.pg.patches_[:n, :, 2] > 0).all()
     poses, tstamps = slam.terminate()
     assert poses.shape == (75, 7) and np.isfinite(poses).all()
+
+
+def _graph_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph.npz"))
+
+
+def test_bookkeeping_matches_the_reference_dpvo_class(dev):
+    """The tracker's integer state against the state the REFERENCE'S OWN DPVO class went through (tests/golden/graph.npz, made by
+    tests/golden/make_golden_graph.py from the imported dpvo/dpvo.py with the float pipeline replaced by the same scripted
+    decisions): frame / patch counters, active and inactive edge lists, timestamps after every frame, removed-frame links."""
+    from oracle.graph_ref import GraphRef  # noqa: F401
+    g = _graph_golden()
+    decisions = [(bool(a), bool(d)) for a, d in g["dpvo_decisions"]]
+    M = int(g["dpvo_M"])
+    cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
+    cfg.PATCHES_PER_FRAME = M
+    cfg.BUFFER_SIZE = 256
+    torch.manual_seed(0)
+    ht, wd = 96, 128
+    slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev)
+    gen = torch.Generator().manual_seed(0)
+    intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
+    state = {}
+    slam.motion_probe = lambda: 1e9 if state["accept"] else 0.0
+    orig = pops.motionmag_pair
+    thresh = cfg.KEYFRAME_THRESH
+
+    def fake(*a, defer=False, host_buf=None, **k):
+        res = (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
+        return (lambda: res) if defer else res
+    pops.motionmag_pair = fake
+    o = {"E": 0, "Ei": 0, "t": 0}
+    try:
+        for t, (accept, drop) in enumerate(decisions):
+            state["accept"], state["drop"] = accept, drop
+            img = torch.randint(0, 255, (3, ht, wd), generator=gen, dtype=torch.uint8).to(dev)
+            slam(float(t), img, intr)
+            slam.flush()
+            E, Ei, n = int(g["dpvo_E"][t]), int(g["dpvo_E_inac"][t]), int(g["dpvo_n"][t])
+            assert (slam.n, slam.m, slam.counter) == (n, int(g["dpvo_m"][t]), int(g["dpvo_counter"][t])), t
+            for k in ("ii", "jj", "kk"):
+                assert np.array_equal(getattr(slam.pg, k).cpu().numpy(), g["dpvo_" + k][o["E"]:o["E"] + E]), (t, k)
+                assert np.array_equal(getattr(slam.pg, k + "_inac").cpu().numpy(),
+                                      g["dpvo_" + k + "_inac"][o["Ei"]:o["Ei"] + Ei]), (t, k)
+            assert np.array_equal(slam.pg.tstamps_[:n], g["dpvo_tstamps"][o["t"]:o["t"] + n]), t
+            o["E"] += E; o["Ei"] += Ei; o["t"] += n
+    finally:
+        pops.motionmag_pair = orig
+    assert sorted(int(k) for k in slam.pg.delta.keys()) == g["dpvo_delta_keys"].tolist()
+    assert [int(slam.pg.delta[k][0]) for k in sorted(slam.pg.delta.keys())] == g["dpvo_delta_t0"].tolist()
+
+
+def test_patchgraph_edges_loop_and_normalize_match_the_reference(dev):
+    """PatchGraph.edges_loop (patchgraph.py:56-82: candidate generation, flow test, the reference's reduce_edges) and .normalize
+    (:84-95) on the synthetic loop-closure state of tests/golden/make_golden_graph.py: the loop edges must be the reference's
+    bit for bit, the rescaled poses / depths / points agree to f32 rounding (the reference side ran in f32 on f64 lietorch stubs)."""
+    from types import SimpleNamespace
+    from dpvo_amd.patchgraph import PatchGraph
+    from dpvo_amd.lietorch import SE3
+    g = _graph_golden()
+    M, n = int(g["pg_M"]), int(g["pg_n"])
+    cfg = SimpleNamespace(PATCHES_PER_FRAME=M, BUFFER_SIZE=64, LOOP_CLOSURE=True, REMOVAL_WINDOW=22, GLOBAL_OPT_FREQ=15,
+                          KEYFRAME_INDEX=4, MAX_EDGE_AGE=1000, BACKEND_THRESH=64.0)
+    pg = PatchGraph(cfg, 3, 384, 1000, device=dev, dtype=torch.float)
+    pg.n, pg.m = n, n * M
+    pg.poses_[:n] = torch.from_numpy(g["pg_poses"]).to(dev)
+    pg.patches_[:n] = torch.from_numpy(g["pg_patches"]).to(dev).view(n, M, 3, 3, 3)
+    pg.intrinsics_[:n] = torch.from_numpy(g["pg_intr"]).to(dev)
+    for f in range(64):
+        pg.index_[f] = f
+    kk, jj = pg.edges_loop()
+    assert np.array_equal(kk.cpu().numpy(), g["pg_loop_kk"]) and np.array_equal(jj.cpu().numpy(), g["pg_loop_jj"])
+    assert g["pg_loop_kk"].size > 0
+    pg.delta[7] = (6, SE3(torch.tensor([[0.1, -0.2, 0.05, 0.0, 0.0, 0.0, 1.0]], device=dev)))
+    pg.normalize()
+    from tests import helpers as H
+    H.assert_close(pg.poses_[:n].cpu().numpy(), g["pg_norm_poses"], 2e-5, 2e-5, "normalize: poses")
+    H.assert_close(pg.patches_[:n].cpu().numpy(), g["pg_norm_patches"], 2e-5, 2e-5, "normalize: patches")
+    H.assert_close(pg.points_[:n * M].cpu().numpy(), g["pg_norm_points"], 2e-4, 2e-4, "normalize: points")
+    H.assert_close(pg.delta[7][1].data.cpu().numpy(), g["pg_norm_delta"], 2e-6, 2e-6, "normalize: delta")

@@ -241,3 +241,57 @@ def test_dpvo_ref_pipeline_runs_and_tracks_graph_ref():
     assert np.isfinite(ref.poses[:n]).all() and np.isfinite(ref.patches[:n]).all()
     assert np.abs(np.linalg.norm(ref.poses[:n, 3:], axis=-1) - 1).max() < 1e-4
     assert (ref.patches[:n, :, 2] > 0).all()
+
+
+def test_f16_rounding_and_reference_arithmetic_emulation(oracle):
+    """The oracle's emulation of the reference's half arithmetic (correlation_kernel.cu:121-131,221-230):
+    (1) its software float -> f16 rounding is numpy's (RNE, subnormals, overflow), on 2M values incl. exact ties;
+    (2) known answers: a one-channel dot product is h(f1 * f2); a constant window at fractional coordinates blends to
+        the constant up to the rounding of the four half weights; a sum that f16 cannot hold saturates like the kernel's;
+    (3) |emulated - exact| on random half features is bounded by the f16 accumulation error model
+        (128 products of O(1/16) magnitude, each partial sum rounded: a few 1e-3 absolute)."""
+    import ctypes
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(300000).astype(np.float32) * s for s in (1e-8, 1e-6, 1e-4, 1e-2, 1, 100, 3e4, 7e4)])
+    # exact ties between two neighbouring f16 values (normal and subnormal range)
+    h = rng.integers(0, 0x7bff, 200000).astype(np.uint16).view(np.float16).astype(np.float32)
+    hn = (h.astype(np.float16).view(np.uint16) + 1).view(np.float16).astype(np.float32)
+    x = np.concatenate([x, (h + hn) / 2, -(h + hn) / 2, np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e30, np.inf], np.float32)])
+    y = np.empty_like(x)
+    oracle.lib().orc_round_h16(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(x.size), y.ctypes.data_as(ctypes.c_void_p))
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+    # (2a) single channel, integer coords: corr = h(f1 * f2)
+    f1 = np.array([0.3337], np.float16).astype(np.float32).reshape(1, 1, 1, 1)
+    f2 = np.array([1.2344], np.float16).astype(np.float32).reshape(1, 1, 1, 1)
+    co = np.zeros((1, 2, 1, 1), np.float32)
+    out = oracle.corr_forward_h16(f1, f2, co, [0], [0], 0)
+    assert out.reshape(-1)[0] == np.float32(np.float16(f1.item() * f2.item()))
+    # (2b) constant feature map, fractional coords: every weight is rounded to half, so the blend of a constant c is
+    # c * (sum of rounded weights) up to four more roundings
+    C, H2, W2 = 8, 12, 12
+    f1 = np.full((1, C, 1, 1), 0.25, np.float32); f2 = np.full((1, C, H2, W2), 0.5, np.float32)
+    co = np.array([5.3, 6.7], np.float32).reshape(1, 2, 1, 1)
+    out = oracle.corr_forward_h16(f1, f2, co, [0], [0], 1)
+    assert np.allclose(out, C * 0.125, rtol=3e-3)
+    # (2c) saturation: 128 products of 2^10 overflow a half accumulator (max 65504) -> inf, and the blend then multiplies the
+    # zero weights of integer coordinates with it: 0 * inf = NaN, which is what the reference returns as well
+    f1 = np.full((1, 128, 1, 1), 32.0, np.float32); f2 = np.full((1, 128, 4, 4), 32.0, np.float32)
+    out = oracle.corr_forward_h16(f1, f2, np.full((1, 2, 1, 1), 1.0, np.float32), [0], [0], 0)
+    assert np.isnan(out).all()
+    out = oracle.corr_forward_h16(f1, f2, np.full((1, 2, 1, 1), 1.5, np.float32), [0], [0], 0)
+    assert np.isinf(out).all()
+    # (3) random features in the bench's distribution
+    g = rng.standard_normal((6, 128, 3, 3)).astype(np.float32) / 4
+    f = rng.standard_normal((2, 128, 24, 32)).astype(np.float32) / 4
+    E = 64
+    coords = (rng.uniform(4, 20, (E, 2, 1, 1)) + np.zeros((E, 2, 3, 3))).astype(np.float32)
+    us, vs = rng.integers(0, 6, E), rng.integers(0, 2, E)
+    gh, fh = g.astype(np.float16).astype(np.float32), f.astype(np.float16).astype(np.float32)
+    emu = oracle.corr_forward_h16(gh, fh, coords, us, vs, 3)
+    exact = oracle.corr_forward(gh, fh, coords, us, vs, 3)
+    err = np.abs(emu - exact)
+    print("f16-arithmetic emulation vs exact: max %.2e  rms %.2e  (|corr| rms %.2f)" % (err.max(), np.sqrt((err ** 2).mean()),
+                                                                                         np.sqrt((exact ** 2).mean())))
+    assert 1e-4 < err.max() < 2e-2
