@@ -8,7 +8,8 @@ package's modules under the reference's names, so those import lines resolve to 
 import importlib
 import sys
 
-_MODULES = ("dpvo", "net", "patchgraph", "config", "utils", "projective_ops", "altcorr", "fastba", "lietorch", "extractor")
+_MODULES = ("dpvo", "net", "patchgraph", "config", "utils", "projective_ops", "altcorr", "fastba", "lietorch", "extractor",
+            "stream", "plot_utils")
 
 
 def install(name="dpvo", force=False):

@@ -58,7 +58,8 @@ def umeyama(X, Y, with_scale=True):
     if np.linalg.det(U) * np.linalg.det(Vt) < 0:
         S[2, 2] = -1.0
     R = U @ S @ Vt
-    s = float((D * np.diag(S)).sum() / ((Xc ** 2).sum() / X.shape[0])) if with_scale else 1.0
+    var = (Xc ** 2).sum() / X.shape[0]
+    s = float((D * np.diag(S)).sum() / var) if (with_scale and var > 0) else 1.0      # (a trajectory that never moved: no scale)
     return s, R, my - s * R @ mx
 
 
