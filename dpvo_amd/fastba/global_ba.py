@@ -14,7 +14,23 @@ from .. import workspace
 from ..graph import GraphPlan
 
 
-def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, plan=None):
+_PROFILE = None          # tools/gba_bench.py sets this to a list: (phase name, start event, end event) per phase
+
+
+def _mark(name, ev):
+    if _PROFILE is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _PROFILE.append((name, ev, e))
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+    return ev
+
+
+def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, plan=None, f0=None,
+              n_frames=None):
+    """f0 / n_frames: first source frame that owns a patch with an edge and the number of frames up to the last one; the
+    tracker knows them from its own bookkeeping (no read-back); computed here (one host sync) when not given."""
     P = patches.shape[-1]
     E = ii.numel()
     N = t1 - t0
@@ -25,30 +41,40 @@ def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0,
     weight = weight.reshape(-1, 2).float().contiguous()
     if plan is None:
         plan = GraphPlan(ii, jj, kk)
-    kmin, kmax = int(kk.min().item()), int(kk.max().item())
-    f0 = kmin // M
-    n_frames = kmax // M - f0 + 1
+    if f0 is None or n_frames is None:
+        kmin, kmax = (int(v) for v in torch.stack([kk.min(), kk.max()]).tolist())     # one read-back
+        f0 = kmin // M
+        n_frames = kmax // M - f0 + 1
     lm = float(lmbda) if not torch.is_tensor(lmbda) else float(lmbda.reshape(-1)[0].item())
     nbytes = L.lib().dpvo_gba_workspace_bytes(L.i64(E), L.i64(plan.n_pairs_host), L.i64(n_frames), L.i32(M))
     ws = workspace.get(nbytes, poses.device, "gba")
     n6 = 6 * N
     dev = poses.device
-    infos = []
+    # the damped system and its right-hand side live in a per-stream scratch buffer (no allocation per iteration)
+    sy = workspace.get((n6 * n6 + n6) * 4, dev, "gba_sys").view(torch.float32)
+    S = sy[:n6 * n6].view(n6, n6)
+    y = sy[n6 * n6:n6 * n6 + n6]
+    ev = None
+    if _PROFILE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
     for _ in range(iterations):
-        S = torch.zeros(n6, n6, dtype=torch.float32, device=dev)
-        y = torch.zeros(n6, dtype=torch.float32, device=dev)
+        sy[:n6 * n6 + n6].zero_()
         L.check(L.lib().dpvo_gba_linearize(
             L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight), L.f32(lm), L.ptr(ii), L.ptr(jj),
             L.ptr(kk), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(E), L.i32(P), L.i32(M),
             L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(S), L.ptr(y), L.ptr(ws), ctypes.c_size_t(ws.numel()),
             L.stream()), "dpvo_gba_linearize")
+        ev = _mark("linearise + Schur", ev)
         d = S.diagonal()
         d.add_(1e-4 * d + 1.0)                                    # S += I * (1e-4 * S + 1.0)   (ba_cuda.cu:546)
         U, info = torch.linalg.cholesky_ex(S)                      # info ignored by the reference (:547)
+        ev = _mark("damping + Cholesky (rocSOLVER)", ev)
         dX = torch.cholesky_solve(y[:, None], U)[:, 0].contiguous()
-        infos.append(info)
+        ev = _mark("triangular solves", ev)
         L.check(L.lib().dpvo_gba_retract(
             L.ptr(poses), L.ptr(patches), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(E),
             L.i32(P), L.i32(M), L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(dX), L.ptr(ws),
             ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_gba_retract")
+        ev = _mark("back-substitution + retraction", ev)
     return []

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Global bundle adjustment (BASELINE config 5: LOOP_CLOSURE, dpvo.py:312-326) at size: per-phase HIP-event times of one
+`fastba.BA(..., eff_impl=True)` call with 2 iterations for growing numbers of free poses.  Synthetic sequences (M = 96 patches per
+frame as in default.yaml, every edge kept = active + inactive, plus loop edges).  Dev tool -> profiles/rNN_gba.txt"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpvo_amd import fastba, synthetic as S            # noqa: E402
+from dpvo_amd.fastba import global_ba as G             # noqa: E402
+from dpvo_amd.graph import GraphPlan                   # noqa: E402
+from dpvo_amd import projective_ops as pops            # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    M = int(os.environ.get("M", "96"))
+    print(f"{'N free':>7s} {'edges':>8s} {'patches':>8s} | " + " | ".join(f"{n:>30s}" for n in
+          ("linearise + Schur", "damping + Cholesky (rocSOLVER)", "triangular solves", "back-substitution + retraction")) + " | total ms (2 iterations)")
+    for n in (50, 100, 200, 400, 800):
+        cfg = S.GraphCfg(M=M, REMOVAL_WINDOW=10 * n, PATCH_LIFETIME=13)
+        ii, jj, kk = S.replay_graph(n, cfg)
+        old = torch.arange(3, n - 40, max(1, (n - 43) // 12))[:12]
+        ks = (old[:, None] * M + torch.arange(M)[None]).reshape(-1).repeat_interleave(3)
+        js = torch.stack([n - 20 + (old % 7), n - 12 + (old % 5), n - 6 + (old % 3)], 1).repeat_interleave(M, 0).reshape(-1)
+        ii = torch.cat([ii, ks // M]); jj = torch.cat([jj, js]); kk = torch.cat([kk, ks])
+        poses, patches, intr = S.make_scene(n, M=M, seed=1)
+        d = lambda t: t.to(dev)
+        ii, jj, kk, poses, patches, intr = d(ii), d(jj), d(kk), d(poses), d(patches), d(intr)
+        coords = pops.transform_coords(poses, patches, intr, ii, jj, kk)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        target = coords[0, :, :, 1, 1].contiguous() + 0.5 * torch.randn(ii.numel(), 2, generator=g).to(dev)
+        weight = torch.rand(ii.numel(), 2, generator=g).to(dev)
+        plan = GraphPlan(ii, jj, kk)
+        p0, pt0 = poses.clone(), patches.clone()
+        acc = {}
+        reps = 5
+        for r in range(reps + 2):
+            poses.copy_(p0); patches.copy_(pt0)
+            G._PROFILE = [] if r >= 2 else None
+            fastba.BA(poses, patches, intr, target, weight, 1e-4, ii, jj, kk, 1, n, M=M, iterations=2, eff_impl=True, plan=plan)
+            torch.cuda.synchronize()
+            if G._PROFILE:
+                for name, a, b in G._PROFILE:
+                    acc[name] = acc.get(name, 0.0) + a.elapsed_time(b) / reps
+        G._PROFILE = None
+        names = ("linearise + Schur", "damping + Cholesky (rocSOLVER)", "triangular solves", "back-substitution + retraction")
+        print(f"{n - 1:7d} {ii.numel():8d} {plan.n_patches():8d} | " + " | ".join(f"{acc[k]:30.3f}" for k in names) +
+              f" | {sum(acc.values()):.3f}")
+
+
+if __name__ == "__main__":
+    main()
