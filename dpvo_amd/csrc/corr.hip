@@ -17,6 +17,14 @@
 //   HBM/L2-bound by design: ~52.9 KB of algorithmic traffic per edge for 0.3 MFLOP.
 #include "common.h"
 
+#ifdef FU_TRACE
+// per-edge timeline (100 MHz wall clock) of corr_pyramid_kernel for tools/corr_trace.py: [edge slot 65536][8 stamps]
+__device__ unsigned long long* g_corr_trace = nullptr;
+#define CORR_T(i) do { if (g_corr_trace && threadIdx.x == 0 && blockIdx.x < 65536) g_corr_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define CORR_T(i) do {} while (0)
+#endif
+
 #define CORR_C 128
 #define CORR_P 3
 #define CORR_R 3
@@ -110,6 +118,7 @@ __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fma
     if (lane < CORR_NPIX) { meta_i[lane] = fx - mnx; meta_i[16 + lane] = fy - mny; }
     corr_bbox_mfma(a, rsrc, H, W, x0, y0, bw, bh, raw, lane);
     __syncthreads();
+    CORR_T(2 + 2 * level);
     const int np = bw * bh;
 #pragma unroll 4
     for (int s = 0; s < 7; ++s) {
@@ -154,7 +163,8 @@ __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fma
   }
 }
 
-__global__ __launch_bounds__(64) void corr_pyramid_kernel(
+template <int OCC>
+__global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel(
     const _Float16* __restrict__ gmap, const _Float16* __restrict__ fmap0, const _Float16* __restrict__ fmap1,
     const float* __restrict__ coords, const int64_t* __restrict__ us, const int64_t* __restrict__ vs,
     const int32_t* __restrict__ order, _Float16* __restrict__ out, int64_t ld_out, int64_t E, int H0, int W0,
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(64) void corr_pyramid_kernel(
       if (v >= E) continue;
       e = order[v];
     }
+    CORR_T(0);
     // ring-buffer indices (dpvo.py:202-203: ii % (M * pmem), jj % mem), reduced here instead of by two elementwise launches
     const int64_t u = (int)us[e] % N1, v = (int)vs[e] % N2;
     // A fragments: template pixel m = lane&15 (<9), channels [(4s+kg)*8, +8)
@@ -195,8 +206,14 @@ __global__ __launch_bounds__(64) void corr_pyramid_kernel(
       cx = coords[e * 18 + lane];
       cy = coords[e * 18 + 9 + lane];
     }
+#ifdef FU_TRACE
+    { float s0 = cx + (float)a[0][0]; asm volatile("" :: "v"(s0)); }        // (stamp 1 = indices, coordinates and templates have landed)
+#endif
+    CORR_T(1);
     corr_level(a, fmap0 + (int64_t)v * H0 * W0 * CORR_C, H0, W0, cx, cy, raw, meta_i, meta_f, lane, orow, 0);
+    CORR_T(3);
     corr_level(a, fmap1 + (int64_t)v * H1 * W1 * CORR_C, H1, W1, cx * 0.25f, cy * 0.25f, raw, meta_i, meta_f, lane, orow, 1);
+    CORR_T(5);
     // coalesced row store: 441 packed (level0, level1) words
     const uint32_t* src = reinterpret_cast<const uint32_t*>(orow);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
@@ -208,6 +225,7 @@ __global__ __launch_bounds__(64) void corr_pyramid_kernel(
     // zero the padding columns [882, ld_out)
     for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
     __syncthreads();
+    CORR_T(6);
   }
 }
 
@@ -323,9 +341,17 @@ extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, co
   if (N1 <= 0 || N2 <= 0 || N1 > 0x7fffffff || N2 > 0x7fffffff) return DPVO_E_INVALID;
   // with an order hint the grid is padded to 8 slices of ceil(E/8) so that the XCD remap is a bijection onto [0,E)
   const int64_t grid = order ? ((E + 7) >> 3) << 3 : E;
-  hipLaunchKernelGGL(corr_pyramid_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+  static int occ = 0;
+  if (occ == 0) { const char* e = getenv("DPVO_CORR_OCC"); occ = e ? atoi(e) : 3; if (occ < 3 || occ > 5) occ = 3; }
+  if (occ == 3) { hipLaunchKernelGGL(corr_pyramid_kernel<3>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
                      (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2);
+                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
+  else if (occ == 4) { hipLaunchKernelGGL(corr_pyramid_kernel<4>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+                     (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
+                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
+  else { hipLaunchKernelGGL(corr_pyramid_kernel<5>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+                     (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
+                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
@@ -395,3 +421,10 @@ extern "C" int dpvo_patchify_bilinear(const void* net, const int64_t* sn, const 
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
+
+#ifdef FU_TRACE
+extern "C" int dpvo_debug_corr_trace_buffer(void* buf) {      // trace builds only: device buffer of 65536*8 u64, or NULL
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_corr_trace), &p, sizeof(p));
+}
+#endif
