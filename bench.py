@@ -246,7 +246,10 @@ def main():
         avg_E = sum(uE) / len(uE)
         flops = avg_E * UPDATE_FLOP_EDGE
         tf = flops / (avg_ms * 1e-3) / 1e12
-        roof_u = {"bound": "mfma", "kernel": "update operator (Update.forward: 7 launches, dpvo_amd/csrc/update_fused.hip)",
+        auto = net_mod._AUTO_CHOICE.get((device.index,))
+        path = "7 launches, dpvo_amd/csrc/update_fused.hip" if (auto is None or auto[0]) else "23 launches, dpvo_amd/csrc/update.hip"
+        roof_u = {"bound": "mfma", "kernel": f"update operator (Update.forward: {path})",
+                  "autotune_ms": None if auto is None else {"fused": round(auto[1][True], 4), "launch_by_launch": round(auto[1][False], 4)},
                   "flops": flops, "avg_ms": round(avg_ms, 4), "achieved_tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
                   "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "edges_per_call": round(avg_E, 1),
                   "flop_per_edge": UPDATE_FLOP_EDGE, "calls": len(ums),

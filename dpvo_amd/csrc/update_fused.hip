@@ -1585,7 +1585,7 @@ void ws_layout(int64_t E, int64_t maxg, Ws* w) {
 #define FU_DW 6
 #define FU_DW7 6
 #define FU_DWPM 4
-#define FU_DWKB 4
+#define FU_DWKB 6
 
 extern "C" size_t dpvo_update_fused_pack_bytes(int K) { return K > 0 && (K % 16) == 0 ? (size_t)384 * K * 2 : 0; }
 

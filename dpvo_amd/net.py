@@ -28,6 +28,8 @@ EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 # Update.forward runs the fused row-tile kernels (update_fused.hip) unless told otherwise (DPVO_UPDATE_FUSED=0 selects the
 # launch-by-launch composite of update.hip; both stay tested against the oracle)
 FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
+AUTOTUNE = bool(int(__import__("os").environ.get("DPVO_UPDATE_AUTOTUNE", "1")))    # fused vs launch-by-launch by measurement
+_AUTO_CHOICE = {}                                                                     # device index -> (fused?, {True: ms, False: ms})
 PM_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_PM", "0")))      # patch-major (4 launches): opt-in, see DESIGN.md 3.4
 
 
@@ -264,6 +266,8 @@ class Update(nn.Module):
             inp2 = inp2.half()
         inp2 = inp2.contiguous()
 
+        if fused is None and composite and net2.dtype == torch.float32:
+            fused = self._choose_path(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, coords, E, dev, P)
         prof = PROFILE
         if prof is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
@@ -275,6 +279,36 @@ class Update(nn.Module):
             return res
         return self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
                                  composite, fused, patch_edges_ub, E, dev, P)
+
+    def _choose_path(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, coords, E, dev, P):
+        """Which kernels run Update.forward when the caller does not say: the row-tile-resident ones (update_fused.hip) unless
+        DPVO_UPDATE_FUSED=0 -- or, with DPVO_UPDATE_AUTOTUNE=1 (default), whichever of the two HIP paths is faster ON THIS DEVICE,
+        measured once per process at the first full-size call (both run on scratch outputs, ~3 ms, one host sync).  Why: on about
+        one MI355X box in six, kernels with one wave per SIMD run their VALU phases ~5x slower (profiles/README.md, "slow boxes");
+        there the launch-by-launch kernels of update.hip win."""
+        global _AUTO_CHOICE
+        if not FUSED_DEFAULT:
+            return False
+        if not AUTOTUNE or E < 16384:
+            return True
+        key = (dev.index, )
+        if key not in _AUTO_CHOICE:
+            scratch = dict(out=torch.empty(E, DIM, dtype=torch.float32, device=dev),
+                           target_out=torch.empty(E, 2, device=dev) if coords is not None else None,
+                           weight_out=torch.empty(E, 2, device=dev))
+            times = {}
+            for fz in (True, False):
+                for rep in range(3):
+                    if rep == 1:
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, scratch["out"], coords,
+                                      scratch["target_out"], scratch["weight_out"], True, fz, None, E, dev, P)
+                e1.record()
+                e1.synchronize()
+                times[fz] = e0.elapsed_time(e1) / 2
+            _AUTO_CHOICE[key] = (times[True] <= times[False], times)
+        return _AUTO_CHOICE[key][0]
 
     def forward_impl(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out, composite,
                      fused, patch_edges_ub, E, dev, P):
