@@ -14,13 +14,13 @@ slam.motion_probe = lambda: 1.0e9
 frames = bench.make_stream(64, 480, 640, dev)
 intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=dev)
 with torch.no_grad():
-    for t in range(45): slam(float(t), frames[t % 64], intr)
+    for t in range(45): slam(float(t), frames[t % 64], intr, image_ready=False)
     torch.cuda.synchronize()
     host = []
     t0 = time.perf_counter()
     for t in range(45, 105):
         a = time.perf_counter()
-        slam(float(t), frames[t % 64], intr)
+        slam(float(t), frames[t % 64], intr, image_ready=False)
         host.append(time.perf_counter() - a)
     slam.flush(); torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -30,6 +30,6 @@ if len(sys.argv) > 1:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
     with torch.no_grad():
-        for t in range(105, 165): slam(float(t), frames[t % 64], intr)
+        for t in range(105, 165): slam(float(t), frames[t % 64], intr, image_ready=False)
     pr.disable(); slam.flush(); torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats(sys.argv[1] if sys.argv[1] in ("tottime", "cumulative") else "cumulative").print_stats(45)
