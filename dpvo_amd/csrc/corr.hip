@@ -230,220 +230,6 @@ __global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// corr_pyramid_kernel2: the same arithmetic as corr_pyramid_kernel, re-scheduled around what the per-edge timeline showed
-// (tools/corr_trace.py: 17.7 us per edge = indices/coords/templates 1.9 + level-0 tiles 5.2 + blend 2.2 + level-1 tiles 4.4 +
-// blend 2.2 + store 1.2, and ~110 us of VALU issue per SIMD):
-//   * persistent workgroups (one wave each, 12 per CU): the NEXT edge's indices are requested at the top of an edge and its
-//     coordinates / templates in the middle, so an edge no longer starts with two dependent round trips;
-//   * the first tile batch of level 1 is requested BEFORE level 0 is blended (the 64 tile registers are free by then; each level
-//     has its own raw volume in LDS), so the blend runs under the loads;
-//   * the blend is mapped (patch pixel, window row) -> lane and walks the 7 window columns: 16 LDS reads and 4 weights per lane
-//     and level instead of 28 reads, 28 weight products and a div / mod chain per output.
-// Windows that do not fit the single-pass box (extreme scale change, far out of bounds) take corr_level() of the kernel above.
-// ---------------------------------------------------------------------------------------------------
-struct CorrBox { int x0, y0, bw, bh, np; bool single; };
-
-__device__ __forceinline__ CorrBox corr_box(float cx, float cy, int lane, int* __restrict__ mi, float* __restrict__ mf) {
-  const int fx = safe_floor_int(cx), fy = safe_floor_int(cy);
-  int mnx = (lane < CORR_NPIX) ? fx : INT_MAX, mxx = (lane < CORR_NPIX) ? fx : INT_MIN;
-  int mny = (lane < CORR_NPIX) ? fy : INT_MAX, mxy = (lane < CORR_NPIX) ? fy : INT_MIN;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    mnx = min(mnx, __shfl_xor(mnx, o)); mxx = max(mxx, __shfl_xor(mxx, o));
-    mny = min(mny, __shfl_xor(mny, o)); mxy = max(mxy, __shfl_xor(mxy, o));
-  }
-  mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);
-  mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
-  const int64_t bw64 = (int64_t)mxx - mnx + CORR_D, bh64 = (int64_t)mxy - mny + CORR_D;
-  CorrBox b;
-  b.single = (bw64 * bh64 <= CORR_MAXPOS);
-  b.bw = b.single ? (int)bw64 : CORR_D; b.bh = b.single ? (int)bh64 : CORR_D;
-  b.np = b.bw * b.bh;
-  b.x0 = mnx - CORR_R; b.y0 = mny - CORR_R;
-  if (lane < CORR_NPIX) {
-    mf[lane] = cx - floorf(cx); mf[16 + lane] = cy - floorf(cy);
-    mi[lane] = fx - mnx; mi[16 + lane] = fy - mny;
-  }
-  return b;
-}
-
-// four tiles (16 positions each) starting at tile t0: 16 x 16 B per lane in flight
-__device__ __forceinline__ void corr_tiles_issue(u4 (&b)[CORR_U][4], __amdgpu_buffer_rsrc_t rsrc, int H, int W, const CorrBox& bx,
-                                                 int t0, int lane) {
-  const int n = lane & 15, kg = lane >> 4;
-  const float inv_bw = 1.0f / (float)bx.bw;
-#pragma unroll
-  for (int u = 0; u < CORR_U; ++u) {
-    const int pos = (t0 + u) * 16 + n;
-    const int py = (int)(((float)pos + 0.5f) * inv_bw), px = pos - py * bx.bw;
-    const int y = bx.y0 + py, x = bx.x0 + px;
-    const bool ok = (pos < bx.np) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-    const unsigned voff = ok ? (unsigned)(((y * W + x) * CORR_C + kg * 8) * 2) : 0x80000000u;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) b[u][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + s * 64, 0, 0);
-  }
-}
-__device__ __forceinline__ void corr_tiles_consume(const h8 (&a)[4], const u4 (&b)[CORR_U][4], float* __restrict__ raw, int np,
-                                                   int t0, int lane) {
-  const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-  for (int u = 0; u < CORR_U; ++u) {
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], as_h8(b[u][s]), acc, 0, 0, 0);
-    const int pos = (t0 + u) * 16 + n;
-    if (pos < np) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * kg + r;
-        if (m < CORR_NPIX) raw[m * np + pos] = acc[r];
-      }
-    }
-  }
-}
-// lane (p = lane % 9, ay = lane / 9) < 63 blends the 7 outputs (bx = 0..6) of patch pixel p, window row ay
-__device__ __forceinline__ void corr_blend_rows(const float* __restrict__ raw, const int* __restrict__ mi, const float* __restrict__ mf,
-                                                int bw, int np, int lane, int p, int ay, _Float16* __restrict__ orow, int level) {
-  if (lane < 63) {
-    const float ddx = mf[p], ddy = mf[16 + p];
-    const float* rp = raw + p * np + (mi[16 + p] + ay) * bw + mi[p];
-    float r0[8], r1[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { r0[k] = rp[k]; r1[k] = rp[bw + k]; }
-    const float w00 = (1.f - ddx) * (1.f - ddy), w01 = ddx * (1.f - ddy), w10 = (1.f - ddx) * ddy, w11 = ddx * ddy;
-#pragma unroll
-    for (int bx = 0; bx < 7; ++bx) {
-      float o = w00 * r0[bx];
-      o += w01 * r0[bx + 1];
-      o += w10 * r1[bx];
-      o += w11 * r1[bx + 1];
-      orow[2 * (bx * 63 + lane) + level] = (_Float16)o;
-    }
-  }
-}
-
-template <int OCC, int DBG>
-__global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel2(
-    const _Float16* __restrict__ gmap, const _Float16* __restrict__ fmap0, const _Float16* __restrict__ fmap1,
-    const float* __restrict__ coords, const int64_t* __restrict__ us, const int64_t* __restrict__ vs,
-    const int32_t* __restrict__ order, _Float16* __restrict__ out, int64_t ld_out, int64_t E, int H0, int W0,
-    int H1, int W1, int N1, int N2) {
-  __shared__ __attribute__((aligned(16))) float raw[2][CORR_NPIX * CORR_MAXPOS];
-  __shared__ __attribute__((aligned(16))) _Float16 orow[2 * CORR_NOUT + 2];
-  __shared__ int meta_i[2][32];
-  __shared__ float meta_f[2][32];
-  const int lane = threadIdx.x;
-  const int bp = lane % 9, bay = lane / 9;                 // blend mapping (lane constants)
-  const int am = lane & 15, akg = lane >> 4;               // template fragment mapping
-  const int64_t nblk = order ? ((E + 7) >> 3) << 3 : E;
-  const int64_t per = (E + 7) >> 3;
-  auto edge_of = [&](int64_t blk) -> int64_t {             // -1: padding slot of the ordered walk
-    if (blk >= nblk) return -1;
-    if (!order) return blk;
-    const int64_t v = (blk & 7) * per + (blk >> 3);
-    return v < E ? (int64_t)order[v] : -1;
-  };
-  auto load_templates = [&](h8 (&a)[4], int64_t u) {
-    if (am < CORR_NPIX) {
-      const h8* src = reinterpret_cast<const h8*>(gmap + ((int64_t)u * CORR_NPIX + am) * CORR_C) + akg;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = src[4 * s];
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = (h8)(_Float16)0;
-    }
-  };
-  // ---- first edge of this workgroup
-  int64_t blk = blockIdx.x;
-  int64_t e = edge_of(blk);
-  while (e < 0 && blk < nblk) { blk += gridDim.x; e = edge_of(blk); }
-  if (e < 0) return;
-  h8 a[4];
-  float cx = 0.f, cy = 0.f;
-  int64_t v;
-  {
-    const int64_t u = (int)us[e] % N1;
-    v = (int)vs[e] % N2;
-    load_templates(a, u);
-    if (lane < CORR_NPIX) { cx = coords[e * 18 + lane]; cy = coords[e * 18 + 9 + lane]; }
-  }
-  for (;;) {
-    CORR_T(0);
-    // the next edge of this workgroup: indices now, coordinates / templates later in this iteration
-    int64_t blk_n = blk + gridDim.x;
-    int64_t e_n = edge_of(blk_n);
-    while (e_n < 0 && blk_n < nblk) { blk_n += gridDim.x; e_n = edge_of(blk_n); }
-    int64_t un_raw = 0, vn_raw = 0;
-    if (e_n >= 0) { un_raw = us[e_n]; vn_raw = vs[e_n]; }
-
-    const _Float16* f0 = fmap0 + (int64_t)v * H0 * W0 * CORR_C;
-    const _Float16* f1 = fmap1 + (int64_t)v * H1 * W1 * CORR_C;
-    const CorrBox b0 = corr_box(cx, cy, lane, meta_i[0], meta_f[0]);
-    const CorrBox b1 = corr_box(cx * 0.25f, cy * 0.25f, lane, meta_i[1], meta_f[1]);
-    h8 a_n[4];
-    float cx_n = 0.f, cy_n = 0.f;
-    int64_t v_n = 0;
-    if (b0.single && b1.single) {
-      const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)f0, (short)0, H0 * W0 * CORR_C * 2, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)f1, (short)0, H1 * W1 * CORR_C * 2, 0x00020000);
-      u4 tb[CORR_U][4];
-      if (DBG & 1) { for (int u = 0; u < CORR_U; ++u) for (int q = 0; q < 4; ++q) tb[u][q] = (u4)(unsigned)lane; }
-      const int nt0 = (b0.np + 15) >> 4, nt1 = (b1.np + 15) >> 4;
-      for (int t0 = 0; t0 < nt0; t0 += CORR_U) {
-        if (!(DBG & 1)) corr_tiles_issue(tb, rs0, H0, W0, b0, t0, lane);
-        if (!(DBG & 2)) corr_tiles_consume(a, tb, raw[0], b0.np, t0, lane);
-      }
-      CORR_T(2);
-      if (!(DBG & 1)) corr_tiles_issue(tb, rs1, H1, W1, b1, 0, lane);               // level 1, first batch: lands under the level-0 blend
-      if (e_n >= 0) {                                                // next edge: coordinates and templates
-        v_n = (int)vn_raw % N2;
-        load_templates(a_n, (int)un_raw % N1);
-        if (lane < CORR_NPIX) { cx_n = coords[e_n * 18 + lane]; cy_n = coords[e_n * 18 + 9 + lane]; }
-      }
-      __syncthreads();
-      if (!(DBG & 4)) corr_blend_rows(raw[0], meta_i[0], meta_f[0], b0.bw, b0.np, lane, bp, bay, orow, 0);
-      CORR_T(3);
-      if (!(DBG & 2)) corr_tiles_consume(a, tb, raw[1], b1.np, 0, lane);
-      for (int t0 = CORR_U; t0 < nt1; t0 += CORR_U) {
-        if (!(DBG & 1)) corr_tiles_issue(tb, rs1, H1, W1, b1, t0, lane);
-        if (!(DBG & 2)) corr_tiles_consume(a, tb, raw[1], b1.np, t0, lane);
-      }
-      __syncthreads();
-      CORR_T(4);
-      if (!(DBG & 4)) corr_blend_rows(raw[1], meta_i[1], meta_f[1], b1.bw, b1.np, lane, bp, bay, orow, 1);
-      __syncthreads();
-      CORR_T(5);
-    } else {
-      if (e_n >= 0) {
-        v_n = (int)vn_raw % N2;
-        load_templates(a_n, (int)un_raw % N1);
-        if (lane < CORR_NPIX) { cx_n = coords[e_n * 18 + lane]; cy_n = coords[e_n * 18 + 9 + lane]; }
-      }
-      __syncthreads();
-      corr_level(a, f0, H0, W0, cx, cy, raw[0], meta_i[0], meta_f[0], lane, orow, 0);
-      corr_level(a, f1, H1, W1, cx * 0.25f, cy * 0.25f, raw[0], meta_i[0], meta_f[0], lane, orow, 1);
-    }
-    // coalesced row store: 441 packed (level0, level1) words, then the zero padding columns [882, ld_out)
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(orow);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
-    if (!(DBG & 8)) {
-#pragma unroll
-      for (int s = 0; s < 7; ++s) {
-        const int q = lane + 64 * s;
-        if (q < CORR_NOUT) dst[q] = src[q];
-      }
-      for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
-    }
-    __syncthreads();
-    CORR_T(6);
-    if (e_n < 0) break;
-    blk = blk_n; e = e_n; v = v_n; cx = cx_n; cy = cy_n;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = a_n[s];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Generic (any stride, f16/f32, any C/P/radius) single-level kernel: API-parity path of cuda_corr.forward.
 // One thread per output element (e, a, b, i0, j0): 4 window dot products + bilinear.
 // ---------------------------------------------------------------------------------------------------
@@ -555,37 +341,6 @@ extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, co
   if (N1 <= 0 || N2 <= 0 || N1 > 0x7fffffff || N2 > 0x7fffffff) return DPVO_E_INVALID;
   // with an order hint the grid is padded to 8 slices of ceil(E/8) so that the XCD remap is a bijection onto [0,E)
   const int64_t grid = order ? ((E + 7) >> 3) << 3 : E;
-  static int v2 = -1;
-  if (v2 < 0) { const char* ev = getenv("DPVO_CORR_V2"); v2 = ev ? atoi(ev) : 1; }
-  if (v2) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
-    }
-    static int occ2 = 0;
-    if (occ2 == 0) { const char* eo = getenv("DPVO_CORR_OCC2"); occ2 = eo ? atoi(eo) : 3; if (occ2 < 2 || occ2 > 3) occ2 = 3; }
-    int64_t g2 = (int64_t)n_cu * 4 * occ2;                // one wave per workgroup, occ2 waves per SIMD
-    if (g2 > grid) g2 = grid;
-    static int dbg = -1;
-    if (dbg < 0) { const char* ed = getenv("DPVO_CORR_DBG"); dbg = ed ? atoi(ed) : 0; }
-#define CORR_L2(O, G) hipLaunchKernelGGL((corr_pyramid_kernel2<O, G>), dim3((unsigned)g2), dim3(64), 0, (hipStream_t)stream, \
-      (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order, (_Float16*)out, ld_out, E, H0, W0, \
-      H1, W1, (int)N1, (int)N2)
-    if (occ2 == 3) CORR_L2(3, 0);
-    else if (dbg == 1) CORR_L2(2, 1);       // (experiment switches: what is left when a part of the kernel is removed)
-    else if (dbg == 2) CORR_L2(2, 2);
-    else if (dbg == 3) CORR_L2(2, 3);
-    else if (dbg == 4) CORR_L2(2, 4);
-    else if (dbg == 8) CORR_L2(2, 8);
-    else if (dbg == 15) CORR_L2(2, 15);
-    else CORR_L2(2, 0);
-#undef CORR_L2
-    DPVO_LAUNCH_CHECK();
-    return DPVO_OK;
-  }
   static int occ = 0;
   if (occ == 0) { const char* e = getenv("DPVO_CORR_OCC"); occ = e ? atoi(e) : 3; if (occ < 3 || occ > 5) occ = 3; }
   if (occ == 3) { hipLaunchKernelGGL(corr_pyramid_kernel<3>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
