@@ -19,6 +19,17 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Bilinear blend of a 2x2 window exactly as the reference's Python evaluates it (altcorr/correlation.py:62-66):
+// x00 = (1-dy)*(1-dx)*v00 ... ; out = x00 + x01 + x10 + x11, every product and sum rounded to f32 on its own.  The pragma
+// keeps the compiler from contracting a*b+c into an FMA (HIP's __fmul_rn / __fadd_rn are plain operators and do not), which it
+// otherwise decides per translation unit -- and differently with and without packed-FP32 ops -- so that two kernels computing
+// "the same" blend would differ in the last bit.
+__device__ __forceinline__ float blend4_ref(float dx, float dy, float v00, float v01, float v10, float v11) {
+#pragma clang fp contract(off)
+  const float ey = 1.f - dy, ex = 1.f - dx;
+  const float x00 = ey * ex * v00, x01 = ey * dx * v01, x10 = dy * ex * v10, x11 = dy * dx * v11;
+  return ((x00 + x01) + x10) + x11;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -321,11 +321,7 @@ __global__ void patchify_bilinear_kernel(const T* __restrict__ net, int64_t sc, 
         const int i = i0 + aa, j = j0 + bb;
         v[aa][bb] = (i >= 0 && i < H && j >= 0 && j < W) ? (float)net[c * sc + i * sh + j * sw] : 0.f;
       }
-    // same term order as the reference: x00 + x01 + x10 + x11
-    float o = (1.f - dy) * (1.f - dx) * v[0][0];
-    o += (1.f - dy) * dx * v[0][1];
-    o += dy * (1.f - dx) * v[1][0];
-    o += dy * dx * v[1][1];
+    const float o = blend4_ref(dx, dy, v[0][0], v[0][1], v[1][0], v[1][1]);
     out[n] = (T)o;
   }
 }

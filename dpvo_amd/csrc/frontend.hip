@@ -36,10 +36,7 @@ __global__ void patch_colors_kernel(const uint8_t* __restrict__ img, const float
       const int i = i0 + a, j = j0 + b;
       v[a][b] = (i >= 0 && i < H && j >= 0 && j < W) ? 2.0f * ((float)img[((int64_t)cs * H + i) * W + j] * (1.0f / 255.0f)) - 0.5f : 0.f;
     }
-  float o = (1.f - dy) * (1.f - dx) * v[0][0];
-  o += (1.f - dy) * dx * v[0][1];
-  o += dy * (1.f - dx) * v[1][0];
-  o += dy * dx * v[1][1];
+  const float o = blend4_ref(dx, dy, v[0][0], v[0][1], v[1][0], v[1][1]);
   const float f = (o + 0.5f) * (255.0f / 2.0f);
   out[t] = (uint8_t)(int)f;                                        // tensor.to(torch.uint8): truncation toward zero
 }
@@ -276,11 +273,7 @@ __device__ __forceinline__ float fp_blend(float x, float y, int i0, int j0, int 
       const int i = i0 + aa, j = j0 + bb;
       v[aa][bb] = (i >= 0 && i < H && j >= 0 && j < W) ? at(i, j) : 0.f;
     }
-  // same term order as the reference: x00 + x01 + x10 + x11 (correlation.py:62-66)
-  float o = (1.f - dy) * (1.f - dx) * v[0][0];
-  o += (1.f - dy) * dx * v[0][1];
-  o += dy * (1.f - dx) * v[1][0];
-  o += dy * dx * v[1][1];
+  const float o = blend4_ref(dx, dy, v[0][0], v[0][1], v[1][0], v[1][1]);
   return o;
 }
 struct FramePatchesArgs {

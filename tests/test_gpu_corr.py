@@ -94,6 +94,9 @@ def test_patchify_vs_oracle(oracle, dev):
         ref = oracle.patchify(net[0].numpy(), coords[0].numpy(), radius)
         out = altcorr.patchify(net.to(dev), coords.to(dev), radius)
         H.assert_close(out[0].cpu().numpy(), ref, 1e-5, 1e-5, "patchify")
+        # f32 in, f32 arithmetic in the reference's operation order, nothing contracted: bit-identical to the f32 oracle
+        ref32 = oracle.patchify(net[0].numpy(), coords[0].numpy(), radius, dtype=np.float32)
+        assert np.array_equal(out[0].cpu().numpy(), ref32)
         outh = altcorr.patchify(net.half().to(dev), coords.to(dev), radius)
         assert outh.shape == out.shape
 

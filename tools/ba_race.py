@@ -69,11 +69,13 @@ for r in range(60):
                 cols = (a[rows[m]] != b[rows[m]]).any(0).nonzero().flatten().tolist()
                 print("   pair", gq, "size", int(plan0.pair_off[gq + 1] - plan0.pair_off[gq]), "bad local positions", sorted(lp[m].tolist()), "fields", cols)
             for e in rows[:3].tolist():
-                print("   e", e, "now", [f"{x:.6g}" for x in a[e].tolist()][:8], "\n        ref", [f"{x:.6g}" for x in b[e].tolist()][:8])
+                print("   e", e, "now", [f"{x:.6g}" for x in a[e].tolist()], "\n        ref", [f"{x:.6g}" for x in b[e].tolist()], "\n        now-ref", [f"{x:.3g}" for x in (a[e] - b[e]).tolist()])
             A2 = ws[offs[0]:offs[1]].view(torch.float32).view(-1, PAIR); B2 = ref[offs[0]:offs[1]].view(torch.float32).view(-1, PAIR)
             pr = (A2 != B2).any(1).nonzero().flatten()
             print("  pairbuf rows (pairs) differing:", pr.tolist()[:20])
             if pr.numel():
                 g = int(pr[0]); dd = (A2[g] != B2[g]).nonzero().flatten()
                 print("   pair", g, "ij", plan0.pair_ij.view(-1, 2)[g].tolist(), "n diff entries", dd.numel(), "max rel", float(((A2[g] - B2[g]).abs() / (B2[g].abs() + 1e-20)).max()))
+                print("   Gram (row, col) differing:", [(int(x) // 16, int(x) % 16) for x in dd.tolist()])
+                print("   Gram now-ref on those:", [f"{float(A2[g][x] - B2[g][x]):.4g}" for x in dd.tolist()])
 print("done")

@@ -49,4 +49,4 @@ for mode in sys.argv[1:] or ["copy", "copy_sync", "clone", "noenc"]:
                 seen.append(out)
     torch.cuda.synchronize()
     d = (seen[1] != seen[0]).nonzero().flatten() if len(seen) > 1 else []
-    print(f"{mode:12s} mismatching reps: {bad} / {reps - 1}; distinct results {len(seen)}; first diff idx {d[:6].tolist() if len(d) else []} of {len(d)} (poses occupy [0,{p0.numel()}))")
+    print(f"{mode:12s} mismatching reps: {bad} / {reps - 1}; distinct results {len(seen)}; first diff idx {d[:6].tolist() if len(d) else []} of {len(d)} (poses occupy [0,{p0.numel()})); first result checksum {int(seen[0].view(torch.int32).long().sum()):x}")
