@@ -249,7 +249,7 @@ def main():
         auto = net_mod._AUTO_CHOICE.get((device.index,))
         path = "7 launches, dpvo_amd/csrc/update_fused.hip" if (auto is None or auto[0]) else "23 launches, dpvo_amd/csrc/update.hip"
         roof_u = {"bound": "mfma", "kernel": f"update operator (Update.forward: {path})",
-                  "autotune_ms": None if auto is None else {"fused": round(auto[1][True], 4), "launch_by_launch": round(auto[1][False], 4)},
+                  "autotune_ms": None if auto is None else {k: round(v, 4) for k, v in auto[1].items()}, "autotune_edges": None if auto is None else auto[2],
                   "flops": flops, "avg_ms": round(avg_ms, 4), "achieved_tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
                   "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "edges_per_call": round(avg_E, 1),
                   "flop_per_edge": UPDATE_FLOP_EDGE, "calls": len(ums),

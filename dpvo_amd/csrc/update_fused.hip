@@ -112,6 +112,22 @@ __device__ __forceinline__ void bias_load(Bias& b, const _Float16* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) b.v[t][j] = *reinterpret_cast<const h4*>(bias + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
 }
+// (several workgroups per CU: no early bias load, the accumulators start straight from memory)
+template <int RT>
+__device__ __forceinline__ void acc_init_mem(f16v (&acc)[RT][3], const _Float16* __restrict__ bias, const Lane& l) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    f16v v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const h4 b = *reinterpret_cast<const h4*>(bias + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[4 * j + q] = (float)b[q];
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r][t] = v;
+  }
+}
 template <int RT>
 __device__ __forceinline__ void acc_init(f16v (&acc)[RT][3], const Bias& b) {
 #pragma unroll
@@ -270,7 +286,14 @@ __device__ __forceinline__ void layernorm_tile(f16v (&v)[RT][3], float* red, con
 // same, affine parameters in LDS (gb: [gamma 384 | beta 384] f32, feature order; copied once per persistent workgroup):
 // no 96-register parameter block while the 144-register state is live
 template <int RT>
+__device__ __forceinline__ void layernorm_tile_late(f16v (&v)[RT][3], float* red, const float* gp, const float* bp, const Lane& l);
+template <int RT>
 __device__ __forceinline__ void layernorm_tile_lds(f16v (&v)[RT][3], float* red, const float* gb, const Lane& l) {
+  layernorm_tile_late<RT>(v, red, gb, gb + D, l);
+}
+// (also with the parameters in global memory when several workgroups share a CU and cover each other's round trips)
+template <int RT>
+__device__ __forceinline__ void layernorm_tile_late(f16v (&v)[RT][3], float* red, const float* gp, const float* bp, const Lane& l) {
   constexpr int R = 32 * RT;
   float* red1 = red;
   float* red2 = red + R * 4;
@@ -309,7 +332,7 @@ __device__ __forceinline__ void layernorm_tile_lds(f16v (&v)[RT][3], float* red,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int f = 96 * l.w + 32 * t + 8 * j + 4 * l.h;
-      const f4 g = *reinterpret_cast<const f4*>(gb + f), b = *reinterpret_cast<const f4*>(gb + D + f);
+      const f4 g = *reinterpret_cast<const f4*>(gp + f), b = *reinterpret_cast<const f4*>(bp + f);
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -359,6 +382,27 @@ __device__ __forceinline__ void img_store(const f16v (&v)[RT][3], float* ip) {
         for (int q = 0; q < 4; ++q) x[q] = v[r][t][4 * j + q];
         *reinterpret_cast<f4*>(ip + r * IMG_RT_STRIDE + (t * 4 + j) * 256) = x;
       }
+}
+
+// two workgroups per CU: no registers for an image in flight under a GEMM (and the other workgroup covers the latency):
+// v += image, image = v, one 32-row tile at a time
+template <int RT>
+__device__ __forceinline__ void img_add_store_stream(f16v (&v)[RT][3], float* ip) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    Img<1> m;
+    img_load<1>(m, ip + r * IMG_RT_STRIDE);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f4 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[r][t][4 * j + q] += m.v[0][t][j][q]; x[q] = v[r][t][4 * j + q]; }
+        *reinterpret_cast<f4*>(ip + r * IMG_RT_STRIDE + (t * 4 + j) * 256) = x;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // rows of a P-order f16 matrix [., 384] -> the LDS tile.  rows == nullptr: row0 + i; an index < 0 or a row >= E: zeros
@@ -411,8 +455,8 @@ struct P1 {
 };
 
 // K1 -----------------------------------------------------------------------------------------------
-template <int RT, int DW>
-__global__ __launch_bounds__(256, 1) void k1_corr_norm(const P1 p) {
+template <int RT, int DW, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = Geo<RT>::R;
   const Lane l = lane_of();
@@ -429,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void k1_corr_norm(const P1 p) {
   {
     const h8* wp = w_base(p.c0.w, 56, l);
     w_preload<DW>(wf, wp);
-    bias_load(bias, p.c0.b, l);
+    if constexpr (OCC == 1) bias_load(bias, p.c0.b, l);
     constexpr int NS = RT * 2;                         // 16-byte pieces per thread per chunk
     // chunk kc + 2 is requested (into one of two register sets) while chunk kc is multiplied and chunk kc + 1 waits in the
     // other set for its LDS stage: a chunk lasts ~1 us of MFMAs, a miss to HBM under load about twice that.
@@ -452,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void k1_corr_norm(const P1 p) {
     };
     load(st[0], 0);
     load(st[1], 1);
-    acc_init<RT>(acc, bias);
+    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.c0.b, l);
     store(st[0], 0);
     __syncthreads();
     FU_T(0, 1);
@@ -489,39 +533,40 @@ __global__ __launch_bounds__(256, 1) void k1_corr_norm(const P1 p) {
   FU_T(0, 2);
   const h8* wp2 = w_base(p.c2.w, KS384, l);
   w_preload<DW>(wf, wp2);
-  bias_load(bias, p.c2.b, l);
+  if constexpr (OCC == 1) bias_load(bias, p.c2.b, l);
   to_lds<RT, 1>(acc, al, l);                            // (the last barrier of the chunk loop freed the stages)
   __syncthreads();
   // ---- Linear, LayerNorm, ReLU
-  acc_init<RT>(acc, bias);
+  if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.c2.b, l);
   gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp2, al);
   FU_T(0, 3);
   const h8* wp3 = w_base(p.c5.w, KS384, l);
   w_preload<DW>(wf, wp3);
-  bias_load(bias, p.c5.b, l);
+  if constexpr (OCC == 1) bias_load(bias, p.c5.b, l);
   round_f16<RT>(acc);
-  layernorm_tile<RT>(acc, red, p.cln_g, p.cln_b, l);
+  if constexpr (OCC == 1) layernorm_tile<RT>(acc, red, p.cln_g, p.cln_b, l); else layernorm_tile_late<RT>(acc, red, p.cln_g, p.cln_b, l);
   to_lds<RT, 1>(acc, al, l);
   __syncthreads();
   FU_T(0, 4);
-  // ---- Linear; net = LayerNorm(net + inp + .).  The rows of net (feature order) are requested before the GEMM.
-  Img<RT> nv;
-  int64_t ir[RT];
+  // ---- Linear; net = LayerNorm(net + inp + .).
+  if constexpr (OCC == 1) {
+    // one workgroup per CU: the rows of net (feature order) are requested before the GEMM
+    Img<RT> nv;
+    int64_t ir[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    int64_t g = row0 + r * 32 + l.n;
-    g = g < p.E ? g : p.E - 1;
-    ir[r] = g;
-    if (p.inp_rows) { ir[r] = p.inp_rows[g]; if (p.inp_mod > 0) ir[r] %= p.inp_mod; }
+    for (int r = 0; r < RT; ++r) {
+      int64_t g = row0 + r * 32 + l.n;
+      g = g < p.E ? g : p.E - 1;
+      ir[r] = g;
+      if (p.inp_rows) { ir[r] = p.inp_rows[g]; if (p.inp_mod > 0) ir[r] %= p.inp_mod; }
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) nv.v[r][t][j] = *reinterpret_cast<const f4*>(p.net + g * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
-  }
-  acc_init<RT>(acc, bias);
-  gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp3, al);
-  FU_T(0, 5);
-  {
+        for (int j = 0; j < 4; ++j) nv.v[r][t][j] = *reinterpret_cast<const f4*>(p.net + g * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+    }
+    acc_init<RT>(acc, bias);
+    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp3, al);
+    FU_T(0, 5);
     h4 iv[RT][3][4];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -539,8 +584,37 @@ __global__ __launch_bounds__(256, 1) void k1_corr_norm(const P1 p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             acc[r][t][4 * j + q] = (nv.v[r][t][j][q] + (float)iv[r][t][j][q]) + acc[r][t][4 * j + q];
+  } else {
+    // several workgroups per CU: no registers for rows in flight under the GEMM; one 32-row tile at a time afterwards
+    acc_init_mem<RT>(acc, p.c5.b, l);
+    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp3, al);
+    FU_T(0, 5);
+    round_f16<RT>(acc);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      int64_t g = row0 + r * 32 + l.n;
+      g = g < p.E ? g : p.E - 1;
+      int64_t ir = g;
+      if (p.inp_rows) { ir = p.inp_rows[g]; if (p.inp_mod > 0) ir %= p.inp_mod; }
+      f4 nv[3][4]; h4 iv[3][4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          nv[t][j] = *reinterpret_cast<const f4*>(p.net + g * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+          iv[t][j] = *reinterpret_cast<const h4*>(p.inp + ir * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+        }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[r][t][4 * j + q] = (nv[t][j][q] + (float)iv[t][j][q]) + acc[r][t][4 * j + q];
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  layernorm_tile<RT>(acc, red, p.norm_g, p.norm_b, l);
+  if constexpr (OCC == 1) layernorm_tile<RT>(acc, red, p.norm_g, p.norm_b, l); else layernorm_tile_late<RT>(acc, red, p.norm_g, p.norm_b, l);
   FU_T(0, 6);
   img_store<RT>(acc, img_ptr<RT>(p.img, tile, l));
   to_lds<RT, 0>(acc, al, l);
@@ -561,8 +635,8 @@ struct P2 {
 };
 enum { MODE_C1 = 0, MODE_C2 = 1, MODE_H = 2 };
 
-template <int RT, int DW, int MODE>
-__global__ __launch_bounds__(256, 1) void k_chain(const P2 p) {
+template <int RT, int DW, int MODE, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void k_chain(const P2 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = Geo<RT>::R;
   const Lane l = lane_of();
@@ -578,36 +652,40 @@ __global__ __launch_bounds__(256, 1) void k_chain(const P2 p) {
   float* ip = img_ptr<RT>(p.img, tile, l);
   const h8* wpa = w_base(MODE == MODE_H ? p.b.w : p.a.w, KS384, l);
   w_preload<DW>(wf, wpa);
-  bias_load(bias, MODE == MODE_H ? p.b.b : p.a.b, l);
+  if constexpr (OCC == 1) bias_load(bias, MODE == MODE_H ? p.b.b : p.a.b, l);
   gather_rows<RT>(act, p.src, p.rows, row0, p.E, l.tid);
-  if constexpr (MODE == MODE_H) img_load<RT>(im, ip);
+  if constexpr (MODE == MODE_H && OCC == 1) img_load<RT>(im, ip);
   FU_T(1 + MODE, 1);
   __syncthreads();
   FU_T(1 + MODE, 2);
   if constexpr (MODE != MODE_H) {
-    acc_init<RT>(acc, bias);
+    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.a.b, l);
     gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpa, al);
     const h8* wpb = w_base(p.b.w, KS384, l);
     FU_T(1 + MODE, 3);
     w_preload<DW>(wf, wpb);
-    bias_load(bias, p.b.b, l);
-    img_load<RT>(im, ip);                           // lands under the second GEMM
+    if constexpr (OCC == 1) bias_load(bias, p.b.b, l);
+    if constexpr (OCC == 1) img_load<RT>(im, ip);   // lands under the second GEMM
     __syncthreads();
     to_lds<RT, 1>(acc, al, l);
     __syncthreads();
     FU_T(1 + MODE, 4);
-    acc_init<RT>(acc, bias);
+    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.b.b, l);
     gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpb, al);
   } else {
-    acc_init<RT>(acc, bias);
+    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.b.b, l);
     gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpa, al);
   }
   FU_T(1 + MODE, 5);
   const h8* wpf = nullptr;
-  if constexpr (MODE != MODE_C1) { wpf = w_base(p.f.w, KS384, l); w_preload<DW>(wf, wpf); bias_load(bias, p.f.b, l); }
+  if constexpr (MODE != MODE_C1) { wpf = w_base(p.f.w, KS384, l); w_preload<DW>(wf, wpf); if constexpr (OCC == 1) bias_load(bias, p.f.b, l); }
   round_f16<RT>(acc);
-  img_add<RT>(acc, im);
-  img_store<RT>(acc, ip);
+  if constexpr (OCC == 1) {
+    img_add<RT>(acc, im);
+    img_store<RT>(acc, ip);
+  } else {
+    img_add_store_stream<RT>(acc, ip);
+  }
   FU_T(1 + MODE, 6);
   __syncthreads();
   to_lds<RT, 0>(acc, al, l);
@@ -617,15 +695,15 @@ __global__ __launch_bounds__(256, 1) void k_chain(const P2 p) {
     scatter_rows<RT>(act, p.rows16, row0, p.E, l.tid);
     FU_T(1 + MODE, 8);
   } else {
-    acc_init<RT>(acc, bias);
+    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.f.b, l);
     gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpf, al);
     FU_T(1 + MODE, 8);
     const h8* wpg = w_base(p.g.w, KS384, l);
     w_preload<DW>(wf, wpg);
-    bias_load(bias, p.g.b, l);
+    if constexpr (OCC == 1) bias_load(bias, p.g.b, l);
     to_rows<RT>(acc, p.fg, 768, row0, p.E, l);
     FU_T(1 + MODE, 9);
-    acc_init<RT>(acc, bias);
+    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.g.b, l);
     gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpg, al);
     FU_T(1 + MODE, 10);
     to_rows<RT>(acc, p.fg + D, 768, row0, p.E, l);
@@ -1570,7 +1648,7 @@ template <int RT>
 void ws_layout(int64_t E, int64_t maxg, Ws* w) {
   const size_t tiles = (size_t)cdiv64(E > 0 ? E : 1, 32 * RT), g = (size_t)(maxg > 0 ? maxg : 1), e = (size_t)(E > 0 ? E : 1);
   size_t o = 0;
-  w->img = o; o += al256(tiles * 32 * RT * D * 4);
+  w->img = o; o += al256((size_t)cdiv64((int64_t)e, 192) * 192 * D * 4);       // (covers the 64-row and the 96-row tilings)
   w->r16a = o; o += al256(e * D * 2);
   w->r16b = o; o += al256(e * D * 2);
   w->fg = o; o += al256(e * 2 * D * 2);
@@ -1584,6 +1662,13 @@ void ws_layout(int64_t E, int64_t maxg, Ws* w) {
 #define FU_RT 3
 #define FU_DW 6
 #define FU_DW7 6
+#ifndef FU_DW2
+#define FU_DW2 3
+#endif
+#ifndef FU_OCC2
+#define FU_OCC2 2
+#endif
+#define FU_CFG_DEFAULT 3
 #define FU_DWPM 4
 #define FU_DWKB 6
 
@@ -1596,6 +1681,18 @@ extern "C" int dpvo_update_fused_pack(const void* W, int64_t ldw, int K, int k_v
                      chained ? 1 : 0, (_Float16*)out);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
+}
+
+// Tiling of the seven-launch path.  bit 0: the three chain kernels (c1, c2 + f|g, h + f|g), bit 1: the correlation kernel (K1)
+// run 64-row tiles with TWO workgroups per CU (256 registers per wave, nothing requested early: the neighbour workgroup covers
+// the round trips) instead of 96-row tiles with one (512 registers, everything prefetched).  K7 always runs 96 x 1: its phases
+// between the GEMMs are VALU work, which a second workgroup on the same SIMDs does not hide (measured: +40 us).
+// tiling < 0: query; default 3, or DPVO_FU_CFG from the environment.  Results are bit-identical across tilings.
+extern "C" int dpvo_update_fused_tiling(int tiling) {
+  static int cfg = -1;
+  if (cfg < 0) { const char* e = getenv("DPVO_FU_CFG"); cfg = e ? (atoi(e) & 3) : FU_CFG_DEFAULT; }
+  if (tiling >= 0) cfg = tiling & 3;
+  return cfg;
 }
 
 extern "C" size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups) {
@@ -1619,6 +1716,8 @@ extern "C" int dpvo_update_forward_fused(const dpvo_update_fused_params_t* p, co
   for (int i = 0; i < DPVO_UF_NLIN; ++i)
     if (!p->w[i] || !p->b[i]) return DPVO_E_INVALID;
   constexpr int RT = FU_RT, DW = FU_DW;
+  constexpr int RT2 = 2, DW2 = FU_DW2, OCC2 = FU_OCC2;  // several workgroups per CU, 64-row tiles
+  const int cfg = dpvo_update_fused_tiling(-1);
   const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
   Ws L;
   ws_layout<RT>(E, maxg, &L);
@@ -1630,31 +1729,35 @@ extern "C" int dpvo_update_forward_fused(const dpvo_update_fused_params_t* p, co
   _Float16 *r16a = (_Float16*)(wsb + L.r16a), *r16b = (_Float16*)(wsb + L.r16b), *fg = (_Float16*)(wsb + L.fg),
            *y = (_Float16*)(wsb + L.y);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t tiles = cdiv64(E, 32 * RT);
+  const int64_t tiles = cdiv64(E, 32 * RT), tiles2 = cdiv64(E, 32 * RT2);
   auto lin = [&](int i) { return Lin{p->w[i], (const _Float16*)p->b[i]}; };
   int rc;
 #define FU(call) do { rc = (call); if (rc) return rc; } while (0)
   {
     P1 a{lin(DPVO_UF_C0), lin(DPVO_UF_C2), lin(DPVO_UF_C5), p->ln_g[0], p->ln_b[0], p->ln_g[1], p->ln_b[1],
          (const _Float16*)corr, ld_corr, net, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E};
-    FU(launch(k1_corr_norm<RT, DW>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 2) FU(launch(k1_corr_norm<RT2, DW2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    else FU(launch(k1_corr_norm<RT, DW>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C1_0), lin(DPVO_UF_C1_2), Lin{nullptr, nullptr}, Lin{nullptr, nullptr}, r16a, plan + PL.ix, img, r16b,
          nullptr, E};
-    FU(launch(k_chain<RT, DW, MODE_C1>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_C1, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    else FU(launch(k_chain<RT, DW, MODE_C1>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C2N_0), lin(DPVO_UF_C2N_2), lin(DPVO_UF_AKK_F), lin(DPVO_UF_AKK_G), r16b, plan + PL.jx, img, nullptr, fg,
          E};
-    FU(launch(k_chain<RT, DW, MODE_C2>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_C2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    else FU(launch(k_chain<RT, DW, MODE_C2>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   int64_t ngk = n_patches_ub < 1 ? 1 : (n_patches_ub > E ? E : n_patches_ub);
   int64_t ngp = n_pairs_ub < 1 ? 1 : (n_pairs_ub > E ? E : n_pairs_ub);
   FU(dpvo_softagg(fg, 768, plan + PL.perm_k, plan + PL.patch_off, plan + PL.counts + 0, ngk, y, 384, stream));
   {
     P2 a{Lin{nullptr, nullptr}, lin(DPVO_UF_AKK_H), lin(DPVO_UF_AIJ_F), lin(DPVO_UF_AIJ_G), y, plan + PL.ku, img, nullptr, fg, E};
-    FU(launch(k_chain<RT, DW, MODE_H>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_H, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    else FU(launch(k_chain<RT, DW, MODE_H>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   FU(dpvo_softagg(fg, 768, plan + PL.perm_p, plan + PL.pair_off, plan + PL.counts + 1, ngp, y, 384, stream));
   {

@@ -27,6 +27,10 @@ from .utils import Timer, flatmeshgrid
 autocast = torch.autocast
 _CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0")))
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
+# The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
+# DPVO_PLAN_ASYNC (default: on whenever the encoders are overlapped too) its four small kernels + memsets are built on a third
+# stream beside the correlation kernel instead of in front of it (they were ~55 us of a host-paced, mostly idle GPU).
+_PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '')
 
 
 class DPVO:
@@ -111,6 +115,11 @@ class DPVO:
         self.pyramid = (self.fmap1_, self.fmap2_)
 
         self._plan = None          # GraphPlan of the active edge list (rebuilt when edges change)
+        self._plan_stream = None   # third stream for the asynchronous plan build + its two events (reused every frame)
+        self._plan_ev = None
+        self._edges_ev = None
+        self._plan_ready = None    # set while a plan built on the side stream has not been ordered before the main stream yet
+        self.plan_async = (overlap_encoders if _PLAN_ASYNC == '' else bool(int(_PLAN_ASYNC))) and torch.device(device).type == "cuda"
         self._imap_full = None
         self._corr_buf = None
 
@@ -425,7 +434,15 @@ class DPVO:
                   eff_impl=True)
         self.ran_global_ba[self.n] = True
 
-    def plan(self):
+    def plan_sync(self):
+        """order the main stream behind a plan that was built on the side stream (no-op otherwise)"""
+        if self._plan_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._plan_ready)
+            self._plan_ready = None
+
+    def plan(self, edges_ready=None):
+        """`edges_ready`: an event recorded on the current stream behind the last writer of the edge arrays -> build the plan on
+        the side stream behind that event only (the caller runs plan_sync() before the first reader on the main stream)."""
         if self._plan is None or self._plan.E != self.pg.ii.numel():
             ub_p = ub_g = window = None
             if not self.cfg.LOOP_CLOSURE and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
@@ -438,15 +455,39 @@ class DPVO:
                 # counting-sort plan build (falls back to the radix build by itself when the window is too wide for it)
                 flo = max(0, self.n - (self.cfg.REMOVAL_WINDOW + self.cfg.PATCH_LIFETIME + 3))
                 window = (flo, self.n - flo, flo * self.M, (self.n - flo) * self.M)
-            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
-                                   n_frames=self.N, n_patch_ids=self.N * self.M, window=window)
+            build = lambda: GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
+                                      n_frames=self.N, n_patch_ids=self.N * self.M, window=window)
+            if edges_ready is None or ub_p is None:       # (an exact plan reads its counts back: nothing to overlap)
+                self.plan_sync()
+                self._plan = build()
+            else:
+                if self._plan_stream is None:
+                    self._plan_stream = torch.cuda.Stream(device=self.device, priority=-1)   # small kernels beside a chip-filling one
+                    self._plan_ev = torch.cuda.Event()
+                ps, main = self._plan_stream, torch.cuda.current_stream(self.device)
+                ps.wait_event(edges_ready)
+                with torch.cuda.stream(ps):
+                    self._plan = build()
+                    self._plan_ev.record(ps)
+                self._plan.buf.record_stream(main)        # allocated under the side stream, read by the main one
+                self._plan_ready = self._plan_ev
         return self._plan
 
     def update(self):
         with Timer("other", enabled=self.enable_timing):
-            plan = self.plan()
-            coords = self.reproject()
-            corr = self.corr(coords)
+            if self.plan_async and self._plan is None:
+                if self._edges_ev is None:
+                    self._edges_ev = torch.cuda.Event()
+                self._edges_ev.record()                 # behind the edge removal / append of this frame
+                coords = self.reproject()
+                corr = self.corr(coords)
+                plan = self.plan(edges_ready=self._edges_ev)
+                self.plan_sync()
+            else:
+                self.plan_sync()
+                plan = self.plan()
+                coords = self.reproject()
+                corr = self.corr(coords)
             netbuf = self.pg.edges.view("net")          # updated in place (the reference reassigns pg.net)
             # target = coords[..., P//2, P//2] + delta.float(); pg.target / pg.weight = ...  (dpvo.py:339-343): written by
             # the heads kernel straight into the edge store

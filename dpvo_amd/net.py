@@ -29,7 +29,8 @@ EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 # launch-by-launch composite of update.hip; both stay tested against the oracle)
 FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
 AUTOTUNE = bool(int(__import__("os").environ.get("DPVO_UPDATE_AUTOTUNE", "1")))    # fused vs launch-by-launch by measurement
-_AUTO_CHOICE = {}                                                                     # device index -> (fused?, {True: ms, False: ms})
+_AUTO_DEFAULT = {}                                                                    # device index -> the library's tiling before any tuning
+_AUTO_CHOICE = {}                                                                     # device index -> (fused?, {candidate: ms}, E it was measured at)
 PM_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_PM", "0")))      # patch-major (4 launches): opt-in, see DESIGN.md 3.4
 
 
@@ -292,12 +293,21 @@ class Update(nn.Module):
         if not AUTOTUNE or E < 16384:
             return True
         key = (dev.index, )
-        if key not in _AUTO_CHOICE:
+        # (measured again once the edge list has grown by half: which tiling wins depends on how E fills the CUs)
+        if key not in _AUTO_CHOICE or E > 1.5 * _AUTO_CHOICE[key][2]:
             scratch = dict(out=torch.empty(E, DIM, dtype=torch.float32, device=dev),
                            target_out=torch.empty(E, 2, device=dev) if coords is not None else None,
                            weight_out=torch.empty(E, 2, device=dev))
             times = {}
-            for fz in (True, False):
+            if key not in _AUTO_CHOICE:
+                _AUTO_DEFAULT[key] = L.lib().dpvo_update_fused_tiling(-1)
+            default_tiling = _AUTO_DEFAULT[key]
+            cands = [("fused", True, default_tiling), ("launch_by_launch", False, None)]
+            if default_tiling != 0:
+                cands.insert(1, ("fused_96x1", True, 0))          # one workgroup per CU everywhere (the round-2a kernels)
+            for name, fz, tiling in cands:
+                if tiling is not None:
+                    L.lib().dpvo_update_fused_tiling(tiling)
                 for rep in range(3):
                     if rep == 1:
                         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -306,8 +316,10 @@ class Update(nn.Module):
                                       scratch["target_out"], scratch["weight_out"], True, fz, None, E, dev, P)
                 e1.record()
                 e1.synchronize()
-                times[fz] = e0.elapsed_time(e1) / 2
-            _AUTO_CHOICE[key] = (times[True] <= times[False], times)
+                times[name] = e0.elapsed_time(e1) / 2
+            best = min(times, key=times.get)
+            L.lib().dpvo_update_fused_tiling(0 if best == "fused_96x1" else default_tiling)
+            _AUTO_CHOICE[key] = (best != "launch_by_launch", times, E)
         return _AUTO_CHOICE[key][0]
 
     def forward_impl(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out, composite,

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from dpvo_amd import _lib as L
 from dpvo_amd import net as N
 from dpvo_amd.graph import GraphPlan
 from tests import helpers as H
@@ -243,6 +244,37 @@ def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames, flavour):
     assert dx.max().item() < 1e-2 and (dx ** 2).mean().sqrt().item() < 5e-4
     assert (da - db).abs().max().item() < 1e-2 and (wa - wb).abs().max().item() < 4e-3
     assert torch.equal(wb[0], gb) and torch.equal(tb, coords[0, :, :, 1, 1] + db[0])
+
+
+@pytest.mark.parametrize("E_frames", [14, 40])
+def test_fused_tilings_are_bit_identical(dev, E_frames):
+    """dpvo_update_fused_tiling: 64-row tiles with two workgroups per CU vs 96-row tiles with one, per kernel group -- the
+    arithmetic per edge row is the same, so every output must be bit-identical across the four settings."""
+    from dpvo_amd import synthetic as S
+    from dpvo_amd.graph import GraphPlan
+    torch.manual_seed(11)
+    upd = N.Update(3).to(dev)
+    ii, jj, kk = (t.to(dev) for t in S.replay_graph(E_frames))
+    E = ii.numel()
+    g = torch.Generator().manual_seed(6)
+    net = torch.randn(E, 384, generator=g).to(dev)
+    imap = torch.randn(3456, 384, generator=g).half().to(dev)
+    corr = torch.zeros(E, 896, dtype=torch.float16, device=dev)
+    corr[:, :882] = torch.randn(E, 882, generator=g).half().to(dev)
+    plan = GraphPlan(ii, jj, kk)
+    before = L.lib().dpvo_update_fused_tiling(-1)
+    try:
+        res = []
+        for tiling in (0, 1, 2, 3):
+            assert L.lib().dpvo_update_fused_tiling(tiling) == tiling
+            x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
+                               corr_is_padded=True, fused=True)
+            res.append((x.clone(), d.clone(), w.clone()))
+        for r in res[1:]:
+            for a, b in zip(res[0], r):
+                assert torch.equal(a, b)
+    finally:
+        L.lib().dpvo_update_fused_tiling(before)
 
 
 def test_update_full_size_vs_oracle(oracle, dev):

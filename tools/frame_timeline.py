@@ -1,0 +1,13 @@
+#!/usr/bin/env python
+"""One steady-state frame of a rocprofv3 kernel-trace csv as a timeline: start / end (us from the frame's first kernel), queue, kernel.
+    python tools/frame_timeline.py kernel_trace.csv [frames_from_the_end=3]"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+idx = [i for i, r in enumerate(rows) if 'gather_edges' in r['Kernel_Name']]
+a, b = idx[-back - 1], idx[-back]
+t0 = int(rows[a]['Start_Timestamp'])
+for r in rows[a:b]:
+    s, e = (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - t0) / 1e3
+    print(f"{s:9.1f} {e:9.1f} {e - s:7.1f}  q{r['Queue_Id']:>2s}  {r['Kernel_Name'][:70]}")

@@ -51,9 +51,9 @@ wrap(slam, "corr", before="corr_begin", after="corr_end")
 wrap(slam.network.update, "forward", after="update_end")
 wrap(slam, "_keyframe_begin", before="ba_end", after="frame_end")
 with torch.no_grad():
-    for t in range(60): slam(float(t), frames[t % 64], intr)
+    for t in range(60): slam(float(t), frames[t % 64], intr, image_ready=False)
     marks.clear()
-    for t in range(60, 160): slam(float(t), frames[t % 64], intr)
+    for t in range(60, 160): slam(float(t), frames[t % 64], intr, image_ready=False)
     slam.flush()
 torch.cuda.synchronize()
 import collections
