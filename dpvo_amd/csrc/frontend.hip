@@ -97,6 +97,7 @@ __device__ __forceinline__ void append_edges_body(int64_t* __restrict__ ii, int6
     else { const int64_t q = e - nf; k = (int64_t)M * max(n - 1, 0) + q / nj; j = jlo + q % nj; }
     kk[E0 + e] = k; jj[E0 + e] = j; ii[E0 + e] = ix[k];
   }
+  if (!net) return;               // (hidden-state rows handled by the consumer: dpvo_update_forward_fused_rows reads new edges as zeros)
   const int64_t nn = total * (D / 4);
   f4* np = reinterpret_cast<f4*>(net + E0 * D);
   for (int64_t q = gt; q < nn; q += nblk * blockDim.x) np[q] = (f4)0.f;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void gather_edges_body(const GatherArgs& G, const int
   const int64_t n = G.n;
   for (int64_t t = gt; t < n; t += gs) {
     const int64_t s = idx[t];
-    G.oii[t] = ii[s]; G.ojj[t] = jj[s]; G.okk[t] = kk[s];
+    if (G.oii) { G.oii[t] = ii[s]; G.ojj[t] = jj[s]; G.okk[t] = kk[s]; }
     if (G.otarget) { G.otarget[2 * t] = target[2 * s]; G.otarget[2 * t + 1] = target[2 * s + 1]; }
     if (G.oweight) { G.oweight[2 * t] = weight[2 * s]; G.oweight[2 * t + 1] = weight[2 * s + 1]; }
   }
@@ -414,7 +415,7 @@ extern "C" int dpvo_append_edges(int64_t* ii, int64_t* jj, int64_t* kk, float* n
   const int64_t total = nf + (int64_t)M * (n - jlo);
   if (n_new) *n_new = total;
   if (total == 0) return DPVO_OK;
-  if (!ii || !jj || !kk || !net || !ix) return DPVO_E_INVALID;
+  if (!ii || !jj || !kk || !ix) return DPVO_E_INVALID;       // (net == NULL: the caller treats the new state rows as zeros itself)
   hipLaunchKernelGGL(append_edges_kernel, dim3(grid_for(total * (D / 4), 2048)), dim3(256), 0, (hipStream_t)stream, ii, jj,
                      kk, net, ix, E0, n, M, r, D);
   DPVO_LAUNCH_CHECK();
@@ -426,7 +427,9 @@ extern "C" int dpvo_gather_edges(const int64_t* idx, int64_t n, const int64_t* i
                                  int64_t* okk, float* onet, float* otarget, float* oweight, int D, void* stream) {
   if (n < 0 || D <= 0 || (D % 4)) return DPVO_E_INVALID;
   if (n == 0) return DPVO_OK;
-  if (!idx || !ii || !jj || !kk || !oii || !ojj || !okk) return DPVO_E_INVALID;
+  if (!idx || !ii || !jj || !kk) return DPVO_E_INVALID;
+  // (oii = ojj = okk = NULL with onet set: the hidden-state rows only -- a deferred compaction applied late)
+  if ((!oii || !ojj || !okk) && (oii || ojj || okk || !onet || !net)) return DPVO_E_INVALID;
   const GatherArgs A = {idx, n, oii, ojj, okk, onet, otarget, oweight};
   const unsigned g = grid_for(onet ? n * (D / 4) : n, 2048);
   hipLaunchKernelGGL(gather_edges_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, A, A, (int)g, ii, jj, kk, net, target, weight, D);
@@ -475,7 +478,7 @@ extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void
 
 extern "C" int dpvo_frame_state(dpvo_frame_state_t* p, void* stream) {
   if (!p) return DPVO_E_INVALID;
-  const bool fused = p->poses && p->patches_all && p->fmap2_slot && p->ii && p->jj && p->kk && p->net && p->ix && p->fmap && p->imap &&
+  const bool fused = p->poses && p->patches_all && p->fmap2_slot && p->ii && p->jj && p->kk && p->ix && p->fmap && p->imap &&
                      p->img_u8 && p->gmap_slot && p->imap_slot && p->patches_slot && p->colors_slot && (p->coords || (p->xs && p->ys)) &&
                      (!p->intrinsics_slot || p->intrinsics) && p->P == 3 && p->M > 0 && p->mm_n >= 2 && p->md_n >= 3 &&
                      3 * p->M * 9 <= 4096 && p->h > 0 && p->w > 0 && !(p->h % 4) && !(p->w % 4) && !(p->CF % 8) && p->CI > 0 &&

@@ -449,6 +449,7 @@ struct P1 {
   const float *cln_g, *cln_b, *norm_g, *norm_b;
   const _Float16* corr; int64_t ld_corr;
   const float* net;                                   // [E,384] f32, feature order
+  const int64_t* net_rows; int64_t n_kept;            // optional: row g of the state is net[net_rows[g]] for g < n_kept, zero after
   const _Float16* inp; const int64_t* inp_rows; int64_t inp_mod;
   float* img; _Float16* rows16;                       // out
   int64_t E;
@@ -559,10 +560,12 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
       g = g < p.E ? g : p.E - 1;
       ir[r] = g;
       if (p.inp_rows) { ir[r] = p.inp_rows[g]; if (p.inp_mod > 0) ir[r] %= p.inp_mod; }
+      const int64_t gs = !p.net_rows ? g : (g < p.n_kept ? p.net_rows[g] : -1);
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nv.v[r][t][j] = *reinterpret_cast<const f4*>(p.net + g * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+        for (int j = 0; j < 4; ++j)
+          nv.v[r][t][j] = gs >= 0 ? *reinterpret_cast<const f4*>(p.net + gs * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h) : (f4)0.f;
     }
     acc_init<RT>(acc, bias);
     gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp3, al);
@@ -596,12 +599,13 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
       g = g < p.E ? g : p.E - 1;
       int64_t ir = g;
       if (p.inp_rows) { ir = p.inp_rows[g]; if (p.inp_mod > 0) ir %= p.inp_mod; }
+      const int64_t gs = !p.net_rows ? g : (g < p.n_kept ? p.net_rows[g] : -1);
       f4 nv[3][4]; h4 iv[3][4];
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          nv[t][j] = *reinterpret_cast<const f4*>(p.net + g * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+          nv[t][j] = gs >= 0 ? *reinterpret_cast<const f4*>(p.net + gs * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h) : (f4)0.f;
           iv[t][j] = *reinterpret_cast<const h4*>(p.inp + ir * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
         }
 #pragma unroll
@@ -1707,8 +1711,21 @@ extern "C" int dpvo_update_forward_fused(const dpvo_update_fused_params_t* p, co
                                          const int32_t* plan, int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords,
                                          int P, float* net_out, float* delta, float* weight, float* target, int64_t E,
                                          void* ws, size_t ws_bytes, void* stream) {
+  return dpvo_update_forward_fused_rows(p, net, nullptr, 0, inp, inp_rows, inp_mod, corr, ld_corr, plan, n_patches_ub, n_pairs_ub,
+                                        coords, P, net_out, delta, weight, target, E, ws, ws_bytes, stream);
+}
+
+// The same with the edge compaction of remove_factors (dpvo.py:223-238) folded into the first kernel: the hidden state of edge g
+// is net[net_rows[g]] for g < n_kept (the `keep` list of the removal, ascending) and zero for the edges appended after it.
+// net_out may alias net: the first kernel has read every row before the last one writes any.
+extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* p, const float* net, const int64_t* net_rows,
+                                              int64_t n_kept, const void* inp, const int64_t* inp_rows, int64_t inp_mod,
+                                              const void* corr, int64_t ld_corr, const int32_t* plan, int64_t n_patches_ub,
+                                              int64_t n_pairs_ub, const float* coords, int P, float* net_out, float* delta,
+                                              float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, void* stream) {
   using namespace fu;
   if (E < 0 || !p) return DPVO_E_INVALID;
+  if (net_rows && (n_kept < 0 || n_kept > E)) return DPVO_E_INVALID;
   if (E == 0) return DPVO_OK;
   if (!net || !inp || !corr || !plan || !net_out || !delta || !weight || !ws) return DPVO_E_INVALID;
   if (target && (!coords || P <= 0)) return DPVO_E_INVALID;
@@ -1735,7 +1752,7 @@ extern "C" int dpvo_update_forward_fused(const dpvo_update_fused_params_t* p, co
 #define FU(call) do { rc = (call); if (rc) return rc; } while (0)
   {
     P1 a{lin(DPVO_UF_C0), lin(DPVO_UF_C2), lin(DPVO_UF_C5), p->ln_g[0], p->ln_b[0], p->ln_g[1], p->ln_b[1],
-         (const _Float16*)corr, ld_corr, net, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E};
+         (const _Float16*)corr, ld_corr, net, net_rows, n_kept, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E};
     if (cfg & 2) FU(launch(k1_corr_norm<RT2, DW2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
     else FU(launch(k1_corr_norm<RT, DW>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }

@@ -26,6 +26,9 @@ from .utils import Timer, flatmeshgrid
 
 autocast = torch.autocast
 _CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0")))
+# remove_factors leaves the hidden-state rows where they are and hands the keep list to the next update operator call
+# (95 % of the bytes a removal moves; EdgeStore.keep(defer_net=True)); DPVO_DEFER_NET=0: compact immediately
+_DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '1')))
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 # The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
 # DPVO_PLAN_ASYNC (default: on whenever the encoders are overlapped too) its four small kernels + memsets are built on a third
@@ -301,9 +304,9 @@ class DPVO:
             rem = m.nonzero().squeeze(1) if store else None
             keep, keep_h = (~m).nonzero().squeeze(1), None
         if store and rem is not None and rem.numel():
-            es.keep(keep, keep_h, also=(rem, self.pg.edges_inac))      # both gathers in one launch
+            es.keep(keep, keep_h, also=(rem, self.pg.edges_inac), defer_net=_DEFER_NET)      # both gathers in one launch
         else:
-            es.keep(keep, keep_h)
+            es.keep(keep, keep_h, defer_net=_DEFER_NET)
         self._plan = None
 
     def _removal_mask(self, h):
@@ -488,7 +491,10 @@ class DPVO:
                 plan = self.plan()
                 coords = self.reproject()
                 corr = self.corr(coords)
-            netbuf = self.pg.edges.view("net")          # updated in place (the reference reassigns pg.net)
+            # the hidden state, updated in place (the reference reassigns pg.net); a removal of this frame may still be pending
+            # on it (EdgeStore.keep(defer_net=True)): the update operator's first kernel gathers the rows, its last one
+            # writes them back in compact order
+            netbuf, net_rows, n_kept = self.pg.edges.net_deferred()
             # target = coords[..., P//2, P//2] + delta.float(); pg.target / pg.weight = ...  (dpvo.py:339-343): written by
             # the heads kernel straight into the edge store
             es = self.pg.edges
@@ -496,7 +502,9 @@ class DPVO:
             self.network.update(
                 netbuf[None], self.imap, corr, None, self.pg.ii, self.pg.jj, self.pg.kk, plan=plan,
                 inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896), out=netbuf,
-                coords=coords.contiguous(), target_out=target, weight_out=weight)
+                coords=coords.contiguous(), target_out=target, weight_out=weight,
+                net_rows=None if net_rows is None else (net_rows, n_kept))
+            self.pg.edges.net_written()
             lmbda = 1e-4
             target, weight = target[None], weight[None]
 
@@ -664,7 +672,9 @@ class DPVO:
                 fs.poses, fs.mm_n, fs.mm_scale = dp(self.pg.poses_), n, self.cfg.MOTION_DAMPING * fac
                 fs.patches_all, fs.md_n = dp(self.pg.patches_), n
                 fs.fmap2_slot = rp(self._fmap2_cl, n % self.mem)
-                fs.ii, fs.jj, fs.kk, fs.net, fs.ix = dp(es.a["ii"]), dp(es.a["jj"]), dp(es.a["kk"]), dp(es.a["net"]), dp(self.ix)
+                # (no in-place zeroing of the new state rows while a deferred compaction is pending: live rows may still sit there)
+                fs.ii, fs.jj, fs.kk, fs.ix = dp(es.a["ii"]), dp(es.a["jj"]), dp(es.a["kk"]), dp(self.ix)
+                fs.net = dp(es.a["net"]) if es.net_pending is None else None
                 fs.frame_next, fs.m_next, fs.E0, fs.n_new = n + 1, self.m + self.M, es.E, 0
                 fs.res = self.RES
                 fs.M, fs.h, fs.w, fs.H, fs.W, fs.CF, fs.CI, fs.P = self.M, hh, ww, H, W, 128, self.DIM, self.P

@@ -233,12 +233,16 @@ class Update(nn.Module):
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
-                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None, patch_edges_ub=None):
+                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None, patch_edges_ub=None,
+                net_rows=None):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
         `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
         `coords` [1,E,2,P,P] + `target_out` / `weight_out` [E,2] f32 (optional): the heads kernel also writes
         target = coords[..., P//2, P//2] + delta (dpvo.py:340) and the weights straight into the caller's edge arrays.
+        `net_rows` = (int64 device tensor, n_kept): the state of edge g is net[net_rows[g]] for g < n_kept and zero after (a
+        removal whose compaction of `net` was deferred, EdgeStore.keep(defer_net=True)); the seven-launch kernels gather it in
+        their first kernel, every other path gathers it here first.
         Returns net f32 [1,E,384], (delta f32 [1,E,2], weight f32 [1,E,2], None)."""
         P = self._packed or self.pack()
         L.require_cuda(net, inp, corr, ii, jj, kk)
@@ -269,17 +273,26 @@ class Update(nn.Module):
 
         if fused is None and composite and net2.dtype == torch.float32:
             fused = self._choose_path(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, coords, E, dev, P)
+        if net_rows is not None:
+            seven = composite and net2.dtype == torch.float32 and (fused is True or (fused is None and FUSED_DEFAULT)) and not PM_DEFAULT
+            if not seven:
+                rows, n_kept = net_rows
+                tmp = workspace.get(E * DIM * 4, dev, "net_gather")[:E * DIM * 4].view(torch.float32).view(E, DIM)
+                if n_kept:
+                    torch.index_select(net2, 0, rows[:n_kept], out=tmp[:n_kept])
+                tmp[n_kept:].zero_()
+                net2, net_rows = tmp, None
         prof = PROFILE
         if prof is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
             res = self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
-                                    composite, fused, patch_edges_ub, E, dev, P)
+                                    composite, fused, patch_edges_ub, E, dev, P, net_rows)
             ev1.record()
             prof.append((ev0, ev1, E))
             return res
         return self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
-                                 composite, fused, patch_edges_ub, E, dev, P)
+                                 composite, fused, patch_edges_ub, E, dev, P, net_rows)
 
     def _choose_path(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, coords, E, dev, P):
         """Which kernels run Update.forward when the caller does not say: the row-tile-resident ones (update_fused.hip) unless
@@ -323,7 +336,7 @@ class Update(nn.Module):
         return _AUTO_CHOICE[key][0]
 
     def forward_impl(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out, composite,
-                     fused, patch_edges_ub, E, dev, P):
+                     fused, patch_edges_ub, E, dev, P, net_rows=None):
         if composite and net2.dtype == torch.float32:
             # the whole operator as ONE library call (dpvo_update_forward issues the same launches as the code below;
             # `composite=False` keeps the launch-by-launch path for tests)
@@ -359,12 +372,13 @@ class Update(nn.Module):
                 # seven launches of row-tile-resident kernels (update_fused.hip)
                 nbytes = L.lib().dpvo_update_fused_workspace_bytes(L.i64(E), L.i64(maxg))
                 ws = workspace.get(nbytes, dev, "update_fused")
-                L.check(L.lib().dpvo_update_forward_fused(
-                    ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
-                    L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
+                rows, n_kept = net_rows if net_rows is not None else (None, 0)
+                L.check(L.lib().dpvo_update_forward_fused_rows(
+                    ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(rows), L.i64(n_kept), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod),
+                    L.ptr(corr2), L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
                     L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
                     L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
-                    ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_update_forward_fused")
+                    ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_update_forward_fused_rows")
                 return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
             nbytes = L.lib().dpvo_update_workspace_bytes(L.i64(E), L.i64(maxg))
             ws = workspace.get(nbytes, dev, "update")

@@ -37,6 +37,11 @@ class EdgeStore:
         self._stage_flip = 0
         self._staged = {}           # device staging buffer -> its copy event, between stage_indices and the gather that reads it
         self._gathered = None       # recorded on the compute stream after a gather that read staged indices
+        # Deferred compaction of the hidden state (`net`, 1.5 KB per edge = 95 % of what a removal moves): keep(defer_net=True)
+        # compacts everything else and only REMEMBERS the keep list; the update operator's first kernel then reads row g of the
+        # state from net[keep[g]] (zeros for the edges appended since) and its last kernel writes the rows back compact
+        # (dpvo_update_forward_fused_rows).  Any other reader goes through view("net"), which materialises first.
+        self.net_pending = None     # (keep indices [n_kept] int64 on the device, n_kept) or None
 
     def _new(self, cap):
         d = {k: torch.empty(cap, dtype=torch.long, device=self.dev) for k in ("ii", "jj", "kk")}
@@ -53,6 +58,7 @@ class EdgeStore:
     def reserve(self, n):
         if self.E + n <= self.cap:
             return
+        self.materialize_net()
         old, E = self.a, self.E
         self._alloc(max(2 * self.cap, self.E + n))
         for k, v in old.items():
@@ -138,7 +144,37 @@ class EdgeStore:
         return st["dev"][:n]
 
     def view(self, name):
+        if name == "net" and self.net_pending is not None:
+            self.materialize_net()
         return self.a[name][:self.E]
+
+    def net_deferred(self):
+        """(state buffer [E, D], keep indices or None, n_kept) WITHOUT materialising: for dpvo_update_forward_fused_rows"""
+        rows, n_kept = self.net_pending if self.net_pending is not None else (None, 0)
+        return self.a["net"][:self.E], rows, n_kept
+
+    def net_written(self):
+        """the update operator has rewritten every state row in compact order"""
+        if self.net_pending is not None:
+            self.net_pending = None
+            self._mark_gathered()           # (its first kernel read the staged keep list)
+
+    def materialize_net(self):
+        """apply a deferred compaction of the state now (readers other than the fused update operator)"""
+        if self.net_pending is None:
+            return
+        rows, n_kept = self.net_pending
+        self.net_pending = None
+        vp = ctypes.c_void_p
+        if n_kept:
+            L.check(L.lib().dpvo_gather_edges(
+                vp(rows.data_ptr()), ctypes.c_int64(n_kept), vp(self.a["ii"].data_ptr()), vp(self.a["jj"].data_ptr()),
+                vp(self.a["kk"].data_ptr()), vp(self.a["net"].data_ptr()), vp(0), vp(0), vp(0), vp(0), vp(0),
+                vp(self.b["net"].data_ptr()), vp(0), vp(0), ctypes.c_int(self.D), L.stream()), "dpvo_gather_edges")
+        self.a["net"], self.b["net"] = self.b["net"], self.a["net"]
+        if self.E > n_kept:
+            self.a["net"][n_kept:self.E].zero_()
+        self._mark_gathered()
 
     def assign(self, name, value):
         value = value.reshape((-1,) + tuple(self.a[name].shape[1:]))
@@ -165,8 +201,9 @@ class EdgeStore:
         total = self.frame_edge_count(n, M, r)
         self.reserve(total)
         cnt = ctypes.c_int64(0)
+        # (with a deferred compaction pending the new rows must not be zeroed in place: live rows may still sit there)
         L.check(L.lib().dpvo_append_edges(L.ptr(self.a["ii"]), L.ptr(self.a["jj"]), L.ptr(self.a["kk"]),
-                                          L.ptr(self.a["net"]), L.ptr(ix), L.i64(self.E), L.i32(n), L.i32(M), L.i32(r),
+                                          L.ptr(self.a["net"] if self.net_pending is None else None), L.ptr(ix), L.i64(self.E), L.i32(n), L.i32(M), L.i32(r),
                                           L.i32(self.D), ctypes.byref(cnt), L.stream()), "dpvo_append_edges")
         assert cnt.value == total
         self.appended_frame(n, M, r, total)
@@ -174,6 +211,8 @@ class EdgeStore:
     def append(self, ii, jj, kk, net=None, target=None, weight=None):
         n = ii.numel()
         self.reserve(n)
+        if self.with_state and self.net_pending is not None:
+            self.materialize_net()
         E = self.E
         self.a["ii"][E:E + n] = ii; self.a["jj"][E:E + n] = jj; self.a["kk"][E:E + n] = kk
         if self.with_state:
@@ -190,13 +229,13 @@ class EdgeStore:
             self._log.append(("edges",) + tuple(v.cpu().numpy().astype(np.int32) for v in (ii, jj, kk)))
         self.E += n
 
-    def gather_into(self, idx, dst, dst_off):
+    def gather_into(self, idx, dst, dst_off, skip_net=False):
         """dst arrays [dst_off : dst_off+len(idx)] = self arrays[idx] (one kernel)"""
         n = idx.numel()
         copied = self._wait_staged(idx)
         # (raw pointer arithmetic instead of tensor slices: this call sits in the host-paced start of a frame)
         vp = ctypes.c_void_p
-        src, has_net = self.a, dst.get("net") is not None
+        src, has_net = self.a, dst.get("net") is not None and not skip_net
         o = lambda t, row_bytes: vp(t.data_ptr() + dst_off * row_bytes)
         L.check(L.lib().dpvo_gather_edges(
             vp(idx.data_ptr()), ctypes.c_int64(n), vp(src["ii"].data_ptr()), vp(src["jj"].data_ptr()), vp(src["kk"].data_ptr()),
@@ -220,12 +259,15 @@ class EdgeStore:
             self._gathered = torch.cuda.Event()
         self._gathered.record()
 
-    def keep(self, idx, idx_host=None, also=None):
+    def keep(self, idx, idx_host=None, also=None, defer_net=False):
         """compact to the edges listed in idx (sorted ascending), ping-pong buffers.  idx_host: the same indices as a numpy
         array, which keeps the host mirror alive (applied lazily).  also = (idx2, dst_store): additionally append the edges
         idx2 to another store (the inactive edges of remove_factors) -- both gathers in one launch."""
+        defer_net = defer_net and self.with_state
+        if self.net_pending is not None:
+            self.materialize_net()              # (a second removal before the update operator ran: apply the first one now)
         if also is None:
-            self.gather_into(idx, self.b, 0)
+            self.gather_into(idx, self.b, 0, skip_net=defer_net)
         else:
             idx2, dst = also
             n2 = idx2.numel()
@@ -238,13 +280,16 @@ class EdgeStore:
                 vp(idx2.data_ptr()), ctypes.c_int64(n2), o(dst.a["ii"], dst.E, 8), o(dst.a["jj"], dst.E, 8), o(dst.a["kk"], dst.E, 8),
                 o(dst.a.get("net"), dst.E, 4 * self.D), o(dst.a["target"], dst.E, 8), o(dst.a["weight"], dst.E, 8),
                 vp(idx.data_ptr()), ctypes.c_int64(idx.numel()), o(self.b["ii"], 0, 8), o(self.b["jj"], 0, 8), o(self.b["kk"], 0, 8),
-                o(self.b.get("net"), 0, 4 * self.D), o(self.b["target"], 0, 8), o(self.b["weight"], 0, 8),
+                o(None if defer_net else self.b.get("net"), 0, 4 * self.D), o(self.b["target"], 0, 8), o(self.b["weight"], 0, 8),
                 vp(src["ii"].data_ptr()), vp(src["jj"].data_ptr()), vp(src["kk"].data_ptr()),
                 vp(src["net"].data_ptr()) if "net" in src else vp(0), vp(src["target"].data_ptr()), vp(src["weight"].data_ptr()),
                 ctypes.c_int(self.D), L.stream()), "dpvo_gather_edges2")
             self._mark_gathered()
             dst.E += n2
         self.a, self.b = self.b, self.a
+        if defer_net:
+            self.a["net"], self.b["net"] = self.b["net"], self.a["net"]       # the state stays where it is ...
+            self.net_pending = (idx, idx.numel())                            # ... until the update operator gathers it
         if self._h is not None:
             if idx_host is None:
                 self.invalidate_host()

@@ -256,7 +256,7 @@ int dpvo_patch_colors(const void* img_u8, const float* coords, void* out_u8, int
 /* ring-buffer store (dpvo.py:437-438): fmap [C,h,w] -> channels-last slot [h,w,C] + 4x4 avg-pooled [h/4,w/4,C]. */
 int dpvo_store_features(const void* fmap, void* f1_slot, void* f2_slot, int dtype, int C, int h, int w, void* stream);
 /* append_factors(edges_forw) + append_factors(edges_back) (dpvo.py:215-221,362-375,458-459) for frame count n:
- * writes kk, jj, ii = ix[kk] at [E0, E0+n_new) and zeroes the new rows of net [.,D]; *n_new (host) = count. */
+ * writes kk, jj, ii = ix[kk] at [E0, E0+n_new) and zeroes the new rows of net [.,D] (net may be NULL: skipped); *n_new (host) = count. */
 int dpvo_append_edges(int64_t* ii, int64_t* jj, int64_t* kk, float* net, const int64_t* ix, int64_t E0, int n, int M,
                       int r, int D, int64_t* n_new, void* stream);
 /* remove_factors compaction (dpvo.py:223-238): out[t] = in[idx[t]] for ii,jj,kk and (optional) net,target,weight. */
@@ -363,6 +363,14 @@ typedef struct {
 } dpvo_update_fused_params_t;
 size_t dpvo_update_fused_pack_bytes(int K);
 int dpvo_update_fused_pack(const void* W, int64_t ldw, int K, int k_valid, int chained, void* out, void* stream);
+/* dpvo_update_forward_fused with the compaction of remove_factors (dpvo.py:223-238, `self.pg.net = self.pg.net[:,~m]`) folded
+ * into its first kernel: state row g = net[net_rows[g]] for g < n_kept (ascending `keep` list), zero for g >= n_kept (the edges
+ * appended since: append_factors starts them at zero, dpvo.py:219).  net_out may alias net.  net_rows == NULL: as above. */
+int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* p, const float* net, const int64_t* net_rows, int64_t n_kept,
+                                   const void* inp, const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr,
+                                   const int32_t* plan, int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P,
+                                   float* net_out, float* delta, float* weight, float* target, int64_t E, void* ws,
+                                   size_t ws_bytes, void* stream);
 size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups);
 /* Tiling of the seven-launch path (no reference counterpart: a tuning knob of this implementation).  bit 0: chain kernels,
  * bit 1: the correlation-MLP kernel use 64-row tiles with two workgroups per CU instead of 96-row tiles with one.  tiling < 0
