@@ -494,7 +494,7 @@ class DPVO:
             # the hidden state, updated in place (the reference reassigns pg.net); a removal of this frame may still be pending
             # on it (EdgeStore.keep(defer_net=True)): the update operator's first kernel gathers the rows, its last one
             # writes them back in compact order
-            netbuf, net_rows, n_kept = self.pg.edges.net_deferred()
+            netbuf, net_rows, n_kept, net_all = self.pg.edges.net_deferred()
             # target = coords[..., P//2, P//2] + delta.float(); pg.target / pg.weight = ...  (dpvo.py:339-343): written by
             # the heads kernel straight into the edge store
             es = self.pg.edges
@@ -503,7 +503,7 @@ class DPVO:
                 netbuf[None], self.imap, corr, None, self.pg.ii, self.pg.jj, self.pg.kk, plan=plan,
                 inp_rows=self.pg.kk, inp_mod=self.M * self.pmem, corr_is_padded=(corr.stride(1) == 896), out=netbuf,
                 coords=coords.contiguous(), target_out=target, weight_out=weight,
-                net_rows=None if net_rows is None else (net_rows, n_kept))
+                net_rows=None if net_rows is None else (net_rows, n_kept, net_all))
             self.pg.edges.net_written()
             lmbda = 1e-4
             target, weight = target[None], weight[None]

@@ -240,7 +240,8 @@ class Update(nn.Module):
         `out` (optional f32 [E,384] buffer, may alias `net`): receives the new hidden state (in-place update).
         `coords` [1,E,2,P,P] + `target_out` / `weight_out` [E,2] f32 (optional): the heads kernel also writes
         target = coords[..., P//2, P//2] + delta (dpvo.py:340) and the weights straight into the caller's edge arrays.
-        `net_rows` = (int64 device tensor, n_kept): the state of edge g is net[net_rows[g]] for g < n_kept and zero after (a
+        `net_rows` = (int64 device tensor, n_kept, buffer): the state of edge g is buffer[net_rows[g]] (buffer: the [capacity, 384]
+        tensor `net` is the head of) for g < n_kept and zero after (a
         removal whose compaction of `net` was deferred, EdgeStore.keep(defer_net=True)); the seven-launch kernels gather it in
         their first kernel, every other path gathers it here first.
         Returns net f32 [1,E,384], (delta f32 [1,E,2], weight f32 [1,E,2], None)."""
@@ -276,10 +277,10 @@ class Update(nn.Module):
         if net_rows is not None:
             seven = composite and net2.dtype == torch.float32 and (fused is True or (fused is None and FUSED_DEFAULT)) and not PM_DEFAULT
             if not seven:
-                rows, n_kept = net_rows
+                rows, n_kept, src = net_rows
                 tmp = workspace.get(E * DIM * 4, dev, "net_gather")[:E * DIM * 4].view(torch.float32).view(E, DIM)
                 if n_kept:
-                    torch.index_select(net2, 0, rows[:n_kept], out=tmp[:n_kept])
+                    torch.index_select(src.reshape(-1, DIM), 0, rows[:n_kept], out=tmp[:n_kept])
                 tmp[n_kept:].zero_()
                 net2, net_rows = tmp, None
         prof = PROFILE
@@ -372,7 +373,7 @@ class Update(nn.Module):
                 # seven launches of row-tile-resident kernels (update_fused.hip)
                 nbytes = L.lib().dpvo_update_fused_workspace_bytes(L.i64(E), L.i64(maxg))
                 ws = workspace.get(nbytes, dev, "update_fused")
-                rows, n_kept = net_rows if net_rows is not None else (None, 0)
+                rows, n_kept = net_rows[:2] if net_rows is not None else (None, 0)
                 L.check(L.lib().dpvo_update_forward_fused_rows(
                     ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(rows), L.i64(n_kept), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod),
                     L.ptr(corr2), L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),

@@ -149,9 +149,10 @@ class EdgeStore:
         return self.a[name][:self.E]
 
     def net_deferred(self):
-        """(state buffer [E, D], keep indices or None, n_kept) WITHOUT materialising: for dpvo_update_forward_fused_rows"""
+        """(state buffer [E, D], keep indices or None, n_kept, the whole capacity buffer the indices point into) WITHOUT
+        materialising: for dpvo_update_forward_fused_rows"""
         rows, n_kept = self.net_pending if self.net_pending is not None else (None, 0)
-        return self.a["net"][:self.E], rows, n_kept
+        return self.a["net"][:self.E], rows, n_kept, self.a["net"]
 
     def net_written(self):
         """the update operator has rewritten every state row in compact order"""

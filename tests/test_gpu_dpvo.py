@@ -98,6 +98,58 @@ def test_deferred_keyframe_is_bit_identical(dev):
     assert np.array_equal(pa, pb)
 
 
+def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
+    """remove_factors with the compaction of `net` folded into the update operator's first kernel (EdgeStore.keep(defer_net=True),
+    dpvo_update_forward_fused_rows) against compacting at once: same tracker state bit for bit, over kept and dropped keyframes
+    (a dropped keyframe removes twice in one frame: the first deferred compaction is then applied on the spot)."""
+    import dpvo_amd.dpvo as D
+    decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 24 + [(True, True), (True, False), (True, True)] + \
+                [(True, False)] * 4
+    assert D._DEFER_NET
+    a, ra, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True)
+    a.flush()
+    monkeypatch.setattr(D, "_DEFER_NET", False)
+    b, rb, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True)
+    b.flush()
+    torch.cuda.synchronize()
+    assert a.n == b.n and a.pg.edges.E == b.pg.edges.E
+    for k in ("ii", "jj", "kk"):
+        assert torch.equal(getattr(a.pg, k), getattr(b.pg, k))
+    assert torch.equal(a.pg.net, b.pg.net)                                   # (the accessor applies a pending compaction)
+    assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
+    assert torch.equal(a.pg.edges.view("target"), b.pg.edges.view("target")) and torch.equal(a.pg.edges.view("weight"), b.pg.edges.view("weight"))
+
+
+def test_edge_store_deferred_compaction(dev):
+    """EdgeStore.keep(defer_net=True): every reader of `net` other than the fused update operator sees compact rows"""
+    from dpvo_amd.patchgraph import EdgeStore
+    g = torch.Generator().manual_seed(2)
+    def fill(es, n):
+        ii = torch.randint(0, 30, (n,), generator=g).to(dev); jj = torch.randint(0, 30, (n,), generator=g).to(dev)
+        kk = torch.randint(0, 900, (n,), generator=g).to(dev)
+        es.append(ii, jj, kk, net=torch.randn(n, es.D, generator=g).to(dev), target=torch.randn(n, 2, generator=g).to(dev),
+                  weight=torch.rand(n, 2, generator=g).to(dev))
+    a, b = EdgeStore(384, dev, cap=4096), EdgeStore(384, dev, cap=4096)
+    for es in (a, b):
+        g.manual_seed(2); fill(es, 1000)
+    keep1 = torch.sort(torch.randperm(1000, generator=g)[:700]).values.to(dev)
+    a.keep(keep1, defer_net=True); b.keep(keep1)
+    assert a.net_pending is not None and a.net_pending[1] == 700
+    buf, rows, n_kept, whole = a.net_deferred()
+    assert buf.data_ptr() == whole.data_ptr() and buf.shape[0] == 700
+    assert torch.equal(whole[rows[:n_kept]], b.view("net"))                       # what the update operator's first kernel reads
+    keep2 = torch.sort(torch.randperm(700, generator=g)[:500]).values.to(dev)
+    a.keep(keep2, defer_net=True); b.keep(keep2)                                 # second removal: the first one is applied now
+    assert a.net_pending[1] == 500
+    for es in (a, b):
+        g.manual_seed(7); fill(es, 64)                                           # an append with explicit state: applied first
+    assert a.net_pending is None and a.E == b.E == 564
+    for name in ("ii", "jj", "kk", "net", "target", "weight"):
+        assert torch.equal(a.view(name), b.view(name)), name
+    a.keep(keep2, defer_net=True); b.keep(keep2)
+    assert torch.equal(a.view("net"), b.view("net")) and a.net_pending is None    # view() materialises
+
+
 def test_run_to_run_determinism(dev):
     decisions = [(True, False)] * 14
     a, _, _ = _run(dev, decisions, seed=3)
