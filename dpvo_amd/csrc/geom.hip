@@ -288,10 +288,13 @@ __global__ __launch_bounds__(256) void motionmag_plan_kernel(const float* __rest
                                                              const int32_t* __restrict__ pair_off,
                                                              const int32_t* __restrict__ pair_ij,
                                                              const int32_t* __restrict__ n_pairs, int P, int qi, int qj,
-                                                             float beta, float* __restrict__ out) {
+                                                             float beta, float* __restrict__ out,
+                                                             float* __restrict__ status) {
   __shared__ float red[4][1024];
   __shared__ int found[2];
   const int ng = *n_pairs;
+  // the plan's counters [n_patches, n_pairs, 0, ids-outside-the-window flag] ride along with the frame's only read-back
+  if (status && threadIdx.x < 4) status[threadIdx.x] = (float)n_pairs[(int)threadIdx.x - 1];
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   // both pairs located by ONE parallel scan of the pair list (a binary search is ~9 dependent global round trips per
   // pair: 12 of this kernel's 21 us); pairs are unique, so at most one thread writes each slot
@@ -393,14 +396,21 @@ extern "C" int dpvo_point_cloud(const float* poses, const float* patches, const 
 extern "C" int dpvo_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                               const int64_t* jj, const int64_t* kk, const int32_t* plan, int64_t E, int P, int64_t i,
                               int64_t j, float beta, float* out4, void* stream) {
+  return dpvo_motionmag_status(poses, patches, intrinsics, ii, jj, kk, plan, E, P, i, j, beta, out4, nullptr, stream);
+}
+
+extern "C" int dpvo_motionmag_status(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                                     const int64_t* jj, const int64_t* kk, const int32_t* plan, int64_t E, int P, int64_t i,
+                                     int64_t j, float beta, float* out4, float* status4, void* stream) {
   if (E < 0 || P <= 0 || !out4) return DPVO_E_INVALID;
+  if (status4 && !(plan && E > 0)) return DPVO_E_INVALID;
   if (E > 0 && (!poses || !patches || !intrinsics || !ii || !jj || !kk)) return DPVO_E_INVALID;
   if (plan && E > 0) {
     dpvo_plan_layout_t PL;
     dpvo_plan_layout(E, &PL);
     hipLaunchKernelGGL(motionmag_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, poses, patches, intrinsics, kk,
                        plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, plan + PL.counts + 1, P, (int)i, (int)j, beta,
-                       out4);
+                       out4, status4);
   } else
   hipLaunchKernelGGL(motionmag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, E, P, i, j, beta, out4);

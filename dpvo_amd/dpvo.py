@@ -347,7 +347,7 @@ class DPVO:
         # m = self.motionmag(i, j) + self.motionmag(j, i): one kernel + one read-back (was 2 x ~12 launches + 2 syncs);
         # the read-back goes through pinned memory + an event, so waiting for it does not wait for later launches
         if self._mm_host is None:
-            self._mm_host = [torch.empty(4, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._mm_host = [torch.empty(8, dtype=torch.float32).pin_memory() for _ in range(2)]
             self._mm_flip = 0
         host = self._mm_host[self._mm_flip]
         self._mm_flip ^= 1
@@ -376,6 +376,15 @@ class DPVO:
         es = self.pg.edges
         m_ij, m_ji = m_pending()            # the one host read-back of the frame
         m = m_ij + m_ji
+        st = getattr(m_pending, "plan_status", None)
+        if st is not None and st[3] != 0 and not getattr(self, "_plan_exact", False):
+            # the plan was built from bounds (frame / patch id windows, group counts) that this edge list violated: its groups
+            # were clamped for the frame just done.  From now on plans are built exactly (one read-back each), and say so.
+            import warnings
+            warnings.warn("dpvo_amd: an edge fell outside the window the graph plan was sized for "
+                          f"(counters {st}); switching to exact plans", RuntimeWarning)
+            self._plan_exact = True
+            self._plan = None
 
         if m / 2 < self.cfg.KEYFRAME_THRESH:
             k = self.n - self.cfg.KEYFRAME_INDEX

@@ -1,6 +1,8 @@
 """projective_ops: the reference's `dpvo.projective_ops` surface used at inference (dpvo/projective_ops.py)
 with `transform`, `flow_mag` and `point_cloud` as single fused HIP kernels (dpvo_amd/csrc/geom.hip) instead of
 ~12 lietorch + elementwise launches each."""
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -94,22 +96,31 @@ def motionmag_pair(poses, patches, intrinsics, ii, jj, kk, i, j, beta=0.5, plan=
     returns a callable that performs the read-back, so that the caller can do host work while the kernel runs."""
     pd, pt, it, P = _prep(poses, patches, intrinsics)
     E = ii.numel()
-    out = torch.empty(4, dtype=torch.float32, device=pd.device)
-    L.check(L.lib().dpvo_motionmag(L.ptr(pd), L.ptr(pt), L.ptr(it), L.ptr(ii), L.ptr(jj), L.ptr(kk),
-                                   L.ptr(plan.buf if plan is not None and plan.E == E else None), L.i64(E), L.i32(P),
-                                   L.i64(i), L.i64(j), L.f32(beta), L.ptr(out), L.stream()), "dpvo_motionmag")
+    with_plan = plan is not None and plan.E == E and E > 0
+    status = with_plan and (host_buf is None or host_buf.numel() >= 8)
+    out = torch.empty(8 if status else 4, dtype=torch.float32, device=pd.device)
+    if status:        # the plan's counters + window-violation flag come back with the same read-back (out[4:8])
+        L.check(L.lib().dpvo_motionmag_status(L.ptr(pd), L.ptr(pt), L.ptr(it), L.ptr(ii), L.ptr(jj), L.ptr(kk), L.ptr(plan.buf),
+                                              L.i64(E), L.i32(P), L.i64(i), L.i64(j), L.f32(beta), L.ptr(out),
+                                              ctypes.c_void_p(out.data_ptr() + 16), L.stream()), "dpvo_motionmag_status")
+    else:
+        L.check(L.lib().dpvo_motionmag(L.ptr(pd), L.ptr(pt), L.ptr(it), L.ptr(ii), L.ptr(jj), L.ptr(kk),
+                                       L.ptr(plan.buf if with_plan else None), L.i64(E), L.i32(P),
+                                       L.i64(i), L.i64(j), L.f32(beta), L.ptr(out), L.stream()), "dpvo_motionmag")
     ev = None
     if host_buf is not None:            # pinned host buffer: asynchronous copy + event instead of a stream-wide sync
-        host_buf.copy_(out, non_blocking=True)
+        host_buf[:out.numel()].copy_(out, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
 
     def finish():
         if ev is not None:
             ev.synchronize()
-            s0, n0, s1, n1 = host_buf.tolist()
+            vals = host_buf[:out.numel()].tolist()
         else:
-            s0, n0, s1, n1 = out.tolist()
+            vals = out.tolist()
+        s0, n0, s1, n1 = vals[:4]
+        finish.plan_status = tuple(int(v) for v in vals[4:8]) if status else None     # (n_patches, n_pairs, 0, violation flag)
         nan = float("nan")
         return (s0 / n0 if n0 > 0 else nan), (s1 / n1 if n1 > 0 else nan)
     return finish if defer else finish()

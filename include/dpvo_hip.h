@@ -112,6 +112,12 @@ int dpvo_flow_mag(const float* poses, const float* patches, const float* intrins
 int dpvo_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                    const int64_t* jj, const int64_t* kk, const int32_t* plan /* of (ii,jj,kk), or NULL: full scan */,
                    int64_t E, int P, int64_t i, int64_t j, float beta, float* out4, void* stream);
+/* The same, and the plan's counters ride along: status4 = (n_patches, n_pairs, 0, flag) as floats, flag != 0 when
+ * dpvo_plan_build_window saw a frame / patch id outside the window it was promised (groups were then clamped): the caller's
+ * only per-frame read-back also tells it that its bounds were wrong.  Needs a plan. */
+int dpvo_motionmag_status(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                          const int64_t* jj, const int64_t* kk, const int32_t* plan, int64_t E, int P, int64_t i, int64_t j,
+                          float beta, float* out4, float* status4, void* stream);
 
 /* pops.point_cloud centre pixel (projective_ops.py:115-117, dpvo.py:358-360): points[m,3]. */
 int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,

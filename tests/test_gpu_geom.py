@@ -151,6 +151,16 @@ def test_plan_window_reports_ids_outside_the_window(dev):
     torch.cuda.synchronize()
     assert bad.counts.cpu().tolist()[3] == 1
     assert int(bad.perm_k.min()) >= 0 and int(bad.perm_k.max()) < E and int(bad.perm_p.min()) >= 0 and int(bad.perm_p.max()) < E
+    # the flag reaches the host with the frame's only read-back (the flow test of DPVO.keyframe): dpvo_motionmag_status
+    from dpvo_amd import projective_ops as pops
+    poses, patches, intr = (t.to(dev) for t in S.make_scene(20))
+    for plan, flag in ((good, 0), (bad, 1)):
+        host = torch.empty(8, dtype=torch.float32).pin_memory()
+        fin = pops.motionmag_pair(poses, patches, intr, ii.to(dev), jj.to(dev), kk.to(dev), 14, 16, plan=plan, defer=True, host_buf=host)
+        a, b = fin()
+        assert fin.plan_status[3] == flag and fin.plan_status[2] == 0
+        if flag == 0:
+            assert fin.plan_status[:2] == (good.n_patches(), good.n_pairs()) and a == a and b == b
     wide = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), window=(0, 4096, 0, 4096 * 96))        # -> dpvo_plan_build_ranged
     for name in ("perm_k", "ku", "ix", "jx", "perm_p", "pu"):
         assert torch.equal(getattr(wide, name), getattr(good, name)), name
