@@ -64,7 +64,9 @@ __device__ __forceinline__ void store_a(const ARegs<A_F32>& r, _Float16* dst) {
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// (v_exp + v_rcp, 1 ulp; the result is rounded to f16 by every caller -- same function as update_fused.hip's, so that the two paths
+// keep identical rounding points)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 
 // Shared epilogue: acc[i][j][r] = C[m = m0 + wm*64 + i*16 + (lane&15)][n = n0 + wn*64 + j*16 + (lane>>4)*4 + r]

@@ -85,7 +85,13 @@ __device__ __forceinline__ Lane lane_of() {
   return l;
 }
 
+// sigmoid in f32 (its result is rounded to f16 by every caller): v_exp + v_rcp, 1 ulp -- an IEEE division costs ten more VALU
+// instructions per value, a third of K7's VALU work
+#ifdef FU_SIGM_IEEE
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+#else
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -405,10 +411,14 @@ __device__ __forceinline__ void img_add_store_stream(f16v (&v)[RT][3], float* ip
   }
 }
 
-// rows of a P-order f16 matrix [., 384] -> the LDS tile.  rows == nullptr: row0 + i; an index < 0 or a row >= E: zeros
+// rows of a P-order f16 matrix [., 384] -> the LDS tile.  rows == nullptr: row0 + i; an index < 0 or a row >= E: zeros.
+// The row indices are read ONCE per row (one coalesced load, through `sidx`: 32 RT ints of LDS that are free at this point)
+// instead of once per 16-byte piece: 18 dependent 4-byte loads per thread in front of the data loads were a third of the
+// gather's 9-11 us.  Contains one barrier.
+#ifdef FU_GATHER_OLD
 template <int RT>
 __device__ __forceinline__ void gather_rows(char* act, const _Float16* __restrict__ src, const int32_t* __restrict__ rows,
-                                            int64_t row0, int64_t E, int tid) {
+                                            int64_t row0, int64_t E, int tid, int32_t*) {
   constexpr int N = RT * 6;                      // 32 RT rows x 48 pieces of 16 B over 256 threads
   h8 v[N];
   int32_t sr[N];
@@ -429,6 +439,30 @@ __device__ __forceinline__ void gather_rows(char* act, const _Float16* __restric
     *reinterpret_cast<h8*>(act + row * PITCH + ch * 16) = v[i];
   }
 }
+#else
+template <int RT>
+__device__ __forceinline__ void gather_rows(char* act, const _Float16* __restrict__ src, const int32_t* __restrict__ rows,
+                                            int64_t row0, int64_t E, int tid, int32_t* sidx) {
+  constexpr int N = RT * 6;                      // 32 RT rows x 48 pieces of 16 B over 256 threads
+  if (tid < 32 * RT) {
+    const int64_t g = row0 + tid;
+    sidx[tid] = g < E ? (rows ? rows[g] : (int32_t)g) : -1;
+  }
+  __syncthreads();
+  h8 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
+    const int32_t sr = sidx[row];
+    v[i] = sr >= 0 ? *reinterpret_cast<const h8*>(src + (int64_t)sr * D + ch * 8) : (h8)(_Float16)0;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
+    *reinterpret_cast<h8*>(act + row * PITCH + ch * 16) = v[i];
+  }
+}
+#endif
 // the LDS tile -> rows [row0, row0 + R) of a P-order f16 matrix [E, 384]
 template <int RT>
 __device__ __forceinline__ void scatter_rows(const char* act, _Float16* __restrict__ dst, int64_t row0, int64_t E, int tid) {
@@ -657,7 +691,7 @@ __global__ __launch_bounds__(256, OCC) void k_chain(const P2 p) {
   const h8* wpa = w_base(MODE == MODE_H ? p.b.w : p.a.w, KS384, l);
   w_preload<DW>(wf, wpa);
   if constexpr (OCC == 1) bias_load(bias, MODE == MODE_H ? p.b.b : p.a.b, l);
-  gather_rows<RT>(act, p.src, p.rows, row0, p.E, l.tid);
+  gather_rows<RT>(act, p.src, p.rows, row0, p.E, l.tid, reinterpret_cast<int32_t*>(smem + Geo<RT>::ACT_BYTES));
   if constexpr (MODE == MODE_H && OCC == 1) img_load<RT>(im, ip);
   FU_T(1 + MODE, 1);
   __syncthreads();
@@ -750,7 +784,7 @@ __global__ __launch_bounds__(256, 1) void k7_gru_heads(const P7 p) {
   for (int i = l.tid; i < D; i += 256) {
     lnp[i] = p.ln_g[0][i]; lnp[D + i] = p.ln_b[0][i]; lnp[2 * D + i] = p.ln_g[1][i]; lnp[3 * D + i] = p.ln_b[1][i];
   }
-  gather_rows<RT>(act, p.y, p.rows, row0, p.E, l.tid);
+  gather_rows<RT>(act, p.y, p.rows, row0, p.E, l.tid, reinterpret_cast<int32_t*>(red));
   float* ip = img_ptr<RT>(const_cast<float*>(p.img), tile, l);
   {
     Img<RT> im;
