@@ -566,8 +566,22 @@ __global__ void ba_retr_kernel(float* __restrict__ poses, float* __restrict__ pa
   for (int a = threadIdx.x; a < n6; a += blockDim.x) sdx[a] = dX[a];
   __syncthreads();
   for (int k = gt; k < np; k += gridDim.x * blockDim.x) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;              // four independent chains: the loads overlap
+    // four summation chains (a mod 4), the column fetched 20 entries at a time: only 54 waves exist here, so the kernel's
+    // time is its number of dependent round trips (3 for the usual n6 = 60; it was 15 with 4 loads per trip, 12 us)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int a = 0;
+    for (; a + 20 <= n6; a += 20) {
+      float e[20];
+#pragma unroll
+      for (int u = 0; u < 20; ++u) e[u] = Ecol[(int64_t)(a + u) * ldE + k];
+#pragma unroll
+      for (int u = 0; u < 20; u += 4) {
+        s0 += e[u + 0] * sdx[a + u + 0];
+        s1 += e[u + 1] * sdx[a + u + 1];
+        s2 += e[u + 2] * sdx[a + u + 2];
+        s3 += e[u + 3] * sdx[a + u + 3];
+      }
+    }
     for (; a + 4 <= n6; a += 4) {
       s0 += Ecol[(int64_t)(a + 0) * ldE + k] * sdx[a + 0];
       s1 += Ecol[(int64_t)(a + 1) * ldE + k] * sdx[a + 1];
@@ -676,7 +690,8 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
       else
         hipLaunchKernelGGL(ba_solve_kernel<false>, dim3(1), dim3(128), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
     }
-    hipLaunchKernelGGL(ba_retr_kernel, dim3((unsigned)((np_h + 255) / 256)), dim3(256), 0, st, poses, patches,
+    // (64-thread workgroups: np patches are only ~54 waves, spread them over as many CUs)
+    hipLaunchKernelGGL(ba_retr_kernel, dim3((unsigned)((np_h + 63) / 64)), dim3(64), 0, st, poses, patches,
                        plan + PL.kx, n_patches, Qbuf, ubuf, Ecol, np_h, dX, t0, N, P);
   }
   DPVO_LAUNCH_CHECK();

@@ -1,8 +1,9 @@
 #!/bin/bash
-# tools/ab_lib.sh "<extra hipcc flags for update_fused.hip>" : builds dpvo_amd/libdpvo_hip_ab.so = the shipped objects with
+# tools/ab_lib.sh "<extra hipcc flags for update_fused.hip>" [suffix=ab] : builds dpvo_amd/libdpvo_hip_<suffix>.so = the shipped objects with
 # update_fused.hip recompiled with the extra flags (an A/B partner for tools/update_bench.py on ONE box: DPVO_HIP_LIB=...)
 set -e
 cd "$(dirname "$0")/../dpvo_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $1 -c update_fused.hip -o /tmp/uf_ab.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libdpvo_hip_ab.so corr.o geom.o graph.o update.o /tmp/uf_ab.o ba.o ba_global.o frontend.o encoder.o capi.o
-echo built ../libdpvo_hip_ab.so with "$1"
+sfx=${2:-ab}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $1 -c update_fused.hip -o /tmp/uf_$sfx.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libdpvo_hip_$sfx.so corr.o geom.o graph.o update.o /tmp/uf_$sfx.o ba.o ba_global.o frontend.o encoder.o capi.o
+echo built ../libdpvo_hip_$sfx.so with "$1"
