@@ -189,10 +189,17 @@ def main():
     torch.cuda.synchronize(device)                   # the stream is resident before the first frame is tracked
     intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=device)   # calib/tartan.txt
 
+    # counter passes only (tools/pmc_corr.sh): rocprofv3 --pmc serialises every dispatch, and with more than a few dozen
+    # dispatches outstanding (the 12 back-to-back updates of the initialisation frame) it faults; per-kernel counters do not
+    # care about a host sync per frame.  Never set for a timed run.
+    _SYNC_EVERY_FRAME = bool(int(os.environ.get("DPVO_BENCH_SYNC_EVERY_FRAME", "0")))
+
     def step(t):
         # image_ready=False: the frames were staged in HBM and synchronised before the timed region (the metric is quoted with
         # resident inputs), so the encoder stream need not wait for the compute stream
         slam(float(t), frames[t % n_img], intr, image_ready=False)
+        if _SYNC_EVERY_FRAME:
+            torch.cuda.synchronize(device)
 
     from dpvo_amd import multiseq
     clock = multiseq.Clock(dist=dist, device=device)       # barrier + device sync on both sides of the timed region

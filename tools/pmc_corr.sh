@@ -6,7 +6,7 @@ set -e
 root=$(pwd); out=$root/gpurun_out/pmc_corr; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd $root && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python bench.py --steps 8 --warmup 45 > $out/$c.log 2>&1)
+  (cd $root && DPVO_BENCH_SYNC_EVERY_FRAME=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python bench.py --steps 8 --warmup 45 > $out/$c.log 2>&1)
 done
 cd $root
 python - <<'PY'
