@@ -60,6 +60,17 @@ __device__ unsigned long long* g_fu_trace = nullptr;
 namespace {
 namespace fu {
 
+// Soft start (dpvo_update_fused_start_skew): the workgroups of a launch begin in four groups, skew / 4 microseconds apart,
+// instead of all 256 CUs entering the same phase in the same microsecond.  A candidate of the autotune only: it costs a few
+// microseconds per kernel on a normal box (measured: 0 / +10 / +60 us at 4 / 10 / 20 us) and exists for the boxes on which the
+// FIRST, synchronous round of workgroups of every such kernel runs 2x slower than the second, staggered one.
+__device__ __forceinline__ void soft_start(int skew_us) {
+  if (skew_us > 0 && (blockIdx.x & 3)) {
+    const unsigned long long t0 = wall_clock64(), d = (unsigned long long)(blockIdx.x & 3) * (unsigned)skew_us * 25ull;   // 100 MHz ticks
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 constexpr int D = 384;
 constexpr int PITCH = 784;             // bytes per LDS activation row (768 + 16: ds_read_b128 / ds_write_b128 conflict free)
 constexpr int CPITCH = 272;            // bytes per LDS row of one K chunk of the correlation GEMM (256 + 16)
@@ -487,6 +498,7 @@ struct P1 {
   const _Float16* inp; const int64_t* inp_rows; int64_t inp_mod;
   float* img; _Float16* rows16;                       // out
   int64_t E;
+  int skew;                                          // soft start: workgroup b waits (b & 3) * skew / 4 microseconds (0: off)
 };
 
 // K1 -----------------------------------------------------------------------------------------------
@@ -500,6 +512,7 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
   float* red = reinterpret_cast<float*>(smem + Geo<RT>::ACT_BYTES);
   char* al = act + l.n * PITCH + 16 * l.h;
 
+  soft_start(p.skew);
   FU_T(0, 0);
   f16v acc[RT][3];
   h8 wf[DW][3];
@@ -670,6 +683,7 @@ struct P2 {
   _Float16* rows16;                                 // MODE_C1: out
   _Float16* fg;                                     // else: out [E, 768]
   int64_t E;
+  int skew;                                          // soft start: workgroup b waits (b & 3) * skew / 4 microseconds (0: off)
 };
 enum { MODE_C1 = 0, MODE_C2 = 1, MODE_H = 2 };
 
@@ -682,6 +696,7 @@ __global__ __launch_bounds__(256, OCC) void k_chain(const P2 p) {
   char* act = smem;
   char* al = act + l.n * PITCH + 16 * l.h;
 
+  soft_start(p.skew);
   FU_T(1 + MODE, 0);
   f16v acc[RT][3];
   h8 wf[DW][3];
@@ -760,6 +775,7 @@ struct P7 {
   const float* coords; int pp;                      // optional: target = coords[..., P/2, P/2] + delta
   float *net_out, *delta, *weight, *target;
   int64_t E;
+  int skew;                                          // soft start: workgroup b waits (b & 3) * skew / 4 microseconds (0: off)
 };
 
 template <int RT, int DW>
@@ -773,6 +789,7 @@ __global__ __launch_bounds__(256, 1) void k7_gru_heads(const P7 p) {
   char* al = act + l.n * PITCH + 16 * l.h;
   char* gl = al + Geo<RT>::ACT_BYTES;               // second tile: where every lane parks its own gate values (no barriers)
 
+  soft_start(p.skew);
   FU_T(4, 0);
   f16v x[RT][3];
   h8 wf[DW][3];
@@ -1733,6 +1750,14 @@ extern "C" int dpvo_update_fused_tiling(int tiling) {
   return cfg;
 }
 
+// Soft start of the seven-launch kernels in microseconds (see fu::soft_start); us < 0: query.  Default 0, or DPVO_FU_SKEW.
+extern "C" int dpvo_update_fused_start_skew(int us) {
+  static int skew = -1;
+  if (skew < 0) { const char* e = getenv("DPVO_FU_SKEW"); skew = e ? atoi(e) : 0; if (skew < 0 || skew > 1000) skew = 0; }
+  if (us >= 0) skew = us > 1000 ? 1000 : us;
+  return skew;
+}
+
 extern "C" size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups) {
   if (E < 0 || max_groups < 0) return 0;
   fu::Ws w;
@@ -1768,7 +1793,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
     if (!p->w[i] || !p->b[i]) return DPVO_E_INVALID;
   constexpr int RT = FU_RT, DW = FU_DW;
   constexpr int RT2 = 2, DW2 = FU_DW2, OCC2 = FU_OCC2;  // several workgroups per CU, 64-row tiles
-  const int cfg = dpvo_update_fused_tiling(-1);
+  const int cfg = dpvo_update_fused_tiling(-1), skew = dpvo_update_fused_start_skew(-1);
   const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
   Ws L;
   ws_layout<RT>(E, maxg, &L);
@@ -1786,19 +1811,19 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
 #define FU(call) do { rc = (call); if (rc) return rc; } while (0)
   {
     P1 a{lin(DPVO_UF_C0), lin(DPVO_UF_C2), lin(DPVO_UF_C5), p->ln_g[0], p->ln_b[0], p->ln_g[1], p->ln_b[1],
-         (const _Float16*)corr, ld_corr, net, net_rows, n_kept, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E};
+         (const _Float16*)corr, ld_corr, net, net_rows, n_kept, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E, skew};
     if (cfg & 2) FU(launch(k1_corr_norm<RT2, DW2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
     else FU(launch(k1_corr_norm<RT, DW>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C1_0), lin(DPVO_UF_C1_2), Lin{nullptr, nullptr}, Lin{nullptr, nullptr}, r16a, plan + PL.ix, img, r16b,
-         nullptr, E};
+         nullptr, E, skew};
     if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_C1, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
     else FU(launch(k_chain<RT, DW, MODE_C1>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C2N_0), lin(DPVO_UF_C2N_2), lin(DPVO_UF_AKK_F), lin(DPVO_UF_AKK_G), r16b, plan + PL.jx, img, nullptr, fg,
-         E};
+         E, skew};
     if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_C2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
     else FU(launch(k_chain<RT, DW, MODE_C2>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
@@ -1806,7 +1831,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   int64_t ngp = n_pairs_ub < 1 ? 1 : (n_pairs_ub > E ? E : n_pairs_ub);
   FU(dpvo_softagg(fg, 768, plan + PL.perm_k, plan + PL.patch_off, plan + PL.counts + 0, ngk, y, 384, stream));
   {
-    P2 a{Lin{nullptr, nullptr}, lin(DPVO_UF_AKK_H), lin(DPVO_UF_AIJ_F), lin(DPVO_UF_AIJ_G), y, plan + PL.ku, img, nullptr, fg, E};
+    P2 a{Lin{nullptr, nullptr}, lin(DPVO_UF_AKK_H), lin(DPVO_UF_AIJ_F), lin(DPVO_UF_AIJ_G), y, plan + PL.ku, img, nullptr, fg, E, skew};
     if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_H, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
     else FU(launch(k_chain<RT, DW, MODE_H>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
@@ -1819,7 +1844,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
     a.ln_g[0] = p->ln_g[2]; a.ln_b[0] = p->ln_b[2]; a.ln_g[1] = p->ln_g[3]; a.ln_b[1] = p->ln_b[3];
     a.d_w = (const _Float16*)p->d_w; a.d_b = (const _Float16*)p->d_b; a.w_w = (const _Float16*)p->w_w; a.w_b = (const _Float16*)p->w_b;
     a.y = y; a.rows = plan + PL.pu; a.img = img; a.coords = coords; a.pp = P * P;
-    a.net_out = net_out; a.delta = delta; a.weight = weight; a.target = target; a.E = E;
+    a.net_out = net_out; a.delta = delta; a.weight = weight; a.target = target; a.E = E; a.skew = skew;
     FU(launch(k7_gru_heads<RT, FU_DW7>, tiles, Geo<RT>::LDS_BYTES + Geo<RT>::ACT_BYTES + 4 * D * 4, a, st));
   }
 #undef FU

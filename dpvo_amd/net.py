@@ -316,12 +316,16 @@ class Update(nn.Module):
             if key not in _AUTO_CHOICE:
                 _AUTO_DEFAULT[key] = L.lib().dpvo_update_fused_tiling(-1)
             default_tiling = _AUTO_DEFAULT[key]
-            cands = [("fused", True, default_tiling), ("launch_by_launch", False, None)]
+            cands = [("fused", True, default_tiling, 0), ("launch_by_launch", False, None, 0)]
             if default_tiling != 0:
-                cands.insert(1, ("fused_96x1", True, 0))          # one workgroup per CU everywhere (the round-2a kernels)
-            for name, fz, tiling in cands:
+                cands.insert(1, ("fused_96x1", True, 0, 0))          # one workgroup per CU everywhere (the round-2a kernels)
+            # soft start: the workgroups of a launch begin in four groups 2 us apart -- for the boxes that run the first,
+            # synchronous round of workgroups of these kernels 2x slower (profiles/README.md, "slow boxes"); loses elsewhere
+            cands.insert(1, ("fused_soft_start", True, default_tiling, 8))
+            for name, fz, tiling, skew in cands:
                 if tiling is not None:
                     L.lib().dpvo_update_fused_tiling(tiling)
+                    L.lib().dpvo_update_fused_start_skew(skew)
                 for rep in range(3):
                     if rep == 1:
                         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -332,7 +336,10 @@ class Update(nn.Module):
                 e1.synchronize()
                 times[name] = e0.elapsed_time(e1) / 2
             best = min(times, key=times.get)
+            if best == "fused_soft_start" and times[best] > 0.97 * times["fused"]:
+                best = "fused"                                    # (within the noise of one measurement: not worth a delay)
             L.lib().dpvo_update_fused_tiling(0 if best == "fused_96x1" else default_tiling)
+            L.lib().dpvo_update_fused_start_skew(8 if best == "fused_soft_start" else 0)
             _AUTO_CHOICE[key] = (best != "launch_by_launch", times, E)
         return _AUTO_CHOICE[key][0]
 

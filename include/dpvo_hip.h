@@ -382,6 +382,9 @@ size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups);
  * bit 1: the correlation-MLP kernel use 64-row tiles with two workgroups per CU instead of 96-row tiles with one.  tiling < 0
  * only queries.  Returns the tiling in effect (default 3, or DPVO_FU_CFG).  Process-wide; results are bit-identical. */
 int dpvo_update_fused_tiling(int tiling);
+/* Soft start of those kernels: workgroup b begins (b & 3) * us / 4 microseconds late (0 = off, the default; us < 0 queries).  A
+ * candidate of the autotune for boxes that throttle when all CUs enter the same phase at once; process-wide, bit-identical. */
+int dpvo_update_fused_start_skew(int us);
 int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const float* net, const void* inp,
                               const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan,
                               int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
