@@ -265,8 +265,8 @@ def test_fused_tilings_are_bit_identical(dev, E_frames):
     before = L.lib().dpvo_update_fused_tiling(-1)
     try:
         res = []
-        for tiling in (0, 1, 2, 3):
-            assert L.lib().dpvo_update_fused_tiling(tiling) == tiling
+        for tiling, skew in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 8), (0, 20)):        # (+ the soft start: a delay, nothing else)
+            assert L.lib().dpvo_update_fused_tiling(tiling) == tiling and L.lib().dpvo_update_fused_start_skew(skew) == skew
             x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
                                corr_is_padded=True, fused=True)
             res.append((x.clone(), d.clone(), w.clone()))
@@ -275,6 +275,7 @@ def test_fused_tilings_are_bit_identical(dev, E_frames):
                 assert torch.equal(a, b)
     finally:
         L.lib().dpvo_update_fused_tiling(before)
+        L.lib().dpvo_update_fused_start_skew(0)
 
 
 def test_update_full_size_vs_oracle(oracle, dev):
