@@ -1723,6 +1723,15 @@ void ws_layout(int64_t E, int64_t maxg, Ws* w) {
 #ifndef FU_OCC2
 #define FU_OCC2 2
 #endif
+#ifndef FU_RT2
+#define FU_RT2 2
+#endif
+#ifndef FU_RT2C
+#define FU_RT2C FU_RT2
+#endif
+#ifndef FU_DW2C
+#define FU_DW2C FU_DW2
+#endif
 #define FU_CFG_DEFAULT 3
 #define FU_DWPM 4
 #define FU_DWKB 6
@@ -1792,7 +1801,8 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   for (int i = 0; i < DPVO_UF_NLIN; ++i)
     if (!p->w[i] || !p->b[i]) return DPVO_E_INVALID;
   constexpr int RT = FU_RT, DW = FU_DW;
-  constexpr int RT2 = 2, DW2 = FU_DW2, OCC2 = FU_OCC2;  // several workgroups per CU, 64-row tiles
+  constexpr int RT2 = FU_RT2, DW2 = FU_DW2, OCC2 = FU_OCC2;
+  constexpr int RT2C = FU_RT2C, DW2C = FU_DW2C;       // chain kernels' own tile height / ring at several workgroups per CU  // several workgroups per CU, 64-row tiles
   const int cfg = dpvo_update_fused_tiling(-1), skew = dpvo_update_fused_start_skew(-1);
   const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
   Ws L;
@@ -1805,7 +1815,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   _Float16 *r16a = (_Float16*)(wsb + L.r16a), *r16b = (_Float16*)(wsb + L.r16b), *fg = (_Float16*)(wsb + L.fg),
            *y = (_Float16*)(wsb + L.y);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t tiles = cdiv64(E, 32 * RT), tiles2 = cdiv64(E, 32 * RT2);
+  const int64_t tiles = cdiv64(E, 32 * RT), tiles2 = cdiv64(E, 32 * RT2), tiles2c = cdiv64(E, 32 * RT2C);
   auto lin = [&](int i) { return Lin{p->w[i], (const _Float16*)p->b[i]}; };
   int rc;
 #define FU(call) do { rc = (call); if (rc) return rc; } while (0)
@@ -1818,13 +1828,13 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   {
     P2 a{lin(DPVO_UF_C1_0), lin(DPVO_UF_C1_2), Lin{nullptr, nullptr}, Lin{nullptr, nullptr}, r16a, plan + PL.ix, img, r16b,
          nullptr, E, skew};
-    if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_C1, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch(k_chain<RT2C, DW2C, MODE_C1, OCC2>, tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
     else FU(launch(k_chain<RT, DW, MODE_C1>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C2N_0), lin(DPVO_UF_C2N_2), lin(DPVO_UF_AKK_F), lin(DPVO_UF_AKK_G), r16b, plan + PL.jx, img, nullptr, fg,
          E, skew};
-    if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_C2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch(k_chain<RT2C, DW2C, MODE_C2, OCC2>, tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
     else FU(launch(k_chain<RT, DW, MODE_C2>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   int64_t ngk = n_patches_ub < 1 ? 1 : (n_patches_ub > E ? E : n_patches_ub);
@@ -1832,7 +1842,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   FU(dpvo_softagg(fg, 768, plan + PL.perm_k, plan + PL.patch_off, plan + PL.counts + 0, ngk, y, 384, stream));
   {
     P2 a{Lin{nullptr, nullptr}, lin(DPVO_UF_AKK_H), lin(DPVO_UF_AIJ_F), lin(DPVO_UF_AIJ_G), y, plan + PL.ku, img, nullptr, fg, E, skew};
-    if (cfg & 1) FU(launch(k_chain<RT2, DW2, MODE_H, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch(k_chain<RT2C, DW2C, MODE_H, OCC2>, tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
     else FU(launch(k_chain<RT, DW, MODE_H>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   FU(dpvo_softagg(fg, 768, plan + PL.perm_p, plan + PL.pair_off, plan + PL.counts + 1, ngp, y, 384, stream));
