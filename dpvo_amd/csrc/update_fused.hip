@@ -98,11 +98,7 @@ __device__ __forceinline__ Lane lane_of() {
 
 // sigmoid in f32 (its result is rounded to f16 by every caller): v_exp + v_rcp, 1 ulp -- an IEEE division costs ten more VALU
 // instructions per value, a third of K7's VALU work
-#ifdef FU_SIGM_IEEE
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
-#else
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-#endif
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -426,31 +422,6 @@ __device__ __forceinline__ void img_add_store_stream(f16v (&v)[RT][3], float* ip
 // The row indices are read ONCE per row (one coalesced load, through `sidx`: 32 RT ints of LDS that are free at this point)
 // instead of once per 16-byte piece: 18 dependent 4-byte loads per thread in front of the data loads were a third of the
 // gather's 9-11 us.  Contains one barrier.
-#ifdef FU_GATHER_OLD
-template <int RT>
-__device__ __forceinline__ void gather_rows(char* act, const _Float16* __restrict__ src, const int32_t* __restrict__ rows,
-                                            int64_t row0, int64_t E, int tid, int32_t*) {
-  constexpr int N = RT * 6;                      // 32 RT rows x 48 pieces of 16 B over 256 threads
-  h8 v[N];
-  int32_t sr[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const int idx = tid + 256 * i, row = idx / 48;
-    const int64_t g = row0 + row;
-    sr[i] = g < E ? (rows ? rows[g] : (int32_t)g) : -1;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
-    v[i] = sr[i] >= 0 ? *reinterpret_cast<const h8*>(src + (int64_t)sr[i] * D + ch * 8) : (h8)(_Float16)0;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
-    *reinterpret_cast<h8*>(act + row * PITCH + ch * 16) = v[i];
-  }
-}
-#else
 template <int RT>
 __device__ __forceinline__ void gather_rows(char* act, const _Float16* __restrict__ src, const int32_t* __restrict__ rows,
                                             int64_t row0, int64_t E, int tid, int32_t* sidx) {
@@ -473,7 +444,6 @@ __device__ __forceinline__ void gather_rows(char* act, const _Float16* __restric
     *reinterpret_cast<h8*>(act + row * PITCH + ch * 16) = v[i];
   }
 }
-#endif
 // the LDS tile -> rows [row0, row0 + R) of a P-order f16 matrix [E, 384]
 template <int RT>
 __device__ __forceinline__ void scatter_rows(const char* act, _Float16* __restrict__ dst, int64_t row0, int64_t E, int tid) {
