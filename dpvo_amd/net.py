@@ -322,6 +322,7 @@ class Update(nn.Module):
             # soft start: the workgroups of a launch begin in four groups 2 us apart -- for the boxes that run the first,
             # synchronous round of workgroups of these kernels 2x slower (profiles/README.md, "slow boxes"); loses elsewhere
             cands.insert(1, ("fused_soft_start", True, default_tiling, 8))
+            cands.insert(2, ("fused_soft_start_40", True, default_tiling, 40))
             for name, fz, tiling, skew in cands:
                 if tiling is not None:
                     L.lib().dpvo_update_fused_tiling(tiling)
@@ -336,10 +337,10 @@ class Update(nn.Module):
                 e1.synchronize()
                 times[name] = e0.elapsed_time(e1) / 2
             best = min(times, key=times.get)
-            if best == "fused_soft_start" and times[best] > 0.97 * times["fused"]:
+            if best.startswith("fused_soft_start") and times[best] > 0.97 * times["fused"]:
                 best = "fused"                                    # (within the noise of one measurement: not worth a delay)
             L.lib().dpvo_update_fused_tiling(0 if best == "fused_96x1" else default_tiling)
-            L.lib().dpvo_update_fused_start_skew(8 if best == "fused_soft_start" else 0)
+            L.lib().dpvo_update_fused_start_skew({"fused_soft_start": 8, "fused_soft_start_40": 40}.get(best, 0))
             _AUTO_CHOICE[key] = (best != "launch_by_launch", times, E)
         return _AUTO_CHOICE[key][0]
 
