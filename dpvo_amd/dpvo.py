@@ -26,14 +26,17 @@ from .utils import Timer, flatmeshgrid
 
 autocast = torch.autocast
 _CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0")))
-# remove_factors leaves the hidden-state rows where they are and hands the keep list to the next update operator call
-# (95 % of the bytes a removal moves; EdgeStore.keep(defer_net=True)); DPVO_DEFER_NET=0: compact immediately
-_DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '1')))
+# DPVO_DEFER_NET=1: remove_factors leaves the hidden-state rows where they are and hands the keep list to the next update operator
+# call (95 % of the bytes a removal moves; EdgeStore.keep(defer_net=True)).  Opt-in: the removal kernel drops from 30 to 3 us, but
+# the frame start then just waits longer for the overlapped encoders, and the staging buffer of the keep list stays busy until
+# the update operator has run, which costs the host its lead (measured: 814 -> 809 frames/sec, +0.6 ms of host CPU per frame).
+_DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '0')))
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 # The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
-# DPVO_PLAN_ASYNC (default: on whenever the encoders are overlapped too) its four small kernels + memsets are built on a third
-# stream beside the correlation kernel instead of in front of it (they were ~55 us of a host-paced, mostly idle GPU).
-_PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '')
+# DPVO_PLAN_ASYNC=1 its four small kernels + memsets are built on a third stream beside the correlation kernel instead of in
+# front of it.  Opt-in: the correlation kernel fills the register file, so the plan's 1024-thread workgroups only run once it
+# drains and the update operator waits for them (measured: no gain, +0.2 ms of host CPU per frame for the extra stream).
+_PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '0')
 
 
 class DPVO:
@@ -118,11 +121,12 @@ class DPVO:
         self.pyramid = (self.fmap1_, self.fmap2_)
 
         self._plan = None          # GraphPlan of the active edge list (rebuilt when edges change)
+        self._deferred_removals = 0
         self._plan_stream = None   # third stream for the asynchronous plan build + its two events (reused every frame)
         self._plan_ev = None
         self._edges_ev = None
         self._plan_ready = None    # set while a plan built on the side stream has not been ordered before the main stream yet
-        self.plan_async = (overlap_encoders if _PLAN_ASYNC == '' else bool(int(_PLAN_ASYNC))) and torch.device(device).type == "cuda"
+        self.plan_async = bool(int(_PLAN_ASYNC)) and torch.device(device).type == "cuda"
         self._imap_full = None
         self._corr_buf = None
 
@@ -307,6 +311,7 @@ class DPVO:
             es.keep(keep, keep_h, also=(rem, self.pg.edges_inac), defer_net=_DEFER_NET)      # both gathers in one launch
         else:
             es.keep(keep, keep_h, defer_net=_DEFER_NET)
+        self._deferred_removals += int(es.net_pending is not None)
         self._plan = None
 
     def _removal_mask(self, h):

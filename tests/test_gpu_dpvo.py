@@ -105,9 +105,10 @@ def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
     import dpvo_amd.dpvo as D
     decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 24 + [(True, True), (True, False), (True, True)] + \
                 [(True, False)] * 4
-    assert D._DEFER_NET
+    monkeypatch.setattr(D, "_DEFER_NET", True)
     a, ra, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True)
     a.flush()
+    assert a._deferred_removals > 0                     # (the deferred path really ran)
     monkeypatch.setattr(D, "_DEFER_NET", False)
     b, rb, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True)
     b.flush()
@@ -118,6 +119,21 @@ def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
     assert torch.equal(a.pg.net, b.pg.net)                                   # (the accessor applies a pending compaction)
     assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
     assert torch.equal(a.pg.edges.view("target"), b.pg.edges.view("target")) and torch.equal(a.pg.edges.view("weight"), b.pg.edges.view("weight"))
+
+
+def test_plan_on_a_third_stream_is_bit_identical(dev, monkeypatch):
+    """DPVO_PLAN_ASYNC=1: the graph plan built on its own stream beside reproject / corr, joined before the update operator"""
+    import dpvo_amd.dpvo as D
+    decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 16
+    a, _, _ = _run(dev, decisions, seed=4, defer=True, check=False, overlap=True)
+    a.flush()
+    monkeypatch.setattr(D, "_PLAN_ASYNC", "1")
+    b, _, _ = _run(dev, decisions, seed=4, defer=True, check=False, overlap=True)
+    b.flush()
+    torch.cuda.synchronize()
+    assert b.plan_async and b._plan_stream is not None and not a.plan_async
+    assert a.n == b.n and torch.equal(a.pg.net, b.pg.net) and torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n])
+    assert torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n]) and torch.equal(a.pg.ii, b.pg.ii)
 
 
 def test_edge_store_deferred_compaction(dev):
