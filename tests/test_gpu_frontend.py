@@ -22,6 +22,16 @@ def test_normalize_colors_features(dev):
     L.check(L.lib().dpvo_normalize_image(L.ptr(img), L.ptr(f32), L.ptr(f16), L.i64(img.numel()), L.stream()), "norm")
     ref = 2 * (img[None, None] / 255.0) - 0.5                          # dpvo.py:389
     assert torch.equal(f32, ref[0, 0]) and torch.equal(f16, ref[0, 0].half())
+    # sizes that are not a multiple of 16 and pointers that are not 16-byte aligned take the scalar tail / scalar path
+    flat = img.reshape(-1)
+    for off, n in ((0, 1000 + 7), (3, 4096), (16, 16 * 50 + 1)):
+        a32 = torch.full((n + 8,), -9.0, device=dev); a16 = torch.full((n + 8,), -9.0, dtype=torch.float16, device=dev)
+        src = flat[off:off + n]
+        L.check(L.lib().dpvo_normalize_image(L.ptr(src), L.ptr(a32), L.ptr(a16), L.i64(n), L.stream()), "norm")
+        r = 2 * (src / 255.0) - 0.5
+        assert torch.equal(a32[:n], r) and torch.equal(a16[:n], r.half()) and (a32[n:] == -9).all() and (a16[n:] == -9).all()
+        L.check(L.lib().dpvo_normalize_image(L.ptr(src), L.ptr(None), L.ptr(a16), L.i64(n), L.stream()), "norm")   # f16 only
+        assert torch.equal(a16[:n], r.half())
     # colours: clr = patchify(images[0], 4*(coords+0.5), 0); clr = (clr[0,:,[2,1,0]] + 0.5) * (255/2) -> uint8
     coords = torch.stack([torch.randint(1, W // 4 - 1, (M,), generator=g), torch.randint(1, H // 4 - 1, (M,), generator=g)], -1).float().to(dev)
     coords[0] = torch.tensor([W / 4 - 0.3, 2.0], device=dev)           # partly out of bounds
