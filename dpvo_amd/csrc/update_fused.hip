@@ -846,22 +846,38 @@ __global__ __launch_bounds__(256, 1) void k7_gru_heads(const P7 p) {
   }
   FU_T(4, 13);
   // ---- hidden state out (feature order) and the heads
-  float dsum[RT][4];
+  // d and w (two Linear(384, 2) on relu(net), net.py:92) as ONE MFMA chain per wave over its own 96 features: the B fragment of
+  // k-step (3w + t) * 2 + c is exactly what to_lds would write for this lane -- relu(x[r][t][8c .. 8c + 7]) in f16 -- so it is
+  // built in registers; the A fragment carries the four head rows (rows 4..31 zero) in the same P order.  18 MFMAs instead of
+  // ~1 000 VALU instructions (relu, two conversions and four FMAs per value); f16 operands, f32 accumulate as before.
+  f16v hacc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r)
 #pragma unroll
-    for (int o = 0; o < 4; ++o) dsum[r][o] = 0.f;
-  h4 wv[3][4][4];                                  // the four head rows at this lane's 48 features (one round trip)
+    for (int k = 0; k < 16; ++k) hacc[r][k] = 0.f;
+  {
+    const int m = l.n;                              // A row = output row of the 32-row MFMA tile: d0, d1, w0, w1, then zeros
+    const _Float16* wrow = m == 0 ? p.d_w : m == 1 ? p.d_w + D : m == 2 ? p.w_w : p.w_w + D;
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int f = 96 * l.w + 32 * t + 8 * j + 4 * l.h;
-      wv[t][j][0] = *reinterpret_cast<const h4*>(p.d_w + f);
-      wv[t][j][1] = *reinterpret_cast<const h4*>(p.d_w + D + f);
-      wv[t][j][2] = *reinterpret_cast<const h4*>(p.w_w + f);
-      wv[t][j][3] = *reinterpret_cast<const h4*>(p.w_w + D + f);
-    }
+      for (int c = 0; c < 2; ++c) {
+        const int base = 96 * l.w + 32 * t + 16 * c + 4 * l.h;      // features base + {0..3} and base + 8 + {0..3}
+        h8 af = (h8)(_Float16)0;
+        if (m < 4) {
+          const h4 lo = *reinterpret_cast<const h4*>(wrow + base), hi = *reinterpret_cast<const h4*>(wrow + base + 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { af[i] = lo[i]; af[4 + i] = hi[i]; }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          h8 bfr;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float v = x[r][t][8 * c + i]; bfr[i] = (_Float16)(v > 0.f ? v : 0.f); }
+          hacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfr, hacc[r], 0, 0, 0);
+        }
+      }
+  }
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -872,24 +888,16 @@ __global__ __launch_bounds__(256, 1) void k7_gru_heads(const P7 p) {
         const int64_t g = row0 + r * 32 + l.n;
         f4 o4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float v = x[r][t][4 * j + q];
-          o4[q] = v;
-          const float a = (float)(_Float16)(v > 0.f ? v : 0.f);
-#pragma unroll
-          for (int o = 0; o < 4; ++o) dsum[r][o] += a * (float)wv[t][j][o][q];
-        }
+        for (int q = 0; q < 4; ++q) o4[q] = x[r][t][4 * j + q];
         if (g < p.E) *reinterpret_cast<f4*>(p.net_out + g * D + f) = o4;
       }
     }
   __syncthreads();                                  // (the LayerNorm partials in `red` are dead)
+  // D[row m][col n]: lane (n, h) holds rows (j & 3) + 8 (j >> 2) + 4 h in register j -> the four head sums of tile row n sit
+  // in registers 0..3 of the lanes with h == 0, both K halves already added
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    f4 s;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) { s[o] = dsum[r][o]; s[o] += xhalf(s[o]); }
-    if (l.h == 0) *reinterpret_cast<f4*>(red + ((r * 32 + l.n) * 4 + l.w) * 4) = s;
-  }
+  for (int r = 0; r < RT; ++r)
+    if (l.h == 0) *reinterpret_cast<f4*>(red + ((r * 32 + l.n) * 4 + l.w) * 4) = (f4){hacc[r][0], hacc[r][1], hacc[r][2], hacc[r][3]};
   __syncthreads();
   if (l.tid < R) {
     const int64_t g = row0 + l.tid;
