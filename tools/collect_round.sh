@@ -7,6 +7,7 @@ python bench.py > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.json
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py > $out/bench_under_rocprof.json 2> /tmp/ks.err )
 f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv; python tools/kstats.py $f 45 > $out/kernel_stats_short.txt
 t=$(find /tmp/ks -name "*kernel_trace.csv" | head -1); python tools/frame_timeline.py $t 3 > $out/frame_timeline.txt
+python tools/kernel_tail_avg.py $t corr_pyramid 20 > $out/corr_steady_state.txt
 bash tools/pmc_corr.sh > $out/pmc_corr.log 2>&1; cp gpurun_out/corr_pmc.json $out/corr_pmc.json
 bash tools/pmc_update.sh > $out/update_pmc.txt 2>&1
 python tools/phase_times.py 2>&1 | grep -v amdgpu > $out/phases.txt
