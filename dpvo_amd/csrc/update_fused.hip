@@ -1695,6 +1695,9 @@ void ws_layout(int64_t E, int64_t maxg, Ws* w) {
 #define FU_RT 3
 #define FU_DW 6
 #define FU_DW7 6
+#ifndef FU_DW1
+#define FU_DW1 6
+#endif
 #ifndef FU_DW2
 #define FU_DW2 3
 #endif
@@ -1801,7 +1804,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
     P1 a{lin(DPVO_UF_C0), lin(DPVO_UF_C2), lin(DPVO_UF_C5), p->ln_g[0], p->ln_b[0], p->ln_g[1], p->ln_b[1],
          (const _Float16*)corr, ld_corr, net, net_rows, n_kept, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E, skew};
     if (cfg & 2) FU(launch(k1_corr_norm<RT2, DW2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
-    else FU(launch(k1_corr_norm<RT, DW>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    else FU(launch(k1_corr_norm<RT, FU_DW1>, tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C1_0), lin(DPVO_UF_C1_2), Lin{nullptr, nullptr}, Lin{nullptr, nullptr}, r16a, plan + PL.ix, img, r16b,
