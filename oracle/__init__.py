@@ -6,8 +6,10 @@ plus the torch-CPU restatement of the update operator (``oracle.update_ref``).
 Only ``tests/``, ``bench.py``'s ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may import this
 package, and only as the checker.  Nothing under ``dpvo_amd/`` imports it.
 
-Parity status: the reference ships no golden vectors for altcorr / fastba / Update:
-native-kernel parity is "unpinned" by reference tests; see ``dpvo_oracle.c`` header for what pins it.
+Parity status: the reference ships no golden vectors for altcorr / fastba / Update.  What pins this
+oracle: (1) goldens made by importing the reference's Python (tests/golden/), (2) since round 3 the reference's OWN
+native kernels, compiled for gfx950 by ``oracle/build_ref.py`` into ``oracle/_ref`` (``ref_native()`` below) and run on
+the GPU box beside the HIP library and this restatement (tests/test_gpu_ref.py); see ``dpvo_oracle.c`` header.
 """
 import ctypes
 import os
@@ -27,6 +29,30 @@ def build(force=False):
 
 
 _lib = None
+_ref_mods = None
+
+
+def ref_native():
+    """(ref_cuda_corr, ref_cuda_ba): the reference's native extensions (cuda_corr: correlation.cpp:57-63, cuda_ba:
+    ba.cpp:183-189 minus solve_system) built from /root/reference by oracle/build_ref.py, or None when oracle/_ref
+    is absent.  They are torch extension modules and need a GPU to run."""
+    global _ref_mods
+    if _ref_mods is None:
+        import importlib.machinery
+        import importlib.util
+        import torch  # noqa: F401  (the extensions link against libtorch)
+        mods = []
+        for name in ("ref_cuda_corr", "ref_cuda_ba"):
+            path = os.path.join(_HERE, "_ref", name + ".so")
+            if not os.path.exists(path):
+                return None
+            loader = importlib.machinery.ExtensionFileLoader(name, path)
+            spec = importlib.util.spec_from_loader(name, loader)
+            mod = importlib.util.module_from_spec(spec)
+            loader.exec_module(mod)
+            mods.append(mod)
+        _ref_mods = tuple(mods)
+    return _ref_mods
 
 
 def lib():
