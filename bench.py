@@ -56,15 +56,22 @@ UPDATE_FLOP_EDGE = 2 * (882 * 384 + 16 * 384 * 384 + 2 * 384 * 2)    # Update.fo
 
 def pmc_traffic():
     """HBM-side bytes per corr_pyramid_kernel launch from the newest committed PMC pass (tools/pmc_corr.sh, two separate
-    rocprofv3 --pmc runs of this same command; corrected as MI355X_MICROARCH.md prescribes), or None."""
+    rocprofv3 --pmc runs of this same command; corrected as MI355X_MICROARCH.md prescribes) -- but only if that pass measured
+    THIS kernel: the file carries the SHA-256 of dpvo_amd/csrc/corr.hip it was taken with, and a file whose fingerprint does not
+    match the source in the tree (or has none) is refused.  Returns (bytes or None, reason)."""
     import glob
+    import hashlib
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corr_pmc.json")))
     if not files:
-        return None
+        return None, "no PMC pass committed"
     try:
-        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+        rec = json.load(open(files[-1]))
+        now = hashlib.sha256(open(os.path.join(ROOT, "dpvo_amd", "csrc", "corr.hip"), "rb").read()).hexdigest()
+        if rec.get("corr_hip_sha256") != now:
+            return None, f"{os.path.basename(files[-1])} was measured on a different corr.hip (stale): refused"
+        return float(rec["traffic_bytes_per_launch"]), os.path.basename(files[-1])
+    except Exception as e:
+        return None, f"unreadable PMC record: {e!r}"
 
 
 def make_stream(n_frames, ht, wd, device, seed=1234):
@@ -129,6 +136,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="default", choices=["default", "fast"])
     ap.add_argument("--seed-offset", type=int, default=None, help="sequence / weight seed offset (default: the rank)")
+    ap.add_argument("--drop-every", type=int, default=0,
+                    help="k > 0: the keyframe test drops keyframe n - KEYFRAME_INDEX on every k-th frame (scripted decision: the "
+                         "remove-frame + renumber + ring-shift branch of dpvo.py:266-310 runs INSIDE the timed region); 0: never "
+                         "(the steady state the metric is quoted on); at N = 1 the default run appends a short second leg with k = 3")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -174,7 +185,7 @@ def main():
     # frames needed beyond the requested warm-up are run as an untimed pre-roll BEFORE the W warm-up steps
     preroll = max(0, 45 - args.warmup)
     total = preroll + args.warmup + args.steps
-    cfg.BUFFER_SIZE = max(cfg.BUFFER_SIZE, total + 16)      # every frame stays a keyframe in this workload
+    cfg.BUFFER_SIZE = max(cfg.BUFFER_SIZE, total + 80)      # every frame stays a keyframe in this workload (+ the second leg)
     seed_off = rank if args.seed_offset is None else args.seed_offset
     torch.manual_seed(1234 + seed_off)
     net = VONet()
@@ -184,6 +195,8 @@ def main():
                 # with a multi-stream tracker each hit a memory access fault on this ROCm stack (profiles/README.md)
                 overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "0" if shared else "1"))))
     slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
+    if args.drop_every > 0:
+        slam.keyframe_override = lambda counter: counter % args.drop_every == 0
     n_img = 64
     frames = make_stream(n_img, ht, wd, device, seed=1234 + seed_off)
     torch.cuda.synchronize(device)                   # the stream is resident before the first frame is tracked
@@ -220,6 +233,26 @@ def main():
     corr_mod.PROFILE = None
     net_mod.PROFILE = None
     E_now = int(slam.pg.ii.numel())
+    # second leg (N = 1, default run only): the same tracker goes on with a keyframe dropped every 3rd frame -- the branch a
+    # real sequence takes on most frames (dpvo.py:266-310: edges of the dropped frame removed, ids renumbered, ring buffers
+    # shifted down).  Reported beside the headline, never part of `value`.
+    drop_leg = None
+    if world == 1 and args.drop_every == 0 and not os.environ.get("DPVO_BENCH_NO_DROP_LEG"):
+        k_drop, n_warm, n_timed = 3, 12, 36
+        slam.keyframe_override = lambda counter: counter % k_drop == 0
+        with torch.no_grad():
+            for t in range(total, total + n_warm):
+                step(t)
+            slam.flush(); torch.cuda.synchronize(device)
+            n0, t0 = slam.n, time.perf_counter()
+            for t in range(total + n_warm, total + n_warm + n_timed):
+                step(t)
+            slam.flush(); torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+        drop_leg = {"drop_every": k_drop, "frames": n_timed, "frames_per_sec": round(n_timed / dt, 1),
+                    "ms_per_frame": round(1e3 * dt / n_timed, 4), "keyframes_dropped": n_timed - (slam.n - n0),
+                    "edges_after": int(slam.pg.ii.numel())}
+        slam.keyframe_override = None
     res = multiseq.gather_results(args.steps, local, extra=1e6 * (cpu1 - cpu0) / args.steps, dist=dist,
                                   device=device if backend == "nccl" else "cpu")
     elapsed = res["seconds"]                          # max over ranks
@@ -231,7 +264,7 @@ def main():
         avg_ms = sum(corr_ms) / len(corr_ms)
         avg_E = sum(corr_edges) / len(corr_edges)
         streaming = avg_E * B_EDGE / (avg_ms * 1e-3) / 1e9
-        traffic = pmc_traffic() if args.config == "default" else None     # the committed PMC pass is of the default config
+        traffic, traffic_src = pmc_traffic() if args.config == "default" else (None, "the committed PMC pass is of the default config")
         # every byte touched once: live part of the pyramid (34 of 36 frames, both levels) + templates + coords + indices + output
         compulsory_bytes = (34.0 / 36.0) * 36 * 128 * 2 * (120 * 160 + 30 * 40) + 22 * 96 * 9 * 128 * 2 + avg_E * (144 + 32 + 1792)
         counter = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
@@ -242,7 +275,7 @@ def main():
                 "frac_counter": round(counter / HBM_PEAK_GBS, 4) if counter is not None else None,
                 "frac_streaming": round(streaming / HBM_PEAK_GBS, 4),
                 "frac_compulsory": round(compulsory_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "algorithmic_bytes": avg_E * B_EDGE, "compulsory_bytes": round(compulsory_bytes),
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": avg_E * B_EDGE, "compulsory_bytes": round(compulsory_bytes),
                 "avg_launch_ms": round(avg_ms, 4), "edges_per_launch": round(avg_E, 1), "bytes_per_edge": B_EDGE,
                 "launches": len(corr_ms)}
     roof_u = None
@@ -253,10 +286,8 @@ def main():
         avg_E = sum(uE) / len(uE)
         flops = avg_E * UPDATE_FLOP_EDGE
         tf = flops / (avg_ms * 1e-3) / 1e12
-        auto = net_mod._AUTO_CHOICE.get((device.index,))
-        path = "7 launches, dpvo_amd/csrc/update_fused.hip" if (auto is None or auto[0]) else "23 launches, dpvo_amd/csrc/update.hip"
+        path = "7 launches, dpvo_amd/csrc/update_fused.hip" if net_mod.FUSED_DEFAULT else "23 launches, dpvo_amd/csrc/update.hip"
         roof_u = {"bound": "mfma", "kernel": f"update operator (Update.forward: {path})",
-                  "autotune_ms": None if auto is None else {k: round(v, 4) for k, v in auto[1].items()}, "autotune_edges": None if auto is None else auto[2],
                   "flops": flops, "avg_ms": round(avg_ms, 4), "achieved_tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
                   "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "edges_per_call": round(avg_E, 1),
                   "flop_per_edge": UPDATE_FLOP_EDGE, "calls": len(ums),
@@ -270,9 +301,9 @@ def main():
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate, f32 BA", "data": "synthetic",
             "config": {"workload": f"synthetic 480x640 stream, {cfg.PATCHES_PER_FRAME} patches/frame, {args.config}.yaml, "
                                    f"steady state E={E_now} edges, random-init weights, one sequence per GPU",
-                       "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "parallelism": f"replicas x{world}" + ("" if backend == "nccl" or world == 1 else
+                       "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "drop_every": args.drop_every, "parallelism": f"replicas x{world}" + ("" if backend == "nccl" or world == 1 else
                                                                 f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
-            "roofline": roof, "roofline_update": roof_u,
+            "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg,
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
                          for i, r in enumerate(res["per_rank"])],
         }

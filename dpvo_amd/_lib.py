@@ -24,7 +24,7 @@ SYMBOLS = [
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
     "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target", "dpvo_update_workspace_bytes", "dpvo_update_forward",
-    "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_tiling", "dpvo_update_fused_start_skew",
+    "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_default_tiling",
     "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",

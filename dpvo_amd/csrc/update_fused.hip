@@ -44,6 +44,7 @@
 // Precision contract: unchanged from update.hip: Linear = f16 operands, f32 accumulate, one rounding to
 // f16; LayerNorm -> f32; residual adds in f32; gate * res is a half product.
 #include "common.h"
+#include <atomic>
 
 #ifdef FU_TRACE
 // per-workgroup timeline (100 MHz wall clock) for tools/fu_trace.py: [kernel id 8][block 1024][wave 4][stamp 16]
@@ -1663,14 +1664,19 @@ __global__ void pack_kernel(const _Float16* __restrict__ W, int64_t ldw, int K, 
   }
 }
 
-template <typename K, typename P>
-int launch(K kern, int64_t tiles, int lds, const P& p, hipStream_t st) {
-  static bool attr_done = false;          // (one flag per kernel: the template is instantiated per kernel type)
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPVO_E_UNSUPPORTED;
-    attr_done = true;
+// The kernel is a non-type template parameter, so every kernel instantiation owns its flag word: bit d = the dynamic-LDS
+// attribute has been set on device d (relaxed atomics: setting it twice is harmless, it only must not be skipped).
+template <auto KERN, typename P>
+int launch(int64_t tiles, int lds, const P& p, hipStream_t st) {
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DPVO_E_INVALID;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
+    if (hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPVO_E_UNSUPPORTED;
+    attr_done.fetch_or(bit, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), (size_t)lds, st, p);
+  hipLaunchKernelGGL(KERN, dim3((unsigned)tiles), dim3(256), (size_t)lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -1711,7 +1717,7 @@ void ws_layout(int64_t E, int64_t maxg, Ws* w) {
 #define FU_RT2C FU_RT2
 #endif
 #ifndef FU_DW2C
-#define FU_DW2C FU_DW2
+#define FU_DW2C 6            // the chain kernels fit a 6-deep ring in 250 registers at two workgroups per CU (K1 spills beyond 3)
 #endif
 #define FU_CFG_DEFAULT 3
 #define FU_DWPM 4
@@ -1728,25 +1734,13 @@ extern "C" int dpvo_update_fused_pack(const void* W, int64_t ldw, int K, int k_v
   return DPVO_OK;
 }
 
-// Tiling of the seven-launch path.  bit 0: the three chain kernels (c1, c2 + f|g, h + f|g), bit 1: the correlation kernel (K1)
-// run 64-row tiles with TWO workgroups per CU (256 registers per wave, nothing requested early: the neighbour workgroup covers
-// the round trips) instead of 96-row tiles with one (512 registers, everything prefetched).  K7 always runs 96 x 1: its phases
-// between the GEMMs are VALU work, which a second workgroup on the same SIMDs does not hide (measured: +40 us).
-// tiling < 0: query; default 3, or DPVO_FU_CFG from the environment.  Results are bit-identical across tilings.
-extern "C" int dpvo_update_fused_tiling(int tiling) {
-  static int cfg = -1;
-  if (cfg < 0) { const char* e = getenv("DPVO_FU_CFG"); cfg = e ? (atoi(e) & 3) : FU_CFG_DEFAULT; }
-  if (tiling >= 0) cfg = tiling & 3;
-  return cfg;
-}
-
-// Soft start of the seven-launch kernels in microseconds (see fu::soft_start); us < 0: query.  Default 0, or DPVO_FU_SKEW.
-extern "C" int dpvo_update_fused_start_skew(int us) {
-  static int skew = -1;
-  if (skew < 0) { const char* e = getenv("DPVO_FU_SKEW"); skew = e ? atoi(e) : 0; if (skew < 0 || skew > 1000) skew = 0; }
-  if (us >= 0) skew = us > 1000 ? 1000 : us;
-  return skew;
-}
+// Tiling of the seven-launch path (dpvo_update_fused_params_t.tiling).  bit 0: the three chain kernels (c1, c2 + f|g, h + f|g),
+// bit 1: the correlation kernel (K1) run 64-row tiles with TWO workgroups per CU (256 registers per wave, nothing requested early:
+// the neighbour workgroup covers the round trips) instead of 96-row tiles with one (512 registers, everything prefetched).  K7
+// always runs 96 x 1: its phases between the GEMMs are VALU work, which a second workgroup on the same SIMDs does not hide
+// (measured: +40 us).  Results are bit-identical across tilings.  The library keeps NO state: the tiling and the soft start
+// travel with the parameter block of each call.
+extern "C" int dpvo_update_fused_default_tiling(void) { return FU_CFG_DEFAULT; }
 
 extern "C" size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups) {
   if (E < 0 || max_groups < 0) return 0;
@@ -1784,7 +1778,8 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   constexpr int RT = FU_RT, DW = FU_DW;
   constexpr int RT2 = FU_RT2, DW2 = FU_DW2, OCC2 = FU_OCC2;
   constexpr int RT2C = FU_RT2C, DW2C = FU_DW2C;       // chain kernels' own tile height / ring at several workgroups per CU  // several workgroups per CU, 64-row tiles
-  const int cfg = dpvo_update_fused_tiling(-1), skew = dpvo_update_fused_start_skew(-1);
+  const int cfg = (p->tiling < 0 ? FU_CFG_DEFAULT : p->tiling) & 3;
+  const int skew = p->start_skew < 0 ? 0 : (p->start_skew > 1000 ? 1000 : p->start_skew);
   const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
   Ws L;
   ws_layout<RT>(E, maxg, &L);
@@ -1799,32 +1794,32 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   const int64_t tiles = cdiv64(E, 32 * RT), tiles2 = cdiv64(E, 32 * RT2), tiles2c = cdiv64(E, 32 * RT2C);
   auto lin = [&](int i) { return Lin{p->w[i], (const _Float16*)p->b[i]}; };
   int rc;
-#define FU(call) do { rc = (call); if (rc) return rc; } while (0)
+#define FU(...) do { rc = (__VA_ARGS__); if (rc) return rc; } while (0)
   {
     P1 a{lin(DPVO_UF_C0), lin(DPVO_UF_C2), lin(DPVO_UF_C5), p->ln_g[0], p->ln_b[0], p->ln_g[1], p->ln_b[1],
          (const _Float16*)corr, ld_corr, net, net_rows, n_kept, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E, skew};
-    if (cfg & 2) FU(launch(k1_corr_norm<RT2, DW2, OCC2>, tiles2, Geo<RT2>::LDS_BYTES, a, st));
-    else FU(launch(k1_corr_norm<RT, FU_DW1>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 2) FU(launch<k1_corr_norm<RT2, DW2, OCC2>>(tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    else FU(launch<k1_corr_norm<RT, FU_DW1>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C1_0), lin(DPVO_UF_C1_2), Lin{nullptr, nullptr}, Lin{nullptr, nullptr}, r16a, plan + PL.ix, img, r16b,
          nullptr, E, skew};
-    if (cfg & 1) FU(launch(k_chain<RT2C, DW2C, MODE_C1, OCC2>, tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
-    else FU(launch(k_chain<RT, DW, MODE_C1>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_C1, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
+    else FU(launch<k_chain<RT, DW, MODE_C1>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C2N_0), lin(DPVO_UF_C2N_2), lin(DPVO_UF_AKK_F), lin(DPVO_UF_AKK_G), r16b, plan + PL.jx, img, nullptr, fg,
          E, skew};
-    if (cfg & 1) FU(launch(k_chain<RT2C, DW2C, MODE_C2, OCC2>, tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
-    else FU(launch(k_chain<RT, DW, MODE_C2>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_C2, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
+    else FU(launch<k_chain<RT, DW, MODE_C2>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   int64_t ngk = n_patches_ub < 1 ? 1 : (n_patches_ub > E ? E : n_patches_ub);
   int64_t ngp = n_pairs_ub < 1 ? 1 : (n_pairs_ub > E ? E : n_pairs_ub);
   FU(dpvo_softagg(fg, 768, plan + PL.perm_k, plan + PL.patch_off, plan + PL.counts + 0, ngk, y, 384, stream));
   {
     P2 a{Lin{nullptr, nullptr}, lin(DPVO_UF_AKK_H), lin(DPVO_UF_AIJ_F), lin(DPVO_UF_AIJ_G), y, plan + PL.ku, img, nullptr, fg, E, skew};
-    if (cfg & 1) FU(launch(k_chain<RT2C, DW2C, MODE_H, OCC2>, tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
-    else FU(launch(k_chain<RT, DW, MODE_H>, tiles, Geo<RT>::LDS_BYTES, a, st));
+    if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_H, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
+    else FU(launch<k_chain<RT, DW, MODE_H>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   FU(dpvo_softagg(fg, 768, plan + PL.perm_p, plan + PL.pair_off, plan + PL.counts + 1, ngp, y, 384, stream));
   {
@@ -1836,7 +1831,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
     a.d_w = (const _Float16*)p->d_w; a.d_b = (const _Float16*)p->d_b; a.w_w = (const _Float16*)p->w_w; a.w_b = (const _Float16*)p->w_b;
     a.y = y; a.rows = plan + PL.pu; a.img = img; a.coords = coords; a.pp = P * P;
     a.net_out = net_out; a.delta = delta; a.weight = weight; a.target = target; a.E = E; a.skew = skew;
-    FU(launch(k7_gru_heads<RT, FU_DW7>, tiles, Geo<RT>::LDS_BYTES + Geo<RT>::ACT_BYTES + 4 * D * 4, a, st));
+    FU(launch<k7_gru_heads<RT, FU_DW7>>(tiles, Geo<RT>::LDS_BYTES + Geo<RT>::ACT_BYTES + 4 * D * 4, a, st));
   }
 #undef FU
   return DPVO_OK;
@@ -1916,7 +1911,7 @@ extern "C" int dpvo_update_forward_pm(const dpvo_update_fused_params_t* p, const
   if (grid_tiles > L.max_tiles) grid_tiles = L.max_tiles;
   (void)n_cu;
   int rc;
-#define FU(call) do { rc = (call); if (rc) return rc; } while (0)
+#define FU(...) do { rc = (__VA_ARGS__); if (rc) return rc; } while (0)
   {
     int64_t g = cdiv64(E, 1024);
     if (g > 64) g = 64;
@@ -1935,7 +1930,7 @@ extern "C" int dpvo_update_forward_pm(const dpvo_update_fused_params_t* p, const
     a.inp_mod = inp_mod;
     a.perm_k = plan + PL.perm_k; a.ix = plan + PL.ix; a.jx = plan + PL.jx; a.ku = plan + PL.ku;
     a.tiles = tiles; a.hdr = hdr; a.img = img; a.fg = fg; a.E = E;
-    FU(launch(ka_kernel<RT, FU_DWPM>, grid_tiles, GeoA<RT>::LDS_BYTES, a, st));
+    FU(launch<ka_kernel<RT, FU_DWPM>>(grid_tiles, GeoA<RT>::LDS_BYTES, a, st));
   }
   {
     int64_t ngp = n_pairs_ub < 1 ? 1 : (n_pairs_ub > E ? E : n_pairs_ub);
@@ -1954,7 +1949,7 @@ extern "C" int dpvo_update_forward_pm(const dpvo_update_fused_params_t* p, const
     a.y = y; a.pu = plan + PL.pu; a.perm_k = plan + PL.perm_k; a.tiles = tiles; a.hdr = hdr; a.img = img;
     a.coords = coords; a.pp = P * P;
     a.net_out = net_out; a.delta = delta; a.weight = weight; a.target = target; a.E = E;
-    FU(launch(kb_kernel<RT, FU_DWKB>, grid_tiles, GeoA<RT>::LDS_BYTES, a, st));
+    FU(launch<kb_kernel<RT, FU_DWKB>>(grid_tiles, GeoA<RT>::LDS_BYTES, a, st));
   }
   if (status) {      // device int32: 1 if a patch had more than 32 RT edges (results then undefined but memory safe)
     if (hipMemcpyAsync(status, hdr + HDR_ERR, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return DPVO_E_INVALID;

@@ -60,6 +60,10 @@ class DPVO:
         self._fs = None             # dpvo_frame_state_t, reused
         self._kf_pending = None
         self._mm_host = None
+        # keyframe_override: None, or a callable(frame counter) -> bool that REPLACES the outcome of the flow test of
+        # dpvo.py:266-270 (True = drop keyframe n - KEYFRAME_INDEX); the test kernel and its read-back still run.  For workloads
+        # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
+        self.keyframe_override = None
         self.device = torch.device(device)
         self.load_weights(network)
         self.is_initialized = False
@@ -391,7 +395,10 @@ class DPVO:
             self._plan_exact = True
             self._plan = None
 
-        if m / 2 < self.cfg.KEYFRAME_THRESH:
+        drop = m / 2 < self.cfg.KEYFRAME_THRESH
+        if self.keyframe_override is not None:
+            drop = bool(self.keyframe_override(self.counter))
+        if drop:
             k = self.n - self.cfg.KEYFRAME_INDEX
             t0 = self.pg.tstamps_[k - 1]
             t1 = self.pg.tstamps_[k]

@@ -25,12 +25,10 @@ DIM = 384
 PROFILE = None
 
 EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
-# Update.forward runs the fused row-tile kernels (update_fused.hip) unless told otherwise (DPVO_UPDATE_FUSED=0 selects the
-# launch-by-launch composite of update.hip; both stay tested against the oracle)
+# Update.forward runs the seven row-tile kernels of update_fused.hip -- always the same path, whatever the box (round 2's
+# run-time autotune between five candidates is gone: a tracker's output must not depend on a timing).  The comparators
+# (launch-by-launch update.hip, patch-major) are reached explicitly: fused=False / fused="pm" or the two environment switches.
 FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
-AUTOTUNE = bool(int(__import__("os").environ.get("DPVO_UPDATE_AUTOTUNE", "1")))    # fused vs launch-by-launch by measurement
-_AUTO_DEFAULT = {}                                                                    # device index -> the library's tiling before any tuning
-_AUTO_CHOICE = {}                                                                     # device index -> (fused?, {candidate: ms}, E it was measured at)
 PM_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_PM", "0")))      # patch-major (4 launches): opt-in, see DESIGN.md 3.4
 
 
@@ -109,7 +107,7 @@ class _UpdFusedParams(ctypes.Structure):
     """dpvo_update_fused_params_t"""
     _fields_ = [("w", ctypes.c_void_p * UF_NLIN), ("b", ctypes.c_void_p * UF_NLIN), ("ln_g", ctypes.c_void_p * 4),
                 ("ln_b", ctypes.c_void_p * 4), ("d_w", ctypes.c_void_p), ("d_b", ctypes.c_void_p), ("w_w", ctypes.c_void_p),
-                ("w_b", ctypes.c_void_p)]
+                ("w_b", ctypes.c_void_p), ("tiling", ctypes.c_int32), ("start_skew", ctypes.c_int32)]
 
 
 def fused_pack(W, K=None, chained=True):
@@ -166,6 +164,11 @@ class Update(nn.Module):
         self.ncorr = 2 * 49 * p * p
         self.kpad = (self.ncorr + 31) // 32 * 32
         self._packed = None
+        # tile shape / soft start of the seven-launch kernels: per instance, handed to the library with every call (the
+        # library keeps no state); -1 = the library's default tiling.  Bit-identical results for every value.
+        env = __import__("os").environ
+        self.tiling = int(env.get("DPVO_FU_CFG", "-1"))
+        self.start_skew = int(env.get("DPVO_FU_SKEW", "0"))
 
     # -------------------------------------------------------------------------------------- operand images
     def pack(self):
@@ -218,6 +221,7 @@ class Update(nn.Module):
                 fp.ln_g[i] = P[name][0].data_ptr()
                 fp.ln_b[i] = P[name][1].data_ptr()
             fp.d_w, fp.d_b, fp.w_w, fp.w_b = (t.data_ptr() for t in (*P["d"], *P["w"]))
+            fp.tiling, fp.start_skew = self.tiling, self.start_skew
             P["_fparams"] = fp
         self._packed = P
         return P
@@ -272,8 +276,6 @@ class Update(nn.Module):
             inp2 = inp2.half()
         inp2 = inp2.contiguous()
 
-        if fused is None and composite and net2.dtype == torch.float32:
-            fused = self._choose_path(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, coords, E, dev, P)
         if net_rows is not None:
             seven = composite and net2.dtype == torch.float32 and (fused is True or (fused is None and FUSED_DEFAULT)) and not PM_DEFAULT
             if not seven:
@@ -294,55 +296,6 @@ class Update(nn.Module):
             return res
         return self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
                                  composite, fused, patch_edges_ub, E, dev, P, net_rows)
-
-    def _choose_path(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, coords, E, dev, P):
-        """Which kernels run Update.forward when the caller does not say: the row-tile-resident ones (update_fused.hip) unless
-        DPVO_UPDATE_FUSED=0 -- or, with DPVO_UPDATE_AUTOTUNE=1 (default), whichever of the two HIP paths is faster ON THIS DEVICE,
-        measured once per process at the first full-size call (both run on scratch outputs, ~3 ms, one host sync).  Why: on about
-        one MI355X box in six, kernels with one wave per SIMD run their VALU phases ~5x slower (profiles/README.md, "slow boxes");
-        there the launch-by-launch kernels of update.hip win."""
-        global _AUTO_CHOICE
-        if not FUSED_DEFAULT:
-            return False
-        if not AUTOTUNE or E < 16384:
-            return True
-        key = (dev.index, )
-        # (measured again once the edge list has grown by half: which tiling wins depends on how E fills the CUs)
-        if key not in _AUTO_CHOICE or E > 1.5 * _AUTO_CHOICE[key][2]:
-            scratch = dict(out=torch.empty(E, DIM, dtype=torch.float32, device=dev),
-                           target_out=torch.empty(E, 2, device=dev) if coords is not None else None,
-                           weight_out=torch.empty(E, 2, device=dev))
-            times = {}
-            if key not in _AUTO_CHOICE:
-                _AUTO_DEFAULT[key] = L.lib().dpvo_update_fused_tiling(-1)
-            default_tiling = _AUTO_DEFAULT[key]
-            cands = [("fused", True, default_tiling, 0), ("launch_by_launch", False, None, 0)]
-            if default_tiling != 0:
-                cands.insert(1, ("fused_96x1", True, 0, 0))          # one workgroup per CU everywhere (the round-2a kernels)
-            # soft start: the workgroups of a launch begin in four groups 2 us apart -- for the boxes that run the first,
-            # synchronous round of workgroups of these kernels 2x slower (profiles/README.md, "slow boxes"); loses elsewhere
-            cands.insert(1, ("fused_soft_start", True, default_tiling, 8))
-            cands.insert(2, ("fused_soft_start_40", True, default_tiling, 40))
-            for name, fz, tiling, skew in cands:
-                if tiling is not None:
-                    L.lib().dpvo_update_fused_tiling(tiling)
-                    L.lib().dpvo_update_fused_start_skew(skew)
-                for rep in range(3):
-                    if rep == 1:
-                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                    self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, scratch["out"], coords,
-                                      scratch["target_out"], scratch["weight_out"], True, fz, None, E, dev, P)
-                e1.record()
-                e1.synchronize()
-                times[name] = e0.elapsed_time(e1) / 2
-            best = min(times, key=times.get)
-            if best.startswith("fused_soft_start") and times[best] > 0.97 * times["fused"]:
-                best = "fused"                                    # (within the noise of one measurement: not worth a delay)
-            L.lib().dpvo_update_fused_tiling(0 if best == "fused_96x1" else default_tiling)
-            L.lib().dpvo_update_fused_start_skew({"fused_soft_start": 8, "fused_soft_start_40": 40}.get(best, 0))
-            _AUTO_CHOICE[key] = (best != "launch_by_launch", times, E)
-        return _AUTO_CHOICE[key][0]
 
     def forward_impl(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out, composite,
                      fused, patch_edges_ub, E, dev, P, net_rows=None):
@@ -379,6 +332,7 @@ class Update(nn.Module):
                 fused = True                     # (does not fit the patch-major limits: the seven-launch path)
             if fused:
                 # seven launches of row-tile-resident kernels (update_fused.hip)
+                P["_fparams"].tiling, P["_fparams"].start_skew = self.tiling, self.start_skew
                 nbytes = L.lib().dpvo_update_fused_workspace_bytes(L.i64(E), L.i64(maxg))
                 ws = workspace.get(nbytes, dev, "update_fused")
                 rows, n_kept = net_rows[:2] if net_rows is not None else (None, 0)

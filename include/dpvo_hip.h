@@ -366,6 +366,11 @@ typedef struct {
   const float* ln_g[4];
   const float* ln_b[4];
   const void *d_w, *d_b, *w_w, *w_b;
+  /* tuning knobs of the seven-launch path (no reference counterpart), per call -- the library holds no mutable state:
+   * tiling: bit 0 = chain kernels, bit 1 = the correlation-MLP kernel use 64-row tiles with two workgroups per CU instead of
+   *   96-row tiles with one; < 0 = dpvo_update_fused_default_tiling().  start_skew: workgroup b begins (b & 3) * us / 4
+   *   microseconds late (0 = off).  Results are bit-identical for every setting. */
+  int32_t tiling, start_skew;
 } dpvo_update_fused_params_t;
 size_t dpvo_update_fused_pack_bytes(int K);
 int dpvo_update_fused_pack(const void* W, int64_t ldw, int K, int k_valid, int chained, void* out, void* stream);
@@ -378,13 +383,7 @@ int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* p, const fl
                                    float* net_out, float* delta, float* weight, float* target, int64_t E, void* ws,
                                    size_t ws_bytes, void* stream);
 size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups);
-/* Tiling of the seven-launch path (no reference counterpart: a tuning knob of this implementation).  bit 0: chain kernels,
- * bit 1: the correlation-MLP kernel use 64-row tiles with two workgroups per CU instead of 96-row tiles with one.  tiling < 0
- * only queries.  Returns the tiling in effect (default 3, or DPVO_FU_CFG).  Process-wide; results are bit-identical. */
-int dpvo_update_fused_tiling(int tiling);
-/* Soft start of those kernels: workgroup b begins (b & 3) * us / 4 microseconds late (0 = off, the default; us < 0 queries).  A
- * candidate of the autotune for boxes that throttle when all CUs enter the same phase at once; process-wide, bit-identical. */
-int dpvo_update_fused_start_skew(int us);
+int dpvo_update_fused_default_tiling(void);      /* 3 */
 int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const float* net, const void* inp,
                               const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan,
                               int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,

@@ -248,7 +248,7 @@ def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames, flavour):
 
 @pytest.mark.parametrize("E_frames", [14, 40])
 def test_fused_tilings_are_bit_identical(dev, E_frames):
-    """dpvo_update_fused_tiling: 64-row tiles with two workgroups per CU vs 96-row tiles with one, per kernel group -- the
+    """dpvo_update_fused_params_t.tiling: 64-row tiles with two workgroups per CU vs 96-row tiles with one, per kernel group -- the
     arithmetic per edge row is the same, so every output must be bit-identical across the four settings."""
     from dpvo_amd import synthetic as S
     from dpvo_amd.graph import GraphPlan
@@ -262,25 +262,35 @@ def test_fused_tilings_are_bit_identical(dev, E_frames):
     corr = torch.zeros(E, 896, dtype=torch.float16, device=dev)
     corr[:, :882] = torch.randn(E, 882, generator=g).half().to(dev)
     plan = GraphPlan(ii, jj, kk)
-    before = L.lib().dpvo_update_fused_tiling(-1)
-    try:
-        res = []
-        for tiling, skew in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 8), (0, 20)):        # (+ the soft start: a delay, nothing else)
-            assert L.lib().dpvo_update_fused_tiling(tiling) == tiling and L.lib().dpvo_update_fused_start_skew(skew) == skew
-            x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
-                               corr_is_padded=True, fused=True)
-            res.append((x.clone(), d.clone(), w.clone()))
-        for r in res[1:]:
-            for a, b in zip(res[0], r):
-                assert torch.equal(a, b)
-    finally:
-        L.lib().dpvo_update_fused_tiling(before)
-        L.lib().dpvo_update_fused_start_skew(0)
+    assert L.lib().dpvo_update_fused_default_tiling() == 3
+    res = []
+    for tiling, skew in ((0, 0), (1, 0), (2, 0), (3, 0), (-1, 0), (3, 8), (0, 20)):        # (+ the soft start: a delay, nothing else)
+        upd.tiling, upd.start_skew = tiling, skew          # per instance, per call: the library holds no state
+        x, (d, w, _) = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456,
+                           corr_is_padded=True, fused=True)
+        res.append((x.clone(), d.clone(), w.clone()))
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b)
+    # two instances with different settings in one process do not disturb each other
+    torch.manual_seed(11)
+    upd2 = N.Update(3).to(dev)
+    upd2.tiling = 0
+    upd.tiling = 3
+    xa = upd(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True)[0]
+    xb = upd2(net[None].clone(), imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True)[0]
+    assert torch.equal(xa, xb) and upd.tiling == 3 and upd2.tiling == 0
 
 
-def test_update_full_size_vs_oracle(oracle, dev):
-    """E = 45 312 (BASELINE config 2): ONE full Update.forward of the fused kernels against oracle/update_ref.py on every
-    edge (f64 math with the autocast rounding points; ~20 s of CPU).  Same stated tolerances as the small cases."""
+_FULL_ORACLE = {}
+
+
+@pytest.mark.parametrize("path", ["default", "pm", "launch_by_launch"])
+def test_update_full_size_vs_oracle(oracle, dev, path):
+    """E = 45 312 (BASELINE config 2): ONE full Update.forward against oracle/update_ref.py on every edge (f64 math with the
+    autocast rounding points; ~20 s of CPU, computed once for the three cases).  "default" is exactly what DPVO.update() and
+    bench.py run: no `fused` argument, the seven-launch kernels with the default tiling, called through the composite entry
+    with the imap table + row ids; "pm" / "launch_by_launch" are the two comparators.  Same stated tolerances as the small cases."""
     from oracle import update_ref
     from dpvo_amd import synthetic as S
     torch.manual_seed(1234)
@@ -296,11 +306,19 @@ def test_update_full_size_vs_oracle(oracle, dev):
     net = torch.randn(E, 384, generator=g); inp = torch.randn(E, 384, generator=g).half()
     corr = torch.randn(E, 882, generator=g).half()
     sd = {k: v for k, v in upd.state_dict().items()}
-    rn, rd, rw = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
+    if "ref" not in _FULL_ORACLE:
+        _FULL_ORACLE["ref"] = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
+    rn, rd, rw = _FULL_ORACLE["ref"]
     upd = upd.to(dev)
-    out, (d, w, _) = upd(net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev),
-                         fused="pm", patch_edges_ub=25)
-    assert int(upd.pm_status.view(torch.int32)[0].item()) == 0
+    args = (net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
+    if path == "default":
+        assert N.FUSED_DEFAULT and not N.PM_DEFAULT and upd.tiling == -1 and upd.start_skew == 0
+        out, (d, w, _) = upd(*args)
+    elif path == "pm":
+        out, (d, w, _) = upd(*args, fused="pm", patch_edges_ub=25)
+        assert int(upd.pm_status.view(torch.int32)[0].item()) == 0
+    else:
+        out, (d, w, _) = upd(*args, fused=False)
     H.assert_close(out[0].cpu().numpy(), rn.numpy(), 2e-2, 1e-2, "net (full size)")
     rms = float(((out[0].cpu().double() - rn) ** 2).mean().sqrt())
     assert rms < 2e-3, rms

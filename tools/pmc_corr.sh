@@ -10,8 +10,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $root
 python - <<'PY'
-import csv, glob, json
-res = {}
+import csv, glob, hashlib, json
+res = {"corr_hip_sha256": hashlib.sha256(open("dpvo_amd/csrc/corr.hip", "rb").read()).hexdigest()}   # bench.py ignores the file once the kernel source changes
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmc_corr/{c}/**/*counter_collection.csv", recursive=True)[0]
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "corr_pyramid_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
