@@ -170,6 +170,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    os.environ.setdefault("DPVO_PROFILE_EVENTS", "1")      # the tracker creates its pool of timing events up front (warm-up), not in the timed region
     from dpvo_amd import altcorr
     from dpvo_amd.altcorr import correlation as corr_mod
     from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML, FAST_YAML

@@ -29,7 +29,7 @@ SYMBOLS = [
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
-    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state",
+    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state", "dpvo_keyframe_step", "dpvo_frame_update",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_pool4_nhwc",
 ]
 
@@ -47,6 +47,37 @@ class FrameState(ctypes.Structure):
         [(k, ctypes.c_int64) for k in ("frame_next", "m_next", "E0", "n_new")] +
         [(k, ctypes.c_float) for k in ("res", "mm_scale")] +
         [(k, ctypes.c_int32) for k in ("M", "h", "w", "H", "W", "CF", "CI", "P", "mm_n", "md_n", "ap_n", "ap_r", "D")])
+
+
+class Ring(ctypes.Structure):
+    """dpvo_ring_t"""
+    _fields_ = [("base", ctypes.c_void_p), ("slot_bytes", ctypes.c_int64), ("ring", ctypes.c_int64)]
+
+
+class KeyframeStep(ctypes.Structure):
+    """dpvo_keyframe_step_t"""
+    _fields_ = ([(k, ctypes.c_void_p) for k in (
+        "ii", "jj", "kk", "net", "target", "weight", "ii_b", "jj_b", "kk_b", "net_b", "target_b", "weight_b",
+        "ii_inac", "jj_inac", "kk_inac", "target_inac", "weight_inac")] +
+        [("inac_room", ctypes.c_int64)] +
+        [(k, ctypes.c_void_p) for k in ("flow4", "poses", "delta_pose", "keep_idx", "rem_idx", "keep_rows", "result", "result_host")] +
+        [("ring", Ring * 8), ("n_ring", ctypes.c_int32), ("E", ctypes.c_int64)] +
+        [(k, ctypes.c_int32) for k in ("n", "M", "D", "keyframe_index", "removal_window", "loop_closure",
+                                       "optimization_window", "forced")] +
+        [("keyframe_thresh", ctypes.c_float)])
+
+
+class FrameUpdate(ctypes.Structure):
+    """dpvo_frame_update_t"""
+    _fields_ = ([("kf", KeyframeStep), ("fs", ctypes.c_void_p), ("ev_fs", ctypes.c_void_p), ("fs_auto", ctypes.c_int32),
+                 ("index_map", ctypes.c_void_p), ("net", ctypes.c_void_p), ("net_rows", ctypes.c_void_p), ("n_kept", ctypes.c_int64)] +
+                [(k, ctypes.c_void_p) for k in ("poses", "patches", "intrinsics", "points", "ix", "gmap", "fmap1", "fmap2",
+                                                "imap", "upd", "coords", "corr", "delta", "plan", "ws_plan", "ws_update", "ws_ba")] +
+                [(k, ctypes.c_size_t) for k in ("ws_plan_bytes", "ws_update_bytes", "ws_ba_bytes")] +
+                [("result_dev", ctypes.c_void_p), ("ev", ctypes.c_void_p * 4), ("m", ctypes.c_int64), ("n_buffer", ctypes.c_int64)] +
+                [(k, ctypes.c_int32) for k in ("P", "pmem", "mem", "H0", "W0", "H1", "W1", "patch_lifetime", "ba_window",
+                                               "iterations")] +
+                [("lmbda", ctypes.c_float), ("mm_beta", ctypes.c_float)])
 
 
 class PlanLayout(ctypes.Structure):

@@ -1,0 +1,297 @@
+// track.hip -- one tracked frame with the host off the critical path.
+//
+//   dpvo_keyframe_step : DPVO.keyframe (reference dpvo/dpvo.py:266-310) decided and executed ON THE DEVICE: flow test ->
+//                        decision, edges of the dropped keyframe removed + ids renumbered + ring buffers shifted, edges that
+//                        left the optimisation window moved to the inactive store, the rest compacted in order.  The host
+//                        only reads an 8-word result (decision + counts), one frame later if it likes.
+//   dpvo_frame_update  : DPVO.update (dpvo.py:328-360) + that keyframe step as ONE C-ABI call: the launch sequence the
+//                        Python front-end used to pace with ~10 ctypes calls (plan, reproject, correlation, update
+//                        operator, BA, point cloud, flow test, removal) is issued back to back.
+//
+// Why: the reference resolves the keyframe decision with two `.item()` synchronisations and then rebuilds every edge tensor
+// with boolean masks (dpvo.py:223-238); rounds 1-2 of this library kept a host mirror of the index arrays so that the masks
+// could be computed while the GPU was busy, which still cost ~0.25 ms of numpy per frame and paced the start of the next frame.
+// Here the masks never leave the device.
+//
+// Ordering guarantees of the compaction (bit-exact bookkeeping, tests/test_gpu_dpvo.py): both removals of the reference are
+// order preserving, so ONE stable partition of the renumbered list into (kept, inactive, dropped) yields the same active and
+// inactive lists as the reference's two passes.
+#include "common.h"
+#include "se3_dev.h"
+
+namespace {
+
+enum { RES_DECISION = 0, RES_KEEP = 1, RES_REM = 2, RES_E = 3, RES_OVERFLOW = 4 };
+
+struct Renum { int drop; int k; int M; };
+__device__ __forceinline__ void renumber(const Renum& R, int64_t& i, int64_t& j, int64_t& k) {
+  if (R.drop) {                                   // dpvo.py:281-283
+    if (i > R.k) { k -= R.M; i -= 1; }
+    if (j > R.k) j -= 1;
+  }
+}
+
+// ---- 1. decision + stable partition, two small launches: (a) every 1024-edge chunk counts its kept / inactive edges,
+//         (b) every chunk adds up the counts of the chunks before it and writes its indices in order.  (One workgroup walking
+//         all ~5 x 10^4 index triples took 95 us; this takes ~2 x 5.)
+__device__ __forceinline__ int kf_decide(const dpvo_keyframe_step_t& a) {
+  int d;
+  if (a.forced >= 0) d = a.forced ? 1 : 0;
+  else {
+    // m = motionmag(i, j) + motionmag(j, i); drop iff m / 2 < KEYFRAME_THRESH (dpvo.py:266-271).  A direction without
+    // edges gives mean = NaN in the reference (mean of an empty tensor) and the comparison is false.
+    const float s0 = a.flow4[0], n0 = a.flow4[1], s1 = a.flow4[2], n1 = a.flow4[3];
+    const float nan = __builtin_nanf("");
+    const float m = (n0 > 0.f ? s0 / n0 : nan) + (n1 > 0.f ? s1 / n1 : nan);
+    d = (m / 2.f < a.keyframe_thresh) ? 1 : 0;
+  }
+  const int k = a.n - a.keyframe_index;
+  if (k < 1 || k >= a.n) d = 0;                   // (no such keyframe: cannot happen once the tracker is initialised)
+  return d;
+}
+// class of edge e under decision d: 0 dropped with its keyframe, 1 kept, 2 moved to the inactive store
+__device__ __forceinline__ int kf_class(const dpvo_keyframe_step_t& a, int d, int64_t e) {
+  const Renum R = {d, a.n - a.keyframe_index, a.M};
+  int64_t i = a.ii[e], j = a.jj[e], k = a.kk[e];
+  if (R.drop && (i == R.k || j == R.k)) return 0;
+  renumber(R, i, j, k);
+  const int n_after = a.n - (d ? 1 : 0);
+  bool rem = (k / a.M) < n_after - a.removal_window;         // ix[kk] < n - REMOVAL_WINDOW (dpvo.py:305): index_ rows hold their frame number
+  if (a.loop_closure && rem) rem = !(((j - i) > 30) && (j > (n_after - a.optimization_window)));      // dpvo.py:307-308
+  return rem ? 2 : 1;
+}
+constexpr int KF_CHUNK = 1024;
+__global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts) {
+  __shared__ int wsum[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d = kf_decide(a);
+  const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
+  const int cls = e < a.E ? kf_class(a, d, e) : 0;
+  const unsigned long long bk = __ballot(cls == 1), br = __ballot(cls == 2);
+  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); }
+  __syncthreads();
+  if (tid == 0) {
+    int tk = 0, tr = 0;
+    for (int w = 0; w < 16; ++w) { tk += wsum[0][w]; tr += wsum[1][w]; }
+    counts[2 * blockIdx.x] = tk; counts[2 * blockIdx.x + 1] = tr;
+    if (blockIdx.x == 0 && a.delta_pose) {
+      // dP = SE3(poses[k]) * SE3(poses[k-1]).inv() (dpvo.py:276), with lietorch's store / load between the two ops
+      const int k = a.n - a.keyframe_index;
+      if (k >= 1 && k < a.n) {
+        float tmp[7];
+        store_pose(tmp, se3_inv(load_pose(a.poses + 7 * (int64_t)(k - 1))));
+        store_pose(a.delta_pose, se3_mul(load_pose(a.poses + 7 * (int64_t)k), load_pose(tmp)));
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe_step_t a, const int32_t* __restrict__ counts) {
+  __shared__ int wsum[2][16];
+  __shared__ int base[2], total[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d = kf_decide(a);
+  if (tid < 2) {                                  // exclusive prefix over the chunks before this one (<= a few dozen), and the total
+    int pre = 0, tot = 0;
+    for (int b = 0; b < (int)gridDim.x; ++b) { const int c = counts[2 * b + tid]; if (b < (int)blockIdx.x) pre += c; tot += c; }
+    base[tid] = pre; total[tid] = tot;
+  }
+  const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
+  const int cls = e < a.E ? kf_class(a, d, e) : 0;
+  const unsigned long long bk = __ballot(cls == 1), br = __ballot(cls == 2);
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int pk = __popcll(bk & below), pr = __popcll(br & below);
+  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); }
+  __syncthreads();
+  int ok = base[0], orr = base[1];
+  for (int w = 0; w < wv; ++w) { ok += wsum[0][w]; orr += wsum[1][w]; }
+  if (cls == 1) { a.keep_idx[ok + pk] = (int32_t)e; if (a.keep_rows) a.keep_rows[ok + pk] = e; }
+  if (cls == 2 && orr + pr < a.inac_room) a.rem_idx[orr + pr] = (int32_t)e;
+  if (blockIdx.x == 0 && tid == 0) {
+    int nrem = total[1], ovf = 0;
+    if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
+    a.result[RES_DECISION] = d; a.result[RES_KEEP] = total[0]; a.result[RES_REM] = nrem; a.result[RES_E] = (int32_t)a.E;
+    a.result[RES_OVERFLOW] = ovf; a.result[5] = a.result[6] = a.result[7] = 0;
+  }
+}
+
+// ---- 2. the two gathers (kept -> spare set, incl. the 1.5 KB hidden-state rows; inactive -> tail of the inactive store)
+__global__ __launch_bounds__(256) void kf_gather_kernel(const dpvo_keyframe_step_t a, int nblk_keep) {
+  const Renum R = {a.result[RES_DECISION], a.n - a.keyframe_index, a.M};
+  const bool keep_job = (int)blockIdx.x < nblk_keep;
+  const int64_t bid = keep_job ? blockIdx.x : blockIdx.x - nblk_keep, nblk = keep_job ? nblk_keep : gridDim.x - nblk_keep;
+  const int64_t gt = bid * 256 + threadIdx.x, gs = nblk * 256;
+  const int32_t* __restrict__ idx = keep_job ? a.keep_idx : a.rem_idx;
+  const int64_t n = keep_job ? a.result[RES_KEEP] : a.result[RES_REM];
+  int64_t* oi = keep_job ? a.ii_b : a.ii_inac; int64_t* oj = keep_job ? a.jj_b : a.jj_inac; int64_t* ok = keep_job ? a.kk_b : a.kk_inac;
+  float* ot = keep_job ? a.target_b : a.target_inac; float* ow = keep_job ? a.weight_b : a.weight_inac;
+  for (int64_t t = gt; t < n; t += gs) {
+    const int64_t s = idx[t];
+    int64_t i = a.ii[s], j = a.jj[s], k = a.kk[s];
+    renumber(R, i, j, k);
+    oi[t] = i; oj[t] = j; ok[t] = k;
+    ot[2 * t] = a.target[2 * s]; ot[2 * t + 1] = a.target[2 * s + 1];
+    ow[2 * t] = a.weight[2 * s]; ow[2 * t + 1] = a.weight[2 * s + 1];
+  }
+  if (keep_job && a.net_b) {
+    const int dq = a.D / 4;
+    for (int64_t q = gt; q < n * dq; q += gs) {
+      const int64_t t = q / dq;
+      const int c = (int)(q - t * dq);
+      reinterpret_cast<f4*>(a.net_b)[t * dq + c] = reinterpret_cast<const f4*>(a.net)[(int64_t)idx[t] * dq + c];
+    }
+  }
+}
+
+// ---- 3. ring buffers: slot i <- slot i + 1 for i = k .. n - 2 (dpvo.py:289-299), only if the keyframe was dropped.  A thread
+//         owns the same 16-byte piece of every slot, so the in-place chain needs no synchronisation.
+__global__ __launch_bounds__(256) void kf_shift_kernel(const dpvo_keyframe_step_t a, int blocks_per_ring) {
+  if (!a.result[RES_DECISION]) return;
+  const int r = blockIdx.x / blocks_per_ring;
+  if (r >= a.n_ring) return;
+  const dpvo_ring_t G = a.ring[r];
+  const int64_t units = G.slot_bytes / 16;
+  const int k = a.n - a.keyframe_index;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  for (int64_t u = (int64_t)(blockIdx.x - r * blocks_per_ring) * 256 + threadIdx.x; u < units; u += (int64_t)blocks_per_ring * 256) {
+    for (int i = k; i < a.n - 1; ++i) {
+      const int64_t src = G.ring ? (i + 1) % G.ring : (i + 1), dst = G.ring ? i % G.ring : i;
+      const u4v v = *reinterpret_cast<const u4v*>((const char*)G.base + src * G.slot_bytes + u * 16);
+      *reinterpret_cast<u4v*>((char*)G.base + dst * G.slot_bytes + u * 16) = v;
+    }
+  }
+  // (slot sizes that are not a multiple of 16 bytes: the tail, byte by byte, by the first block of the ring)
+  const int64_t tail0 = units * 16;
+  if (blockIdx.x == r * blocks_per_ring)
+    for (int64_t b = tail0 + threadIdx.x; b < G.slot_bytes; b += 256)
+      for (int i = k; i < a.n - 1; ++i) {
+        const int64_t src = G.ring ? (i + 1) % G.ring : (i + 1), dst = G.ring ? i % G.ring : i;
+        ((char*)G.base)[dst * G.slot_bytes + b] = ((const char*)G.base)[src * G.slot_bytes + b];
+      }
+}
+
+inline unsigned blocks_for(int64_t n, int64_t cap) {
+  int64_t g = cdiv64(n, 256);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
+  if (!a || a->E < 0 || a->E >= (1ll << 31) || a->M <= 0 || a->D <= 0 || (a->D % 4) || a->n_ring < 0 || a->n_ring > 8) return DPVO_E_INVALID;
+  if (!a->result || !a->keep_idx || !a->rem_idx || (a->forced < 0 && !a->flow4) || !a->poses) return DPVO_E_INVALID;
+  if (a->E > 0 && (!a->ii || !a->jj || !a->kk || !a->target || !a->weight || !a->ii_b || !a->jj_b || !a->kk_b || !a->target_b ||
+                   !a->weight_b || !a->ii_inac || !a->jj_inac || !a->kk_inac || !a->target_inac || !a->weight_inac))
+    return DPVO_E_INVALID;
+  if ((a->net == nullptr) != (a->net_b == nullptr)) return DPVO_E_INVALID;
+  for (int r = 0; r < a->n_ring; ++r)
+    if (!a->ring[r].base || a->ring[r].slot_bytes <= 0 || a->ring[r].ring < 0) return DPVO_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  // the per-chunk counts live behind the 8 result words: `result` has room for 8 + 2 * ceil(E / 1024) ints
+  int32_t* counts = a->result + 8;
+  const unsigned chunks = (unsigned)(a->E > 0 ? cdiv64(a->E, KF_CHUNK) : 1);
+  hipLaunchKernelGGL(kf_count_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, counts);
+  hipLaunchKernelGGL(kf_select_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, (const int32_t*)counts);
+  if (a->E > 0) {
+    const unsigned gk = blocks_for(a->net_b ? a->E * (a->D / 4) : a->E, 2048), gr = blocks_for(a->E, 16);
+    hipLaunchKernelGGL(kf_gather_kernel, dim3(gk + gr), dim3(256), 0, st, *a, (int)gk);
+  }
+  if (a->n_ring > 0) {
+    int64_t mx = 0;
+    for (int r = 0; r < a->n_ring; ++r) mx = a->ring[r].slot_bytes > mx ? a->ring[r].slot_bytes : mx;
+    const unsigned bpr = blocks_for(mx / 16, 512);
+    hipLaunchKernelGGL(kf_shift_kernel, dim3(bpr * (unsigned)a->n_ring), dim3(256), 0, st, *a, (int)bpr);
+  }
+  DPVO_LAUNCH_CHECK();
+  if (a->result_host) {
+    hipError_t e = hipMemcpyAsync(a->result_host, a->result, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
+  if (!a || !a->upd || !a->result_dev) return DPVO_E_INVALID;
+  const dpvo_keyframe_step_t& K = a->kf;
+  const int64_t E = K.E;
+  const int n = K.n, M = K.M;
+  if (E <= 0 || n < 2 || M <= 0 || a->P <= 0 || K.loop_closure) return DPVO_E_INVALID;
+  if (!a->poses || !a->patches || !a->intrinsics || !a->points || !a->ix || !a->gmap || !a->fmap1 || !a->fmap2 || !a->imap ||
+      !a->coords || !a->corr || !a->delta || !a->plan || !a->ws_plan || !a->ws_update || !a->ws_ba || !a->net)
+    return DPVO_E_INVALID;
+  if (a->net_rows && (a->n_kept < 0 || a->n_kept > E)) return DPVO_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+#define STEP(...) do { rc = (__VA_ARGS__); if (rc) return rc; } while (0)
+  // ---- the new frame's state (patch gathers, motion model, depth median, pyramid level 1, its edges): dpvo.py:400-459
+  if (a->fs) {
+    if (a->fs_auto) {
+      // frame f = n - 1 is the one being added (the caller has already counted it): its ring slots, index rows and edges
+      if (K.n_ring != 8 || !a->index_map) return DPVO_E_INVALID;
+      dpvo_frame_state_t* F = a->fs;
+      const int64_t f = n - 1;
+      auto slot = [&](int r, int64_t i) { const dpvo_ring_t& G = K.ring[r]; return (char*)G.base + (G.ring ? i % G.ring : i) * G.slot_bytes; };
+      F->colors_slot = slot(0, f); F->patches_slot = (float*)slot(2, f);
+      F->intrinsics_slot = F->intrinsics ? (float*)slot(3, f) : nullptr;
+      F->imap_slot = slot(4, f); F->gmap_slot = slot(5, f); F->fmap = slot(6, f); F->fmap2_slot = slot(7, f);
+      F->index_row = const_cast<int64_t*>(a->ix) + (f + 1) * M; F->index_map = a->index_map + (f + 1);
+      F->poses = a->poses; F->mm_n = (int)f; F->patches_all = a->patches; F->md_n = (int)f;
+      F->ii = const_cast<int64_t*>(K.ii); F->jj = const_cast<int64_t*>(K.jj); F->kk = const_cast<int64_t*>(K.kk); F->ix = a->ix;
+      const int r = a->patch_lifetime, jlo = n - r > 0 ? n - r : 0;
+      const int64_t total = (int64_t)M * ((n - 1 > 0 ? n - 1 : 0) - jlo) + (int64_t)M * (n - jlo);      // dpvo.py:362-375
+      if (total > E) return DPVO_E_INVALID;
+      F->E0 = E - total; F->ap_n = n; F->ap_r = r; F->D = K.D;
+      F->net = a->net_rows ? nullptr : a->net;            // (rows >= n_kept read as zeros when the compaction is deferred)
+      F->frame_next = f + 1; F->m_next = a->m;            // index_[f + 1] = f + 1, index_map_[f + 1] = m (after the increment)
+      F->M = M; F->P = a->P; F->h = a->H0; F->w = a->W0;
+    }
+    STEP(dpvo_frame_state(a->fs, stream));
+    if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
+  }
+  // ---- graph plan: every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
+  //      PATCH_LIFETIME frames of it (dpvo.py:305,362-375): counting-sort build over that window, bounds on the group counts
+  const int RW = K.removal_window, PL = a->patch_lifetime;
+  const int64_t nf = n < RW + 2 ? n : RW + 2;
+  const int64_t ub_p = nf * M, ub_g = nf * (2 * PL + 2);
+  const int64_t np_ub = ub_p < E ? ub_p : E, ng_ub = ub_g < E ? ub_g : E;
+  const int64_t flo = n - (RW + PL + 3) > 0 ? n - (RW + PL + 3) : 0;
+  rc = dpvo_plan_build_window(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M, stream);
+  if (rc == DPVO_E_UNSUPPORTED)
+    rc = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, stream);
+  if (rc) return rc;
+  // ---- reproject -> correlation -> update operator (dpvo.py:331-343)
+  STEP(dpvo_reproject(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->coords, E, a->P, 1, stream));
+  if (a->ev[0] && hipEventRecord((hipEvent_t)a->ev[0], st) != hipSuccess) return DPVO_E_INVALID;
+  STEP(dpvo_corr_pyramid_forward(a->gmap, a->fmap1, a->fmap2, a->coords, K.kk, K.jj, nullptr, a->corr, 896, E, 128, a->P,
+                                 (int64_t)a->pmem * M, a->mem, a->H0, a->W0, a->H1, a->W1, 3, stream));
+  if (a->ev[1] && hipEventRecord((hipEvent_t)a->ev[1], st) != hipSuccess) return DPVO_E_INVALID;
+  if (a->ev[2] && hipEventRecord((hipEvent_t)a->ev[2], st) != hipSuccess) return DPVO_E_INVALID;
+  float* net = a->net;
+  float* target = const_cast<float*>(K.target);
+  float* weight = const_cast<float*>(K.weight);
+  STEP(dpvo_update_forward_fused_rows(a->upd, net, a->net_rows, a->n_kept, a->imap, K.kk, (int64_t)a->pmem * M, a->corr, 896, a->plan, np_ub, ng_ub,
+                                      a->coords, a->P, net, a->delta, weight, target, E, a->ws_update, a->ws_update_bytes, stream));
+  if (a->ev[3] && hipEventRecord((hipEvent_t)a->ev[3], st) != hipSuccess) return DPVO_E_INVALID;
+  // ---- two local BA iterations over the last ba_window poses (dpvo.py:351-354), point cloud (:358-360)
+  int t0 = n - a->ba_window;
+  if (t0 < 1) t0 = 1;
+  STEP(dpvo_ba(a->poses, a->patches, a->intrinsics, target, weight, a->lmbda, K.ii, K.jj, K.kk, a->plan, np_ub, ng_ub, E, a->P, t0, n,
+               a->iterations, nullptr, a->ws_ba, a->ws_ba_bytes, stream));
+  STEP(dpvo_point_cloud(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, a->P, stream));
+  // ---- keyframe: flow test between frames k - 1 and k + 1 (dpvo.py:266-269), then everything else on the device
+  const int k = n - K.keyframe_index;
+  STEP(dpvo_motionmag_status(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->plan, E, a->P, k - 1, k + 1, a->mm_beta,
+                             a->result_dev, a->result_dev + 4, stream));
+  dpvo_keyframe_step_t kf = K;
+  kf.flow4 = a->result_dev;
+  kf.result = reinterpret_cast<int32_t*>(a->result_dev + 8);
+  kf.poses = a->poses;
+  void* host = kf.result_host;
+  kf.result_host = nullptr;
+  STEP(dpvo_keyframe_step(&kf, stream));
+#undef STEP
+  if (host) {
+    hipError_t e = hipMemcpyAsync(host, a->result_dev, 16 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  return DPVO_OK;
+}

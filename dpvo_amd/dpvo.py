@@ -37,6 +37,12 @@ _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # 
 # front of it.  Opt-in: the correlation kernel fills the register file, so the plan's 1024-thread workgroups only run once it
 # drains and the update operator waits for them (measured: no gain, +0.2 ms of host CPU per frame for the extra stream).
 _PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '0')
+# DPVO_FRAME_CALL=1 (default): a steady-state frame's update() + keyframe() are ONE C-ABI call (dpvo_frame_update) and the keyframe
+# decision, the edge removal, the renumbering and the ring-buffer shifts happen on the device (dpvo_keyframe_step); the host
+# reads a 16-word result one frame later.  0: the round-2 path (Python-paced launches, host mirror of the index arrays).
+_FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
+# the result read-back waits on an event created with hipEventBlockingSync: the waiting thread sleeps instead of spinning
+_BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
 
 
 class DPVO:
@@ -59,6 +65,8 @@ class DPVO:
         self._fp_done = None
         self._fs = None             # dpvo_frame_state_t, reused
         self._kf_pending = None
+        self._fu = None             # buffers + dpvo_frame_update_t of the one-call frame path
+        self._fu_pending = None
         self._mm_host = None
         # keyframe_override: None, or a callable(frame counter) -> bool that REPLACES the outcome of the flow test of
         # dpvo.py:266-270 (True = drop keyframe n - KEYFRAME_INDEX); the test kernel and its read-back still run.  For workloads
@@ -366,13 +374,17 @@ class DPVO:
         es = self.pg.edges
         to_remove = self._removal_mask(es.host())
         staged = self._stage_removal(to_remove, True)
-        return m_pending, to_remove, staged
+        forced = None if self.keyframe_override is None else bool(self.keyframe_override(self.counter))
+        return m_pending, to_remove, staged, forced
 
     def flush(self):
         """apply a deferred keyframe decision (no-op otherwise)"""
         if self._kf_pending is not None:
             pending, self._kf_pending = self._kf_pending, None
             self._keyframe_finish(*pending)
+        if self._fu_pending is not None:
+            pending, self._fu_pending = self._fu_pending, None
+            self._frame_update_finish(*pending)
 
     def keyframe(self):
         pending = self._keyframe_begin()
@@ -381,7 +393,7 @@ class DPVO:
         else:
             self._keyframe_finish(*pending)
 
-    def _keyframe_finish(self, m_pending, to_remove, staged):
+    def _keyframe_finish(self, m_pending, to_remove, staged, forced=None):
         es = self.pg.edges
         m_ij, m_ji = m_pending()            # the one host read-back of the frame
         m = m_ij + m_ji
@@ -395,9 +407,7 @@ class DPVO:
             self._plan_exact = True
             self._plan = None
 
-        drop = m / 2 < self.cfg.KEYFRAME_THRESH
-        if self.keyframe_override is not None:
-            drop = bool(self.keyframe_override(self.counter))
+        drop = (m / 2 < self.cfg.KEYFRAME_THRESH) if forced is None else forced
         if drop:
             k = self.n - self.cfg.KEYFRAME_INDEX
             t0 = self.pg.tstamps_[k - 1]
@@ -441,6 +451,179 @@ class DPVO:
             h = es.host()
             for k in ("ii", "jj", "kk"):
                 assert np.array_equal(h[k], getattr(self.pg, k).cpu().numpy()), f"edge mirror diverged ({k})"
+
+    # ------------------------------------------------------------------------------------------ one-call frame path
+    def _frame_call_ok(self, n=None):
+        from . import net as net_mod
+        n = self.n if n is None else n
+        return (_FRAME_CALL and self.is_initialized and not self.cfg.LOOP_CLOSURE and self._hip_enc is not None and self.P == 3
+                and self._gmap_cl.dtype == torch.float16 and net_mod.FUSED_DEFAULT and not net_mod.PM_DEFAULT
+                and n - self.cfg.KEYFRAME_INDEX >= 1 and self.cfg.OPTIMIZATION_WINDOW <= 20)
+
+    def _frame_update_buffers(self):
+        """persistent scratch + the two pre-filled argument blocks (one per ping-pong parity of the edge store) of
+        dpvo_frame_update, sized for the edge store's capacity"""
+        es = self.pg.edges
+        fu = self._fu
+        if fu is not None and fu["cap"] == es.cap and (es.a is fu["sets"][0] or es.a is fu["sets"][1]):
+            return fu
+        dev, cap, lib, cfg = self.device, es.cap, L.lib(), self.cfg
+        nf = cfg.REMOVAL_WINDOW + 2
+        maxg = max(nf * self.M, nf * (2 * cfg.PATCH_LIFETIME + 2))
+        i32, f32 = torch.int32, torch.float32
+        prof_on = bool(int(__import__("os").environ.get("DPVO_PROFILE_EVENTS", "0")))
+        nb = lambda n: torch.empty(max(int(n), 16), dtype=torch.uint8, device=dev)
+        fu = {"cap": cap, "sets": (es.a, es.b),
+              "coords": torch.empty(cap, 2, self.P, self.P, dtype=f32, device=dev),
+              "corr": torch.zeros(cap, 896, dtype=torch.float16, device=dev),
+              "delta": torch.empty(cap, 2, dtype=f32, device=dev),
+              "plan": torch.empty(L.plan_layout(cap).total_ints, dtype=i32, device=dev),
+              "ws_plan": nb(lib.dpvo_plan_workspace_bytes(L.i64(cap))),
+              "ws_update": nb(lib.dpvo_update_fused_workspace_bytes(L.i64(cap), L.i64(maxg))),
+              "ws_ba": nb(lib.dpvo_ba_workspace_bytes(L.i64(cap), L.i32(20))),
+              "keep": torch.empty(cap, dtype=i32, device=dev), "rem": torch.empty(cap, dtype=i32, device=dev),
+              "keep_rows": torch.empty(cap, dtype=torch.int64, device=dev), "evpos": 0,
+              # timing events for bench.py's roofline legs (HIP events around the correlation kernel / the update operator
+              # inside the call): created once, re-recorded in place -- creating events per frame costs the host ~20 us
+              "evpool": [torch.cuda.Event(enable_timing=True) for _ in range(512)] if prof_on else None,
+              "result": torch.zeros(16 + 2 * (cap // 1024 + 2), dtype=f32, device=dev),
+              "host": [torch.zeros(16, dtype=f32).pin_memory() for _ in range(2)],
+              "dpose": torch.zeros(2, 7, dtype=f32, device=dev),
+              "ev": [torch.cuda.Event() for _ in range(2)], "wait_ema": 0.0,
+              "args": [L.FrameUpdate(), L.FrameUpdate()]}
+        for e_ in (fu["evpool"] or ()):
+            e_.record()                 # (creates the HIP event handle)
+        dp = lambda t: t.data_ptr()
+        upd = self.network.update
+        fp = (upd._packed or upd.pack())["_fparams"]
+        rings = ((self.pg.colors_, 0), (self.pg.poses_, 0), (self.pg.patches_, 0), (self.pg.intrinsics_, 0), (self.imap_, self.pmem),
+                 (self._gmap_cl, self.pmem), (self._fmap1_cl, self.mem), (self._fmap2_cl, self.mem))
+        hh, ww = self._fmap1_cl.shape[1:3]
+        for par in (0, 1):
+            a = fu["args"][par]
+            kf = a.kf
+            A, B = fu["sets"][par], fu["sets"][par ^ 1]
+            # (the hidden state is not moved by the keyframe step: net / net_b stay NULL, the kept rows' old numbers go to
+            #  keep_rows and the next update operator gathers them in its first kernel, dpvo_update_forward_fused_rows)
+            kf.ii, kf.jj, kf.kk, kf.target, kf.weight = dp(A["ii"]), dp(A["jj"]), dp(A["kk"]), dp(A["target"]), dp(A["weight"])
+            kf.ii_b, kf.jj_b, kf.kk_b, kf.target_b, kf.weight_b = dp(B["ii"]), dp(B["jj"]), dp(B["kk"]), dp(B["target"]), dp(B["weight"])
+            kf.delta_pose = dp(fu["dpose"]) + 28 * par
+            kf.keep_idx, kf.rem_idx, kf.result_host = dp(fu["keep"]), dp(fu["rem"]), fu["host"][par].data_ptr()
+            kf.keep_rows = dp(fu["keep_rows"])
+            a.index_map = dp(self.pg.index_map_)
+            for r, (t, ring) in enumerate(rings):
+                kf.ring[r].base, kf.ring[r].slot_bytes, kf.ring[r].ring = dp(t), t.stride(0) * t.element_size(), ring
+            kf.n_ring, kf.M, kf.D = len(rings), self.M, es.D
+            kf.keyframe_index, kf.removal_window, kf.loop_closure = cfg.KEYFRAME_INDEX, cfg.REMOVAL_WINDOW, 0
+            kf.optimization_window, kf.keyframe_thresh = cfg.OPTIMIZATION_WINDOW, cfg.KEYFRAME_THRESH
+            a.poses, a.patches, a.intrinsics, a.points, a.ix = (dp(self.pg.poses_), dp(self.pg.patches_), dp(self.pg.intrinsics_),
+                                                                dp(self.pg.points_), dp(self.pg.index_))
+            a.gmap, a.fmap1, a.fmap2, a.imap = dp(self._gmap_cl), dp(self._fmap1_cl), dp(self._fmap2_cl), dp(self.imap_)
+            a.upd = ctypes.addressof(fp)
+            a.coords, a.corr, a.delta, a.plan = dp(fu["coords"]), dp(fu["corr"]), dp(fu["delta"]), dp(fu["plan"])
+            a.ws_plan, a.ws_update, a.ws_ba = dp(fu["ws_plan"]), dp(fu["ws_update"]), dp(fu["ws_ba"])
+            a.ws_plan_bytes, a.ws_update_bytes, a.ws_ba_bytes = fu["ws_plan"].numel(), fu["ws_update"].numel(), fu["ws_ba"].numel()
+            a.result_dev = dp(fu["result"])
+            a.n_buffer = self.N
+            a.P, a.pmem, a.mem, a.H0, a.W0 = self.P, self.pmem, self.mem, hh, ww
+            a.H1, a.W1 = self._fmap2_cl.shape[1:3]
+            a.patch_lifetime, a.ba_window, a.iterations, a.lmbda, a.mm_beta = cfg.PATCH_LIFETIME, cfg.OPTIMIZATION_WINDOW, 2, 1e-4, 0.5
+        fu["fparams"] = fp
+        self._fu = fu
+        return fu
+
+    def _frame_update_call(self, fs=None):
+        """DPVO.update() + DPVO.keyframe() (dpvo.py:328-360,266-310) of a steady-state frame as one library call (with `fs`, a
+        filled dpvo_frame_state_t, also the new frame's state stores and edges in front of it); the keyframe decision is taken
+        and executed on the device, its result is consumed by flush() -- at the start of the next call."""
+        from . import net as net_mod
+        from .altcorr import correlation as corr_mod
+        es, inac, cfg = self.pg.edges, self.pg.edges_inac, self.cfg
+        fu = self._frame_update_buffers()
+        par = 0 if es.a is fu["sets"][0] else 1
+        E, n = es.E, self.n
+        room = min(E, 8 * self.M * cfg.PATCH_LIFETIME)
+        inac.reserve(room)
+        a = fu["args"][par]
+        kf = a.kf
+        I, o = inac.a, inac.E
+        kf.ii_inac, kf.jj_inac, kf.kk_inac = I["ii"].data_ptr() + 8 * o, I["jj"].data_ptr() + 8 * o, I["kk"].data_ptr() + 8 * o
+        kf.target_inac, kf.weight_inac, kf.inac_room = I["target"].data_ptr() + 8 * o, I["weight"].data_ptr() + 8 * o, room
+        kf.E, kf.n = E, n
+        kf.forced = -1 if self.keyframe_override is None else int(bool(self.keyframe_override(self.counter)))
+        upd = self.network.update
+        fu["fparams"].tiling, fu["fparams"].start_skew = upd.tiling, upd.start_skew
+        a.net = es.a["net"].data_ptr()
+        if es.net_pending is not None:
+            a.net_rows, a.n_kept = es.net_pending[0].data_ptr(), es.net_pending[1]
+        else:
+            a.net_rows, a.n_kept = None, 0
+        for i, lst in enumerate((corr_mod.PROFILE, net_mod.PROFILE)):
+            if lst is not None:         # bench.py: HIP events around the correlation kernel / the update operator, from a pool whose
+                pool = fu["evpool"]     # handles exist already (the call re-records them in place)
+                if pool is None:
+                    pool = fu["evpool"] = [torch.cuda.Event(enable_timing=True) for _ in range(512)]
+                if not pool[0].cuda_event:
+                    for e_ in pool:
+                        e_.record()
+                pos = fu["evpos"]
+                fu["evpos"] = (pos + 2) % len(pool)
+                e0, e1 = pool[pos], pool[pos + 1]
+                a.ev[2 * i], a.ev[2 * i + 1] = e0.cuda_event, e1.cuda_event
+                lst.append((e0, e1, E))
+            elif a.ev[2 * i]:
+                a.ev[2 * i] = a.ev[2 * i + 1] = None
+        a.m = self.m
+        if fs is not None:
+            a.fs, a.ev_fs, a.fs_auto = ctypes.addressof(fs), (self._fp_done.cuda_event if self._fp_done is not None else None), 1
+        else:
+            a.fs = a.ev_fs = None
+        L.check(L.lib().dpvo_frame_update(ctypes.byref(a), L.stream()), "dpvo_frame_update")
+        es.net_pending = None           # (gathered by the operator's first kernel, rewritten compact by its last one)
+        ev = fu["ev"][par]
+        ev.record()
+        self._plan = None
+        self._fu_pending = (ev, fu["host"][par], par, n, E, __import__("time").perf_counter())
+
+    def _frame_update_finish(self, ev, host, flip, n, E, t_enq):
+        """the host side of the keyframe step whose device side dpvo_keyframe_step has already executed (dpvo.py:266-310)"""
+        # The result lands when the GPU has finished the frame, ~1 ms after it was enqueued; the host gets here after ~0.3 ms.
+        # Sleep through most of the expected rest (running mean of the last waits), then wait on the event: a spinning wait from
+        # the start would burn a host core per tracker for nothing.
+        import time
+        fu = self._fu
+        if _BLOCKING_SYNC and not ev.query():
+            rest = fu["wait_ema"] - (time.perf_counter() - t_enq)
+            if rest > 2.5e-4:
+                time.sleep(rest - 2.0e-4)
+        ev.synchronize()
+        fu["wait_ema"] = 0.8 * fu["wait_ema"] + 0.2 * (time.perf_counter() - t_enq) if fu["wait_ema"] else (time.perf_counter() - t_enq)
+        res = host.view(torch.int32)[8:13].tolist()
+        decision, n_keep, n_rem, e_in, overflow = res
+        if e_in != E or overflow:
+            raise L.DPVOHipError(f"dpvo_keyframe_step: inconsistent result {res} for E = {E}")
+        st = [int(v) for v in host[4:8].tolist()]
+        if st[3] != 0 and not getattr(self, "_plan_exact", False):
+            import warnings
+            warnings.warn("dpvo_amd: an edge fell outside the window the graph plan was sized for "
+                          f"(counters {st}); switching to exact plans", RuntimeWarning)
+            self._plan_exact = True
+        es, inac = self.pg.edges, self.pg.edges_inac
+        if decision:
+            k = n - self.cfg.KEYFRAME_INDEX
+            t0 = self.pg.tstamps_[k - 1]
+            t1 = self.pg.tstamps_[k]
+            self.pg.delta[t1] = (t0, SE3(self._fu["dpose"][flip].clone()))
+            self.pg.tstamps_[k:n - 1] = self.pg.tstamps_[k + 1:n]
+            self.n -= 1
+            self.m -= self.M
+        es.a, es.b = es.b, es.a
+        es.a["net"], es.b["net"] = es.b["net"], es.a["net"]       # the state stays where it is ...
+        es.net_pending = (fu["keep_rows"][:n_keep], n_keep)        # ... until the next update operator gathers it (or a reader asks)
+        es.E = n_keep
+        inac.E += n_rem
+        es.invalidate_host()
+        self._plan = None
 
     def __run_global_BA(self):
         """ Global bundle adjustment
@@ -591,7 +774,7 @@ class DPVO:
         image_u8 = image.contiguous()
         H, W = image_u8.shape[-2:]
         hip_enc = self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM'
-        side = pre_rng = None
+        side = pre_rng = fs_deferred = None
         appended = False
         if hip_enc and self.overlap_encoders:
             if self._enc_stream is None:
@@ -608,27 +791,29 @@ class DPVO:
                 side.wait_event(image_ready)
         main_stream = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(side if side is not None else main_stream):
+            if hip_enc and side is not None and patch_coords is None and depth_init is None and self.P == 3:
+                # the frame's three random draws (same generator order as the serial path) depend on nothing: issued FIRST on
+                # the side stream -- behind the encoders they sat on the frame's critical path (the next frame starts when the
+                # side stream is done)
+                hh_, ww_ = self._fmap1_cl.shape[1:3]
+                pre_rng = (torch.randint(1, ww_ - 1, size=[1, self.M], device=self.device),
+                           torch.randint(1, hh_ - 1, size=[1, self.M], device=self.device),
+                           torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device))
+                for t_ in pre_rng:
+                    t_.record_stream(main_stream)        # allocated on the side stream, read on the main one
             img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
             img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
             L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),
                                                  L.stream()), "dpvo_normalize_image")
             maps = None
             if hip_enc:
-                # both encoders as 15 MFMA launches, fmap written straight into its channels-last ring slot
+                # both encoders as MFMA launches, fmap written straight into its channels-last ring slot
                 # (the reference also writes fmap1_[n % mem] before the motion probe may reject the frame, dpvo.py:437)
                 slot = self._fmap1_cl[self.n % self.mem]
                 if self._imap_full is None:
                     self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
                 self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
                 if side is not None:
-                    if patch_coords is None and depth_init is None and self.P == 3:
-                        # the frame's three random draws (same generator order as below) do not depend on anything either
-                        hh, ww = slot.shape[:2]
-                        pre_rng = (torch.randint(1, ww - 1, size=[1, self.M], device=self.device),
-                                   torch.randint(1, hh - 1, size=[1, self.M], device=self.device),
-                                   torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device))
-                        for t_ in pre_rng:
-                            t_.record_stream(main_stream)        # allocated on the side stream, read on the main one
                     enc_done = torch.cuda.Event()
                     enc_done.record(side)
         if hip_enc:
@@ -684,24 +869,31 @@ class DPVO:
                     fs = self._fs = L.FrameState()
                 dp = lambda t: None if t is None else t.data_ptr()
                 rp = lambda t, i: t.data_ptr() + int(i) * t.stride(0) * t.element_size()
-                fs.fmap, fs.imap, fs.img_u8, fs.coords = dp(maps[0]), dp(maps[1]), dp(image_u8), dp(cdev)
+                fast_call = self._frame_call_ok(n + 1) and not getattr(self, "_plan_exact", False)
+                fs.imap, fs.img_u8, fs.coords = dp(maps[1]), dp(image_u8), dp(cdev)
                 fs.xs, fs.ys, fs.depth, fs.intrinsics = dp(xs), dp(ys), dp(depth), dp(intr_dev)
-                fs.gmap_slot, fs.imap_slot = rp(self._gmap_cl, n % self.pmem), rp(self.imap_, n % self.pmem)
-                fs.patches_slot, fs.colors_slot = rp(self.pg.patches_, n), rp(self.pg.colors_, n)
-                fs.intrinsics_slot = rp(self.pg.intrinsics_, n) if intr_dev is not None else None
-                fs.index_row, fs.index_map = rp(self.pg.index_, n + 1), rp(self.pg.index_map_, n + 1)
-                fs.poses, fs.mm_n, fs.mm_scale = dp(self.pg.poses_), n, self.cfg.MOTION_DAMPING * fac
-                fs.patches_all, fs.md_n = dp(self.pg.patches_), n
-                fs.fmap2_slot = rp(self._fmap2_cl, n % self.mem)
-                # (no in-place zeroing of the new state rows while a deferred compaction is pending: live rows may still sit there)
-                fs.ii, fs.jj, fs.kk, fs.ix = dp(es.a["ii"]), dp(es.a["jj"]), dp(es.a["kk"]), dp(self.ix)
-                fs.net = dp(es.a["net"]) if es.net_pending is None else None
-                fs.frame_next, fs.m_next, fs.E0, fs.n_new = n + 1, self.m + self.M, es.E, 0
-                fs.res = self.RES
-                fs.M, fs.h, fs.w, fs.H, fs.W, fs.CF, fs.CI, fs.P = self.M, hh, ww, H, W, 128, self.DIM, self.P
-                fs.ap_n, fs.ap_r, fs.D = n + 1, self.cfg.PATCH_LIFETIME, es.D
-                L.check(L.lib().dpvo_frame_state(ctypes.byref(fs), L.stream()), "dpvo_frame_state")
-                assert fs.n_new == total
+                fs.mm_scale, fs.res = self.cfg.MOTION_DAMPING * fac, self.RES
+                fs.H, fs.W, fs.CF, fs.CI = H, W, 128, self.DIM
+                if not fast_call:       # (dpvo_frame_update derives everything that depends on the frame number itself)
+                    fs.fmap = dp(maps[0])
+                    fs.gmap_slot, fs.imap_slot = rp(self._gmap_cl, n % self.pmem), rp(self.imap_, n % self.pmem)
+                    fs.patches_slot, fs.colors_slot = rp(self.pg.patches_, n), rp(self.pg.colors_, n)
+                    fs.intrinsics_slot = rp(self.pg.intrinsics_, n) if intr_dev is not None else None
+                    fs.index_row, fs.index_map = rp(self.pg.index_, n + 1), rp(self.pg.index_map_, n + 1)
+                    fs.poses, fs.mm_n = dp(self.pg.poses_), n
+                    fs.patches_all, fs.md_n = dp(self.pg.patches_), n
+                    fs.fmap2_slot = rp(self._fmap2_cl, n % self.mem)
+                    # (no in-place zeroing of the new state rows while a deferred compaction is pending: live rows may still sit there)
+                    fs.ii, fs.jj, fs.kk, fs.ix = dp(es.a["ii"]), dp(es.a["jj"]), dp(es.a["kk"]), dp(self.ix)
+                    fs.net = dp(es.a["net"]) if es.net_pending is None else None
+                    fs.frame_next, fs.m_next, fs.E0, fs.n_new = n + 1, self.m + self.M, es.E, 0
+                    fs.M, fs.h, fs.w, fs.P = self.M, hh, ww, self.P
+                    fs.ap_n, fs.ap_r, fs.D = n + 1, self.cfg.PATCH_LIFETIME, es.D
+                # (the one-call frame path issues it itself, in front of the plan: no Python between the two)
+                fs_deferred = fs if fast_call else None
+                if fs_deferred is None:
+                    L.check(L.lib().dpvo_frame_state(ctypes.byref(fs), L.stream()), "dpvo_frame_state")
+                    assert fs.n_new == total
                 es.appended_frame(n + 1, self.M, self.cfg.PATCH_LIFETIME, total)
                 self._plan = None
                 appended = True
@@ -729,8 +921,12 @@ class DPVO:
                 L.check(L.lib().dpvo_pool4_nhwc(L.ptr(maps[0]), L.row_ptr(self._fmap2_cl, self.n % self.mem), L.i32(hh), L.i32(ww),
                                                 L.i32(128), L.stream()), "dpvo_pool4_nhwc")
             if self.overlap_encoders:
-                self._fp_done = torch.cuda.Event()
-                self._fp_done.record()
+                if self._fp_done is None:
+                    self._fp_done = torch.cuda.Event()
+                if fs_deferred is None:
+                    self._fp_done.record()
+                elif not self._fp_done.cuda_event:
+                    self._fp_done.record()              # (creates the handle; re-recorded behind dpvo_frame_state inside the call)
         else:
             fmap, gmap, imap, patches, _, coords = \
                 self.network.patchify(img32 if img32 is not None else img16,
@@ -821,5 +1017,10 @@ class DPVO:
                 self.update()
 
         elif self.is_initialized:
-            self.update()
-            self.keyframe()
+            if fs_deferred is not None or (self._frame_call_ok() and not getattr(self, "_plan_exact", False)):
+                self._frame_update_call(fs_deferred)
+                if not self.defer_keyframe:
+                    self.flush()
+            else:
+                self.update()
+                self.keyframe()

@@ -402,6 +402,74 @@ int dpvo_update_forward_pm(const dpvo_update_fused_params_t* params, const float
                            float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One tracked frame, host off the critical path  (DPVO.update + DPVO.keyframe, dpvo/dpvo.py:266-360)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* dpvo_keyframe_step: DPVO.keyframe (dpvo.py:266-310) WITHOUT a host decision.  On the device, in stream order:
+ *   1. decision: drop keyframe k = n - keyframe_index iff (s0/n0 + s1/n1) / 2 < keyframe_thresh, with (s0, n0, s1, n1) =
+ *      flow4 = the output of dpvo_motionmag for (k - 1, k + 1) (dpvo.py:266-270); `forced` >= 0 replaces the test (0 keep, 1 drop);
+ *   2. if dropped: delta_pose = P[k] * P[k-1]^-1 (dpvo.py:276), the edges with ii == k or jj == k leave (remove_factors(...,
+ *      store=False), :279), the ids above k are renumbered (:281-283) and ring slots k+1 .. n-1 of every per-frame buffer in
+ *      `ring` move down one slot (:289-299);  n' = n - 1, else n' = n;
+ *   3. the edges whose source frame kk / M < n' - removal_window leave to the inactive store (remove_factors(..., store=True),
+ *      :305-310; with loop_closure != 0 the long-range edges of :307-308 stay), the others are compacted in order into the
+ *      spare arrays (*_b).
+ * result (device, 8 x int32 followed by 2 * ceil(E / 1024) ints of scratch; the 8 words are also copied to result_host if not
+ * NULL -- pinned memory, asynchronous):
+ *   [0] decision, [1] edges kept, [2] edges moved to the inactive store, [3] E, [4] 1 if the inactive room was too small
+ *   (nothing written beyond it).  The caller swaps its array sets and updates its counters when it reads the result --
+ *   one frame later, if it likes: nothing on the device waits for the host. */
+typedef struct { void* base; int64_t slot_bytes; int64_t ring; } dpvo_ring_t;   /* ring = 0: slot i lives at i, else at i % ring */
+typedef struct {
+  const int64_t *ii, *jj, *kk; const float *net, *target, *weight;             /* active edges (E) */
+  int64_t *ii_b, *jj_b, *kk_b; float *net_b, *target_b, *weight_b;             /* spare set: receives the kept edges */
+  int64_t *ii_inac, *jj_inac, *kk_inac; float *target_inac, *weight_inac;      /* tail of the inactive store */
+  int64_t inac_room;
+  const float* flow4; const float* poses; float* delta_pose;
+  int32_t *keep_idx, *rem_idx;                                                 /* scratch, E ints each */
+  int64_t* keep_rows;               /* optional [E]: the kept edges' old row numbers as int64 -- with net == net_b == NULL the hidden
+                                       state is NOT moved and this list is what dpvo_update_forward_fused_rows takes as net_rows */
+  int32_t* result; void* result_host;
+  dpvo_ring_t ring[8]; int32_t n_ring;
+  int64_t E;
+  int32_t n, M, D, keyframe_index, removal_window, loop_closure, optimization_window, forced;
+  float keyframe_thresh;
+} dpvo_keyframe_step_t;
+int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream);
+
+/* dpvo_frame_update: DPVO.update() + DPVO.keyframe() of one steady-state frame (dpvo.py:328-360,266-310; no loop closure)
+ * as ONE call: graph plan (window build, ranged fallback), reproject, two-level correlation, update operator (seven
+ * launches), two local BA iterations, point cloud, flow test, dpvo_keyframe_step, result copy.  Every pointer is a caller
+ * buffer (capacity buffers + workspaces sized with the *_workspace_bytes functions for E); ev[0..3] (hipEvent_t or NULL) are
+ * recorded before / after the correlation kernel and before / after the update operator (roofline measurement).
+ * result_dev: 16 words -- [0..3] flow sums, [4..7] plan counters (float), [8..15] the dpvo_keyframe_step result -- followed by
+ * that step's 2 * ceil(E / 1024) ints of scratch.  fs (may be NULL): a dpvo_frame_state to issue first (the new frame's patch
+ * gathers, state stores and edges: everything between the encoders and the plan), with ev_fs (hipEvent_t or NULL) recorded
+ * right behind it. */
+typedef struct {
+  dpvo_keyframe_step_t kf;          /* edge arrays, rings, decision parameters; kf.flow4 / kf.result are set by the call */
+  dpvo_frame_state_t* fs; void* ev_fs;
+  int32_t fs_auto;                  /* != 0: the call fills the fields of *fs that depend on the frame number (ring slots, index rows,
+                                       edge arrays and counts) from kf.ring[] (order: colours, poses, patches, intrinsics, imap, gmap,
+                                       fmap1, fmap2), index_map and the counters; the caller sets the per-frame inputs only */
+  int64_t* index_map;
+  float* net;                       /* hidden state [capacity, D], updated in place; kf.net / kf.net_b NULL: rows are not moved by the
+                                       keyframe step, the previous step's keep_rows come back as net_rows / n_kept (NULL: compact) */
+  const int64_t* net_rows; int64_t n_kept;
+  float *poses, *patches, *intrinsics, *points; const int64_t* ix;
+  const void *gmap, *fmap1, *fmap2, *imap;
+  const dpvo_update_fused_params_t* upd;
+  float* coords; void* corr; float* delta; int32_t* plan;
+  void *ws_plan, *ws_update, *ws_ba; size_t ws_plan_bytes, ws_update_bytes, ws_ba_bytes;
+  float* result_dev;
+  void* ev[4];
+  int64_t m, n_buffer;              /* patches so far; BUFFER_SIZE */
+  int32_t P, pmem, mem, H0, W0, H1, W1, patch_lifetime, ba_window, iterations;
+  float lmbda, mm_beta;
+} dpvo_frame_update_t;
+int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * feature encoders  (Patchifier.fnet / .inet: dpvo/extractor.py:200-264, called at dpvo/net.py:116-117)
  * ---------------------------------------------------------------------------------------------- */
 

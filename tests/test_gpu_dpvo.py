@@ -15,8 +15,13 @@ from dpvo_amd.net import VONet
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, overlap=False):
+def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, overlap=False, frame_call=True):
+    """frame_call: steady-state frames through dpvo_frame_update + the device-side keyframe step (default), or the
+    Python-paced round-2 path with its host mirror (DPVO_FRAME_CALL=0)"""
     from oracle.graph_ref import GraphRef
+    import dpvo_amd.dpvo as dpvo_mod
+    fc_before = dpvo_mod._FRAME_CALL
+    dpvo_mod._FRAME_CALL = frame_call
     cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
     cfg.PATCHES_PER_FRAME = M
     cfg.BUFFER_SIZE = 256
@@ -36,6 +41,7 @@ def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, o
         res = (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
         return (lambda: res) if defer else res
     pops.motionmag_pair = fake
+    slam.keyframe_override = lambda counter: state["drop"]        # (the one-call path takes the scripted decision this way)
     try:
         for t, (accept, drop) in enumerate(decisions):
             state["accept"], state["drop"] = accept, drop
@@ -54,15 +60,17 @@ def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, o
             assert slam.pg.net.shape == (1, ref.ii.size, 384) and slam.pg.net.dtype == torch.float32
     finally:
         pops.motionmag_pair = orig
+        dpvo_mod._FRAME_CALL = fc_before
     return slam, ref, calls
 
 
-def test_bookkeeping_bit_exact_and_state_sane(dev):
+@pytest.mark.parametrize("frame_call", [True, False])
+def test_bookkeeping_bit_exact_and_state_sane(dev, frame_call):
     # skip two frames before init, then track; drop some keyframes, keep others
     decisions = [(True, False)] * 3 + [(False, False)] * 2 + [(True, False)] * 9 + [(True, True)] * 3 + \
                 [(True, False)] * 22 + [(True, True), (True, False), (True, True)] + [(True, False)] * 4
-    slam, ref, calls = _run(dev, decisions)
-    assert slam.is_initialized and len(calls) > 20
+    slam, ref, calls = _run(dev, decisions, frame_call=frame_call)
+    assert slam.is_initialized and (frame_call or len(calls) > 20)
     n = slam.n
     P = slam.pg.poses_[:n]
     assert torch.isfinite(P).all()
@@ -98,6 +106,46 @@ def test_deferred_keyframe_is_bit_identical(dev):
     assert np.array_equal(pa, pb)
 
 
+def test_device_keyframe_step_equals_the_host_path(dev):
+    """dpvo_frame_update + dpvo_keyframe_step (decision, removal of the dropped keyframe's edges, renumbering, ring shifts and
+    the window removal all on the device, one C call per frame) against the Python-paced path with its host-side masks: the
+    same tracker state bit for bit -- edges (active and inactive), hidden state, targets / weights, poses, depths, feature rings,
+    the final trajectory -- in every mode (immediate, deferred, overlapped).  The relative pose stored for a dropped frame
+    (dpvo.py:276) is computed inside dpvo_keyframe_step instead of by two lietorch launches: same formulas, but the compiler
+    contracts multiply-adds per translation unit, so it agrees to f32 rounding (1e-6) with the host path and bit for bit
+    between the modes of the device path."""
+    decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 20 + [(True, True), (True, False), (True, True)] + \
+                [(True, True)] * 3 + [(True, False)] * 6
+    ref_run, rr, _ = _run(dev, decisions, seed=7, frame_call=False)
+    first = None
+    for kw in (dict(), dict(defer=True, check=False), dict(defer=True, check=False, overlap=True)):
+        a, _, _ = _run(dev, decisions, seed=7, frame_call=True, **kw)
+        a.flush()
+        torch.cuda.synchronize()
+        b = ref_run
+        assert a.n == b.n == rr.n and a.m == b.m and a.pg.edges.E == b.pg.edges.E and a.pg.edges_inac.E == b.pg.edges_inac.E
+        for k in ("ii", "jj", "kk", "ii_inac", "jj_inac", "kk_inac", "net", "target", "weight", "target_inac", "weight_inac"):
+            assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)), (kw, k)
+        n = a.n
+        for k in ("poses_", "patches_", "intrinsics_", "colors_"):
+            assert torch.equal(getattr(a.pg, k)[:n], getattr(b.pg, k)[:n]), (kw, k)
+        assert np.array_equal(a.pg.tstamps_[:n], b.pg.tstamps_[:n])
+        for k in ("_fmap1_cl", "_fmap2_cl", "_gmap_cl", "imap_"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (kw, k)
+        assert set(a.pg.delta.keys()) == set(b.pg.delta.keys())
+        for t in a.pg.delta:
+            assert a.pg.delta[t][0] == b.pg.delta[t][0], (kw, t)
+            assert (a.pg.delta[t][1].data - b.pg.delta[t][1].data).abs().max().item() < 1e-6, (kw, t)
+            if first is not None:
+                assert torch.equal(a.pg.delta[t][1].data, first.pg.delta[t][1].data), (kw, t)
+        first = first or a
+    pa, ta = a.terminate()
+    pf, _ = first.terminate()
+    pb, tb = ref_run.terminate()
+    assert np.array_equal(pa, pf) and np.array_equal(ta, tb)
+    assert np.abs(pa - pb).max() < 1e-5
+
+
 def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
     """remove_factors with the compaction of `net` folded into the update operator's first kernel (EdgeStore.keep(defer_net=True),
     dpvo_update_forward_fused_rows) against compacting at once: same tracker state bit for bit, over kept and dropped keyframes
@@ -106,11 +154,11 @@ def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
     decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 24 + [(True, True), (True, False), (True, True)] + \
                 [(True, False)] * 4
     monkeypatch.setattr(D, "_DEFER_NET", True)
-    a, ra, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True)
+    a, ra, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True, frame_call=False)
     a.flush()
     assert a._deferred_removals > 0                     # (the deferred path really ran)
     monkeypatch.setattr(D, "_DEFER_NET", False)
-    b, rb, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True)
+    b, rb, _ = _run(dev, decisions, seed=9, defer=True, check=False, overlap=True, frame_call=False)
     b.flush()
     torch.cuda.synchronize()
     assert a.n == b.n and a.pg.edges.E == b.pg.edges.E
@@ -125,10 +173,10 @@ def test_plan_on_a_third_stream_is_bit_identical(dev, monkeypatch):
     """DPVO_PLAN_ASYNC=1: the graph plan built on its own stream beside reproject / corr, joined before the update operator"""
     import dpvo_amd.dpvo as D
     decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 16
-    a, _, _ = _run(dev, decisions, seed=4, defer=True, check=False, overlap=True)
+    a, _, _ = _run(dev, decisions, seed=4, defer=True, check=False, overlap=True, frame_call=False)
     a.flush()
     monkeypatch.setattr(D, "_PLAN_ASYNC", "1")
-    b, _, _ = _run(dev, decisions, seed=4, defer=True, check=False, overlap=True)
+    b, _, _ = _run(dev, decisions, seed=4, defer=True, check=False, overlap=True, frame_call=False)
     b.flush()
     torch.cuda.synchronize()
     assert b.plan_async and b._plan_stream is not None and not a.plan_async
@@ -235,6 +283,7 @@ def test_bookkeeping_matches_the_reference_dpvo_class(dev):
         res = (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
         return (lambda: res) if defer else res
     pops.motionmag_pair = fake
+    slam.keyframe_override = lambda counter: state["drop"]
     o = {"E": 0, "Ei": 0, "t": 0}
     try:
         for t, (accept, drop) in enumerate(decisions):

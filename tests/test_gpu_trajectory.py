@@ -43,6 +43,7 @@ def test_trajectory_matches_oracle_pipeline(dev):
         res = (0.0, 0.0) if state["drop"] else (4 * thresh, 4 * thresh)
         return (lambda: res) if defer else res
     pops.motionmag_pair = fake
+    slam.keyframe_override = lambda counter: state["drop"]       # (the one-call frame path takes the scripted decision this way)
     g = torch.Generator().manual_seed(seed)
     intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
     # a smooth texture translating a few pixels per frame (so that the correlation has structure)
