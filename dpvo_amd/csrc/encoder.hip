@@ -10,7 +10,11 @@
 //     then 9 taps x Cin/32 chunks of v_mfma_f32_16x16x32_f16 run from LDS; weights stream from L1/L2;
 //   * the epilogue adds the bias, rounds to f16 exactly where autocast rounds, stores NHWC and emits per-workgroup
 //     (sum, sum^2) partials per channel; the CONSUMER reduces them in a fixed order (deterministic InstanceNorm);
-//   * fnet (InstanceNorm) and inet (no norm) share every launch (grid.z = encoder).
+//   * fnet (InstanceNorm) and inet (no norm) share every launch (grid.z = encoder);
+//   * a residual block's output relu(fx(x) + relu(fy(y))) (extractor.py:44-55) is not a launch of its own: the convolution that
+//     consumes it forms it while staging its halo (from the two raw tensors and their statistics) and writes the interior of
+//     its tile back for the later readers; the stride-2 1x1 "downsample" convolution of layer2.0 is the centre tap of that
+//     block's first 3x3 stride-2 convolution and runs in the same launch: 10 launches per frame instead of 15.
 #include "common.h"
 
 namespace {
@@ -27,10 +31,23 @@ struct EncPtrs {                         // one per encoder (z = 0 fnet, z = 1 i
   const _Float16* bias;                  // [Cout]
   _Float16* out;                         // NHWC raw conv output (bias added, f16)
   double* out_part;                      // this conv's (sum, sum^2) accumulators [2][64] (zeroed by the host) or null
-  int in_mode;                           // 0 identity, 1 relu, 2 instance-norm + relu
+  int in_mode;                           // 0 identity, 1 relu, 2 instance-norm + relu, 3 residual-block output of (in, in2)
   int cout;                              // number of output channels of THIS encoder for this layer
   float out_scale;                       // multiplies the rounded f16 output (the "/ 4.0" of net.py:116-117)
+  // in_mode 3: the input is relu(fx(in) + relu(fy(in2))) (extractor.py:44-55), formed while the halo is staged
+  const _Float16* in2; const double* in2_part;
+  int x_mode, y_mode;                    // x: 0 identity, 1 relu, 2 instance-norm, 3 instance-norm + relu; y: 1 relu, 3 instance-norm + relu
+  _Float16* mat_out;                     // the interior of the tile of that tensor is written here (its later readers), or null
+  // DS kernels: a second, 1x1 convolution of the same input at the same stride (the centre tap): layer2.0.downsample
+  const _Float16* w2; const _Float16* bias2; _Float16* out2; double* out2_part;
 };
+__host__ __device__ inline EncPtrs enc_ptrs(const _Float16* in, const double* in_part, const _Float16* w, const _Float16* bias, _Float16* out,
+                                            double* out_part, int in_mode, int cout, float out_scale) {
+  EncPtrs p{};
+  p.in = in; p.in_part = in_part; p.w = w; p.bias = bias; p.out = out; p.out_part = out_part; p.in_mode = in_mode; p.cout = cout;
+  p.out_scale = out_scale;
+  return p;
+}
 struct EncArgs { EncPtrs e[2]; };
 #ifdef ENC_TRACE
 __device__ unsigned long long g_enc_trace[2048][8];
@@ -61,7 +78,7 @@ __device__ __forceinline__ void reduce_stats(const double* acc, int /*unused*/, 
 // ---------------------------------------------------------------------------------------------------
 // conv KSxKS (KS = 3 pad 1, or KS = 1 pad 0), stride S, Cin in {32,64}, 64 output channels per workgroup (blockIdx.y)
 // ---------------------------------------------------------------------------------------------------
-template <int CIN, int KS, int S, int NT>
+template <int CIN, int KS, int S, int NT, bool DS = false>
 __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Win, int Hout, int Wout, int n_part_in) {
   constexpr int PAD = KS / 2;
   constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
@@ -70,7 +87,9 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   _Float16* halo = reinterpret_cast<_Float16*>(smem_raw);   // [IH][IW][CIN] swizzled
   float* s_mean = reinterpret_cast<float*>(smem_raw + (size_t)IH * IW * CIN * 2);
   float* s_rstd = s_mean + CIN;
-  float* s_red = s_rstd + CIN;                              // [4 waves][2][64]
+  float* s_mean2 = s_rstd + CIN;                            // (residual input: statistics of the second operand)
+  float* s_rstd2 = s_mean2 + CIN;
+  float* s_red = s_rstd2 + CIN;                             // [4 waves][2][64]
 
   const EncPtrs P = args.e[blockIdx.z];
   const int n0 = blockIdx.y * (16 * NT);
@@ -81,7 +100,8 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   ENC_T(0);
-  if (P.in_mode == 2) reduce_stats<CIN>(P.in_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean, s_rstd);
+  if (P.in_mode == 2 || (P.in_mode == 3 && P.x_mode >= 2)) reduce_stats<CIN>(P.in_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean, s_rstd);
+  if (P.in_mode == 3 && P.y_mode >= 2) reduce_stats<CIN>(P.in2_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean2, s_rstd2);
   __syncthreads();
   ENC_T(1);
 
@@ -93,6 +113,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
     constexpr int NCHUNK = IH * IW * CPP, NPT = (NCHUNK + 255) / 256;
     h8 pf[NPT];
     unsigned inimg = 0;
+    const bool dual = P.in_mode == 3;
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
       const int q = tid + 256 * k;
@@ -105,6 +126,47 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
         inimg |= 1u << k;
       }
     }
+    if (dual) {
+      // relu(fx(x) + relu(fy(y))): the second operand's loads are issued before anything of the first is consumed; the
+      // arithmetic and its f16 rounding points are those of the former resout kernel (= the reference's f16 tensors)
+      h8 pg[NPT];
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) {
+        const int q = tid + 256 * k;
+        const int ch = q % CPP, pix = q / CPP;
+        const int ly = pix / IW, lx = pix - ly * IW;
+        pg[k] = (h8)(_Float16)0;
+        if ((inimg >> k) & 1) pg[k] = *reinterpret_cast<const h8*>(P.in2 + ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) {
+        const int q = tid + 256 * k;
+        if (q < NCHUNK) {
+          const int ch = q % CPP, pix = q / CPP;
+          const int ly = pix / IW, lx = pix - ly * IW;
+          h8 v = (h8)(_Float16)0;
+          if ((inimg >> k) & 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int c = ch * 8 + e;
+              _Float16 a = pf[k][e], b = pg[k][e];
+              if (P.x_mode >= 2) a = (_Float16)(((float)a - s_mean[c]) * s_rstd[c]);
+              if (P.x_mode & 1) a = a > (_Float16)0 ? a : (_Float16)0;
+              if (P.y_mode >= 2) b = (_Float16)(((float)b - s_mean2[c]) * s_rstd2[c]);
+              b = b > (_Float16)0 ? b : (_Float16)0;
+              const _Float16 sum = a + b;                               // f16 add (x + y on f16 tensors)
+              v[e] = sum > (_Float16)0 ? sum : (_Float16)0;
+            }
+            // the tile's own pixels of the block output go back to memory for its other readers (the skip connection of the
+            // next block, the second convolution of a stride-2 block): every pixel is the interior of exactly one tile
+            if (P.mat_out && blockIdx.y == 0 && ly >= PAD && ly < PAD + TH * S && lx >= PAD && lx < PAD + TW * S)
+              *reinterpret_cast<h8*>(P.mat_out + ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8) = v;
+          }
+          const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+          *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
       const int q = tid + 256 * k;
@@ -128,18 +190,29 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
         *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
       }
     }
+    }
   }
   __syncthreads();
 
   ENC_T(2);
   // ---- implicit GEMM: wave w owns output rows 2w, 2w+1 (4 M-tiles of 16 pixels), 4 N-tiles (64 channels)
   f4 acc[4][NT];
+  f4 acc2[DS ? 4 : 1][DS ? NT : 1];                          // DS: the 1x1 convolution on the centre tap
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f4)0.f;
+    for (int j = 0; j < NT; ++j) { acc[i][j] = (f4)0.f; if constexpr (DS) acc2[i][j] = (f4)0.f; }
   const int m = lane & 15, kg = lane >> 4;
   const int ncout = P.cout;
+  h8 fw2[DS ? NT : 1];
+  if constexpr (DS) {
+    static_assert(!DS || (KS == 3 && CIN == 32), "centre-tap second convolution: 3x3, one 32-channel k-step");
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + m;
+      fw2[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w2 + (int64_t)n * 32 + kg * 8) : (h8)(_Float16)0;
+    }
+  }
   constexpr int K = KS * KS * CIN;
   // flat k-steps t = (kh*KS + kw)*(CIN/32) + kc; the filter fragments of step t+2 are fetched (L2) while step t runs:
   // un-prefetched they were a dependent ~0.5 us round trip per step (9 us of a 23 us workgroup for 2 us of MFMA)
@@ -166,17 +239,24 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % (PD + 1)][j], fa, acc[i][j], 0, 0, 0);
+      if constexpr (DS) {
+        if (kh == KS / 2 && kw == KS / 2) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw2[j], fa, acc2[i][j], 0, 0, 0);
+        }
+      }
     }
   }
 
   ENC_T(3);
   // ---- epilogue: bias, f16 rounding, NHWC store, per-channel partial statistics of the ROUNDED values
+  auto epilogue = [&](auto& A, const _Float16* bias, _Float16* out, double* out_part) {
   float ssum[NT][4], ssq[NT][4];
   h4 bias4[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 16 + kg * 4;
-    bias4[j] = (n < ncout) ? *reinterpret_cast<const h4*>(P.bias + n) : (h4)(_Float16)0;
+    bias4[j] = (n < ncout) ? *reinterpret_cast<const h4*>(bias + n) : (h4)(_Float16)0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
   }
@@ -192,15 +272,15 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       h4 hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        hv[r] = (_Float16)(acc[i][j][r] + (float)bv[r]);
+        hv[r] = (_Float16)(A[i][j][r] + (float)bv[r]);
         if (inb) { const float f = (float)hv[r]; ssum[j][r] += f; ssq[j][r] += f * f; }
         hv[r] = (_Float16)((float)hv[r] * P.out_scale);
       }
-      if (inb) *reinterpret_cast<h4*>(P.out + ((int64_t)oy * Wout + ox) * ncout + n) = hv;
+      if (inb) *reinterpret_cast<h4*>(out + ((int64_t)oy * Wout + ox) * ncout + n) = hv;
     }
   }
   ENC_T(4);
-  if (P.out_part) {
+  if (out_part) {
     // reduce over the 16 pixel lanes (xor 1,2,4,8 keeps kg), then over the 4 waves through LDS, fixed order
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -217,10 +297,14 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       if (c < 16 * NT && n0 + c < ncout) {
         const float v = ((s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c]) +
                          (s_red[(2 * 2 + which) * 64 + c] + s_red[(3 * 2 + which) * 64 + c]));
-        unsafeAtomicAdd(&P.out_part[(blockIdx.x % kStatCopies) * 128 + which * 64 + n0 + c], (double)v);
+        unsafeAtomicAdd(&out_part[(blockIdx.x % kStatCopies) * 128 + which * 64 + n0 + c], (double)v);
       }
     }
+    __syncthreads();                        // (s_red is reused by a second epilogue)
   }
+  };
+  epilogue(acc, P.bias, P.out, P.out_part);
+  if constexpr (DS) epilogue(acc2, P.bias2, P.out2, P.out2_part);
   ENC_T(5);
 }
 
@@ -328,53 +412,14 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// residual-block output (extractor.py:44-55): out = relu(fx(x) + relu(fy(y))), f = InstanceNorm (from partials) or id;
-// all intermediate roundings to f16 at the points the reference (f16 tensors) has them.
-// ---------------------------------------------------------------------------------------------------
-struct ResPtrs {
-  const _Float16* x; const double* x_part; int x_mode;      // 0 identity, 1 relu, 2 instance-norm, 3 instance-norm + relu
-  const _Float16* y; const double* y_part; int y_mode;      // 1 relu, 3 instance-norm + relu
-  _Float16* out;
-};
-struct ResArgs { ResPtrs e[2]; };
-
-template <int C>
-__global__ __launch_bounds__(256) void resout_kernel(ResArgs args, int64_t npix, int n_part_x, int n_part_y) {
-  __shared__ float mx[C], rx[C], my[C], ry[C];
-  const ResPtrs P = args.e[blockIdx.y];
-  if (P.x_mode >= 2) reduce_stats<C>(P.x_part, n_part_x, 1.0f / (float)npix, mx, rx);
-  if (P.y_mode >= 2) reduce_stats<C>(P.y_part, n_part_y, 1.0f / (float)npix, my, ry);
-  __syncthreads();
-  const int64_t nchunk = npix * (C / 8);
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nchunk; q += (int64_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(q % (C / 8));
-    h8 xv = *reinterpret_cast<const h8*>(P.x + q * 8);
-    h8 yv = *reinterpret_cast<const h8*>(P.y + q * 8);
-    h8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = ch * 8 + k;
-      _Float16 a = xv[k], b = yv[k];
-      if (P.x_mode >= 2) a = (_Float16)(((float)a - mx[c]) * rx[c]);
-      if (P.x_mode & 1) a = a > (_Float16)0 ? a : (_Float16)0;
-      if (P.y_mode >= 2) b = (_Float16)(((float)b - my[c]) * ry[c]);
-      b = b > (_Float16)0 ? b : (_Float16)0;
-      const _Float16 s = a + b;                               // f16 add (x + y on f16 tensors)
-      o[k] = s > (_Float16)0 ? s : (_Float16)0;
-    }
-    *reinterpret_cast<h8*>(P.out + q * 8) = o;
-  }
-}
-
-template <int CIN, int KS, int S, int NT>
+template <int CIN, int KS, int S, int NT, bool DS = false>
 int launch_conv(const EncArgs& a, int Hin, int Win, int Hout, int Wout, int n_part_in, int cout_max, hipStream_t st) {
   constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
-  const size_t sh = (size_t)IH * IW * CIN * 2 + (2 * CIN + 4 * 2 * 64) * 4;
-  (void)hipFuncSetAttribute((const void*)conv_kernel<CIN, KS, S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  const size_t sh = (size_t)IH * IW * CIN * 2 + (4 * CIN + 4 * 2 * 64) * 4;
+  (void)hipFuncSetAttribute((const void*)conv_kernel<CIN, KS, S, NT, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   const int tiles = ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW);
-  hipLaunchKernelGGL((conv_kernel<CIN, KS, S, NT>), dim3(tiles, (cout_max + 16 * NT - 1) / (16 * NT), 2), dim3(256), sh, st, a, Hin, Win, Hout,
-                     Wout, n_part_in);
+  hipLaunchKernelGGL((conv_kernel<CIN, KS, S, NT, DS>), dim3(tiles, (cout_max + 16 * NT - 1) / (16 * NT), 2), dim3(256), sh, st, a, Hin, Win,
+                     Hout, Wout, n_part_in);
   return (int)hipGetLastError();
 }
 
@@ -398,7 +443,7 @@ extern "C" size_t dpvo_encoders_workspace_bytes(int H, int W) {
   const size_t h2 = H / 2, w2 = W / 2, h4 = H / 4, w4 = W / 4;
   const size_t a32 = enc_al(h2 * w2 * 32 * 2), a64 = enc_al(h4 * w4 * 64 * 2);
   const size_t t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW);
-  return 2 * (3 * a32 + 3 * a64) + enc_al((size_t)2 * 10 * kStatCopies * 128 * 8) + 4096;
+  return 2 * (4 * a32 + 4 * a64) + enc_al((size_t)2 * 10 * kStatCopies * 128 * 8) + 4096;
 }
 
 // fmap_out [H/4][W/4][128], imap_out [H/4][W/4][384] f16 NHWC, both already divided by 4 (net.py:116-117).
@@ -412,10 +457,10 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
   const size_t a32 = enc_al((size_t)h2 * w2 * 32 * 2), a64 = enc_al((size_t)h4 * w4 * 64 * 2);
   const int t2 = ((h2 + TH - 1) / TH) * ((w2 + TW - 1) / TW), t4 = ((h4 + TH - 1) / TH) * ((w4 + TW - 1) / TW);
   char* base = (char*)ws;
-  _Float16 *A[2][3], *B[2][3];
+  _Float16 *A[2][4], *B[2][4];
   for (int z = 0; z < 2; ++z) {
-    for (int i = 0; i < 3; ++i) { A[z][i] = (_Float16*)base; base += a32; }
-    for (int i = 0; i < 3; ++i) { B[z][i] = (_Float16*)base; base += a64; }
+    for (int i = 0; i < 4; ++i) { A[z][i] = (_Float16*)base; base += a32; }
+    for (int i = 0; i < 4; ++i) { B[z][i] = (_Float16*)base; base += a64; }
   }
   // ten (sum, sum^2) accumulator sets per tower, one per statistics-producing conv, zeroed once per forward
   double* Sacc = (double*)base;
@@ -428,54 +473,57 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
     for (int i = 0; i < 10; ++i) Pt[z][i] = Sacc + ((size_t)z * 10 + i) * kStatCopies * 128;
   auto Wp = [&](int z, int i) { return (const _Float16*)weights[z * 22 + i]; };
   const bool nm[2] = {true, false};                       // fnet: instance norm, inet: none (net.py:98-99)
-  const int64_t np2 = (int64_t)h2 * w2, np4 = (int64_t)h4 * w4;
-  (void)t4;
   int rc;
   EncArgs a;
-  ResArgs r;
   const int cin_mode[2] = {2, 1};                         // consumer-side transform of a raw conv output: IN+relu | relu
-  const unsigned rgrid2 = (unsigned)((np2 * 4 + 255) / 256 < 2048 ? (np2 * 4 + 255) / 256 : 2048);
-  const unsigned rgrid4 = (unsigned)((np4 * 8 + 255) / 256 < 2048 ? (np4 * 8 + 255) / 256 : 2048);
 #define STATS(z, i) (nm[z] ? Pt[z][i] : nullptr)
 
+  // Residual-block outputs are formed by their first consumer (in_mode 3) and written back by it (mat_out):
+  //   X1 = relu(f(A0) + relu(f(A2)))  by layer1.1.conv1 -> A1      X2 = relu(X1 + relu(f(A0')))  by layer2.0.conv1 (+ downsample) -> A2
+  //   X3 = relu(f(B2) + relu(f(B1)))  by layer2.1.conv1 -> B3      X4 = relu(X3 + relu(f(B1')))  by conv2 (not stored)
+  auto res = [&](EncPtrs p, const _Float16* y, const double* y_part, int x_mode, int y_mode, _Float16* mat) {
+    p.in_mode = 3; p.in2 = y; p.in2_part = y_part; p.x_mode = x_mode; p.y_mode = y_mode; p.mat_out = mat;
+    return p;
+  };
   // conv1 (7x7 s2) -> A0 raw, stats P0; x0 = relu(norm1(A0)) is applied on the fly by its consumers      :252-254
-  for (int z = 0; z < 2; ++z) a.e[z] = {nullptr, nullptr, Wp(z, 0), Wp(z, 1), A[z][0], STATS(z, 0), 0, 32, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(nullptr, nullptr, Wp(z, 0), Wp(z, 1), A[z][0], STATS(z, 0), 0, 32, 1.0f);
   hipLaunchKernelGGL(conv1_kernel, dim3(t2, 1, 2), dim3(256), 0, st, (const _Float16*)image_f16, a, H, W, h2, w2);
 
-  // ---- layer1.0 (ResidualBlock 32->32, :44-55): c1 -> A1 (P1), c2 -> A2 (P2), out -> A1
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], STATS(z, 0), Wp(z, 2), Wp(z, 3), A[z][1], STATS(z, 1), cin_mode[z], 32, 1.0f};
+  // ---- layer1.0 (ResidualBlock 32->32, :44-55): c1: x0 -> A1 (P1), c2 -> A2 (P2)
+  for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][0], STATS(z, 0), Wp(z, 2), Wp(z, 3), A[z][1], STATS(z, 1), cin_mode[z], 32, 1.0f);
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][1], STATS(z, 1), Wp(z, 4), Wp(z, 5), A[z][2], STATS(z, 2), cin_mode[z], 32, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][1], STATS(z, 1), Wp(z, 4), Wp(z, 5), A[z][2], STATS(z, 2), cin_mode[z], 32, 1.0f);
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {A[z][0], STATS(z, 0), nm[z] ? 3 : 1, A[z][2], STATS(z, 2), nm[z] ? 3 : 1, A[z][1]};
-  hipLaunchKernelGGL(resout_kernel<32>, dim3(rgrid2, 2), dim3(256), 0, st, r, np2, t2, t2);
-  // ---- layer1.1: input X1 = A1; c1 -> A0 (P0), c2 -> A2 (P1), out -> A0
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][1], nullptr, Wp(z, 6), Wp(z, 7), A[z][0], STATS(z, 3), 0, 32, 1.0f};
+  // ---- layer1.1: input X1 = relu(x0 + relu(f(A2))) formed here and written to A1; c1 -> A3 (P3), c2 -> A0 (P4)
+  for (int z = 0; z < 2; ++z)
+    a.e[z] = res(enc_ptrs(A[z][0], STATS(z, 0), Wp(z, 6), Wp(z, 7), A[z][3], STATS(z, 3), 3, 32, 1.0f), A[z][2], STATS(z, 2),
+                 nm[z] ? 3 : 1, nm[z] ? 3 : 1, A[z][1]);
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], STATS(z, 3), Wp(z, 8), Wp(z, 9), A[z][2], STATS(z, 4), cin_mode[z], 32, 1.0f};
+  for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][3], STATS(z, 3), Wp(z, 8), Wp(z, 9), A[z][0], STATS(z, 4), cin_mode[z], 32, 1.0f);
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {A[z][1], nullptr, 0, A[z][2], STATS(z, 4), nm[z] ? 3 : 1, A[z][0]};
-  hipLaunchKernelGGL(resout_kernel<32>, dim3(rgrid2, 2), dim3(256), 0, st, r, np2, t2, t2);
-  // ---- layer2.0 (32->64, stride 2): input X2 = A0; c1 -> B0 (P0), c2 -> B1 (P2), downsample -> B2 (P3), out -> B0
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 10), Wp(z, 11), B[z][0], STATS(z, 5), 0, 64, 1.0f};
-  if ((rc = launch_conv<32, 3, 2, 4>(a, h2, w2, h4, w4, 0, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], STATS(z, 5), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 6), cin_mode[z], 64, 1.0f};
+  // ---- layer2.0 (32->64, stride 2): input X2 = relu(X1 + relu(f(A0))) formed here and written to A2;
+  //      c1 -> B0 (P5) and, on the centre tap, downsample (1x1 stride 2) -> B2 (P7) in the same launch; c2 -> B1 (P6)
+  for (int z = 0; z < 2; ++z) {
+    a.e[z] = res(enc_ptrs(A[z][1], nullptr, Wp(z, 10), Wp(z, 11), B[z][0], STATS(z, 5), 3, 64, 1.0f), A[z][0], STATS(z, 4), 0,
+                 nm[z] ? 3 : 1, A[z][2]);
+    a.e[z].w2 = Wp(z, 14); a.e[z].bias2 = Wp(z, 15); a.e[z].out2 = B[z][2]; a.e[z].out2_part = STATS(z, 7);
+  }
+  if ((rc = launch_conv<32, 3, 2, 4, true>(a, h2, w2, h4, w4, t2, 64, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(B[z][0], STATS(z, 5), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 6), cin_mode[z], 64, 1.0f);
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {A[z][0], nullptr, Wp(z, 14), Wp(z, 15), B[z][2], STATS(z, 7), 0, 64, 1.0f};
-  if ((rc = launch_conv<32, 1, 2, 4>(a, h2, w2, h4, w4, 0, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][2], STATS(z, 7), nm[z] ? 2 : 0, B[z][1], STATS(z, 6), nm[z] ? 3 : 1, B[z][0]};
-  hipLaunchKernelGGL(resout_kernel<64>, dim3(rgrid4, 2), dim3(256), 0, st, r, np4, t4, t4);
-  // ---- layer2.1: input X3 = B0; c1 -> B1 (P0), c2 -> B2 (P1), out -> B1
-  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][0], nullptr, Wp(z, 16), Wp(z, 17), B[z][1], STATS(z, 8), 0, 64, 1.0f};
-  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, 0, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) a.e[z] = {B[z][1], STATS(z, 8), Wp(z, 18), Wp(z, 19), B[z][2], STATS(z, 9), cin_mode[z], 64, 1.0f};
+  // ---- layer2.1: input X3 = relu(norm(B2) + relu(f(B1))) formed here and written to B3; c1 -> B0 (P8), c2 -> B1 (P9)
+  for (int z = 0; z < 2; ++z)
+    a.e[z] = res(enc_ptrs(B[z][2], STATS(z, 7), Wp(z, 16), Wp(z, 17), B[z][0], STATS(z, 8), 3, 64, 1.0f), B[z][1], STATS(z, 6),
+                 nm[z] ? 2 : 0, nm[z] ? 3 : 1, B[z][3]);
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
-  for (int z = 0; z < 2; ++z) r.e[z] = {B[z][0], nullptr, 0, B[z][2], STATS(z, 9), nm[z] ? 3 : 1, B[z][1]};
-  hipLaunchKernelGGL(resout_kernel<64>, dim3(rgrid4, 2), dim3(256), 0, st, r, np4, t4, t4);
-  // ---- conv2 (1x1, 64 -> 128 | 384), output / 4.0                                                     :259, net.py:116-117
-  a.e[0] = {B[0][1], nullptr, Wp(0, 20), Wp(0, 21), (_Float16*)fmap_out, nullptr, 0, 128, 0.25f};
-  a.e[1] = {B[1][1], nullptr, Wp(1, 20), Wp(1, 21), (_Float16*)imap_out, nullptr, 0, 384, 0.25f};
-  if ((rc = launch_conv<64, 1, 1, 4>(a, h4, w4, h4, w4, 0, 384, st))) return rc;
+  for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(B[z][0], STATS(z, 8), Wp(z, 18), Wp(z, 19), B[z][1], STATS(z, 9), cin_mode[z], 64, 1.0f);
+  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
+  // ---- conv2 (1x1, 64 -> 128 | 384) on X4 = relu(X3 + relu(f(B1))), output / 4.0                        :259, net.py:116-117
+  a.e[0] = res(enc_ptrs(B[0][3], nullptr, Wp(0, 20), Wp(0, 21), (_Float16*)fmap_out, nullptr, 3, 128, 0.25f), B[0][1], STATS(0, 9), 0,
+               nm[0] ? 3 : 1, nullptr);
+  a.e[1] = res(enc_ptrs(B[1][3], nullptr, Wp(1, 20), Wp(1, 21), (_Float16*)imap_out, nullptr, 3, 384, 0.25f), B[1][1], STATS(1, 9), 0,
+               nm[1] ? 3 : 1, nullptr);
+  if ((rc = launch_conv<64, 1, 1, 4>(a, h4, w4, h4, w4, t4, 384, st))) return rc;
 #undef STATS
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;

@@ -481,7 +481,8 @@ int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream);
  *   then weight / bias pairs -- weight as [K/32][Cout][32] where K = (kh, kw, cin) is the flattened filter, i.e. the
  *   [Cout][kh][kw][Cin] tensor cut into 32-wide k-steps with the k-step index outermost -- of layer1.0.conv1, layer1.0.conv2, layer1.1.conv1, layer1.1.conv2,
  *   layer2.0.conv1 (stride 2), layer2.0.conv2, layer2.0.downsample.0 (1x1 stride 2), layer2.1.conv1, layer2.1.conv2,
- *   conv2 (1x1).  15 launches for both towers (MIOpen path: ~114). */
+ *   conv2 (1x1).  10 launches for both towers (MIOpen path: ~114): a residual block output is formed by the convolution that
+ *   consumes it, layer2.0.downsample rides on the centre tap of layer2.0.conv1. */
 size_t dpvo_encoders_workspace_bytes(int H, int W);
 int dpvo_encoders_forward(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out, int H, int W,
                           void* ws, size_t ws_bytes, void* stream);
