@@ -111,62 +111,78 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
     // all global loads of this thread first (they are independent), then the transform + LDS writes: the naive
     // load -> normalise -> store loop is a chain of ~1 us round trips (measured: 4.7 us of a 23 us workgroup)
     constexpr int NCHUNK = IH * IW * CPP, NPT = (NCHUNK + 255) / 256;
-    h8 pf[NPT];
+    // (the stride-2 kernel's 17 x 65 halo is 18 chunks per thread: it only exists for residual inputs, which are staged in
+    //  batches -- holding 18 chunks of a single input in registers would cost it its second workgroup per CU)
+    constexpr bool DUAL_ONLY = (S == 2 && KS == 3);
+    h8 pf[DUAL_ONLY ? 1 : NPT];
     unsigned inimg = 0;
-    const bool dual = P.in_mode == 3;
+    const bool dual = DUAL_ONLY || P.in_mode == 3;
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
       const int q = tid + 256 * k;
       const int ch = q % CPP, pix = q / CPP;
       const int ly = pix / IW, lx = pix - ly * IW;
       const int y = iy0 + ly, x = ix0 + lx;
-      pf[k] = (h8)(_Float16)0;
+      if constexpr (!DUAL_ONLY) pf[k] = (h8)(_Float16)0;
       if (q < NCHUNK && y >= 0 && y < Hin && x >= 0 && x < Win) {
-        pf[k] = *reinterpret_cast<const h8*>(P.in + ((int64_t)y * Win + x) * CIN + ch * 8);
+        if constexpr (!DUAL_ONLY) { if (!dual) pf[k] = *reinterpret_cast<const h8*>(P.in + ((int64_t)y * Win + x) * CIN + ch * 8); }
         inimg |= 1u << k;
       }
     }
     if (dual) {
-      // relu(fx(x) + relu(fy(y))): the second operand's loads are issued before anything of the first is consumed; the
-      // arithmetic and its f16 rounding points are those of the former resout kernel (= the reference's f16 tensors)
-      h8 pg[NPT];
+      // relu(fx(x) + relu(fy(y))): the arithmetic and its f16 rounding points are those of the reference's f16 tensors
+      // (extractor.py:44-55).  Both operands of a batch of KB chunks are requested before anything is consumed; batches keep
+      // the staging registers at 2 x KB x 4 (the 17 x 65 halo of the stride-2 kernel is 18 chunks per thread)
+      constexpr int KB = 6;
 #pragma unroll
-      for (int k = 0; k < NPT; ++k) {
-        const int q = tid + 256 * k;
-        const int ch = q % CPP, pix = q / CPP;
-        const int ly = pix / IW, lx = pix - ly * IW;
-        pg[k] = (h8)(_Float16)0;
-        if ((inimg >> k) & 1) pg[k] = *reinterpret_cast<const h8*>(P.in2 + ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8);
-      }
+      for (int k0 = 0; k0 < NPT; k0 += KB) {
+        h8 px[KB], pg[KB];
 #pragma unroll
-      for (int k = 0; k < NPT; ++k) {
-        const int q = tid + 256 * k;
-        if (q < NCHUNK) {
+        for (int kk = 0; kk < KB; ++kk) {
+          const int k = k0 + kk;
+          if (k >= NPT) break;
+          const int q = tid + 256 * k;
           const int ch = q % CPP, pix = q / CPP;
           const int ly = pix / IW, lx = pix - ly * IW;
-          h8 v = (h8)(_Float16)0;
+          px[kk] = pg[kk] = (h8)(_Float16)0;
           if ((inimg >> k) & 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int c = ch * 8 + e;
-              _Float16 a = pf[k][e], b = pg[k][e];
-              if (P.x_mode >= 2) a = (_Float16)(((float)a - s_mean[c]) * s_rstd[c]);
-              if (P.x_mode & 1) a = a > (_Float16)0 ? a : (_Float16)0;
-              if (P.y_mode >= 2) b = (_Float16)(((float)b - s_mean2[c]) * s_rstd2[c]);
-              b = b > (_Float16)0 ? b : (_Float16)0;
-              const _Float16 sum = a + b;                               // f16 add (x + y on f16 tensors)
-              v[e] = sum > (_Float16)0 ? sum : (_Float16)0;
-            }
-            // the tile's own pixels of the block output go back to memory for its other readers (the skip connection of the
-            // next block, the second convolution of a stride-2 block): every pixel is the interior of exactly one tile
-            if (P.mat_out && blockIdx.y == 0 && ly >= PAD && ly < PAD + TH * S && lx >= PAD && lx < PAD + TW * S)
-              *reinterpret_cast<h8*>(P.mat_out + ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8) = v;
+            const int64_t o = ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8;
+            px[kk] = *reinterpret_cast<const h8*>(P.in + o);
+            pg[kk] = *reinterpret_cast<const h8*>(P.in2 + o);
           }
-          const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
-          *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          const int k = k0 + kk;
+          if (k >= NPT) break;
+          const int q = tid + 256 * k;
+          if (q < NCHUNK) {
+            const int ch = q % CPP, pix = q / CPP;
+            const int ly = pix / IW, lx = pix - ly * IW;
+            h8 v = (h8)(_Float16)0;
+            if ((inimg >> k) & 1) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int c = ch * 8 + e;
+                _Float16 a = px[kk][e], b = pg[kk][e];
+                if (P.x_mode >= 2) a = (_Float16)(((float)a - s_mean[c]) * s_rstd[c]);
+                if (P.x_mode & 1) a = a > (_Float16)0 ? a : (_Float16)0;
+                if (P.y_mode >= 2) b = (_Float16)(((float)b - s_mean2[c]) * s_rstd2[c]);
+                b = b > (_Float16)0 ? b : (_Float16)0;
+                const _Float16 sum = a + b;                               // f16 add (x + y on f16 tensors)
+                v[e] = sum > (_Float16)0 ? sum : (_Float16)0;
+              }
+              // the tile's own pixels of the block output go back to memory for its other readers (the skip connection of
+              // the next block, the second convolution of a stride-2 block): every pixel is the interior of exactly one tile
+              if (P.mat_out && blockIdx.y == 0 && ly >= PAD && ly < PAD + TH * S && lx >= PAD && lx < PAD + TW * S)
+                *reinterpret_cast<h8*>(P.mat_out + ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8) = v;
+            }
+            const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+            *reinterpret_cast<h8*>(halo + ((int64_t)pix * CPP + sch) * 8) = v;
+          }
         }
       }
-    } else {
+    } else if constexpr (!DUAL_ONLY) {
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
       const int q = tid + 256 * k;
@@ -197,22 +213,13 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   ENC_T(2);
   // ---- implicit GEMM: wave w owns output rows 2w, 2w+1 (4 M-tiles of 16 pixels), 4 N-tiles (64 channels)
   f4 acc[4][NT];
-  f4 acc2[DS ? 4 : 1][DS ? NT : 1];                          // DS: the 1x1 convolution on the centre tap
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { acc[i][j] = (f4)0.f; if constexpr (DS) acc2[i][j] = (f4)0.f; }
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f4)0.f;
   const int m = lane & 15, kg = lane >> 4;
   const int ncout = P.cout;
-  h8 fw2[DS ? NT : 1];
-  if constexpr (DS) {
-    static_assert(!DS || (KS == 3 && CIN == 32), "centre-tap second convolution: 3x3, one 32-channel k-step");
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + m;
-      fw2[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w2 + (int64_t)n * 32 + kg * 8) : (h8)(_Float16)0;
-    }
-  }
+  static_assert(!DS || (KS == 3 && CIN == 32), "centre-tap second convolution: 3x3, one 32-channel k-step");
   constexpr int K = KS * KS * CIN;
   // flat k-steps t = (kh*KS + kw)*(CIN/32) + kc; the filter fragments of step t+2 are fetched (L2) while step t runs:
   // un-prefetched they were a dependent ~0.5 us round trip per step (9 us of a 23 us workgroup for 2 us of MFMA)
@@ -239,12 +246,6 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % (PD + 1)][j], fa, acc[i][j], 0, 0, 0);
-      if constexpr (DS) {
-        if (kh == KS / 2 && kw == KS / 2) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw2[j], fa, acc2[i][j], 0, 0, 0);
-        }
-      }
     }
   }
 
@@ -304,7 +305,25 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   }
   };
   epilogue(acc, P.bias, P.out, P.out_part);
-  if constexpr (DS) epilogue(acc2, P.bias2, P.out2, P.out2_part);
+  if constexpr (DS) {
+    // the second, 1x1 convolution (layer2.0.downsample) = one k-step on the centre tap of the halo that is still in LDS; the
+    // accumulators are reused (carrying both sets through the main loop cost the kernel its second workgroup per CU)
+    h8 fw2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + m;
+      fw2[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w2 + (int64_t)n * 32 + kg * 8) : (h8)(_Float16)0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ly = (2 * wave + (i >> 1)) * S + KS / 2, lx = ((i & 1) * 16 + m) * S + KS / 2;
+      const int sch = kg ^ swz4(lx);
+      const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw2[j], fa, (f4)0.f, 0, 0, 0);
+    }
+    epilogue(acc, P.bias2, P.out2, P.out2_part);
+  }
   ENC_T(5);
 }
 
@@ -449,6 +468,14 @@ extern "C" size_t dpvo_encoders_workspace_bytes(int H, int W) {
 // fmap_out [H/4][W/4][128], imap_out [H/4][W/4][384] f16 NHWC, both already divided by 4 (net.py:116-117).
 extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out,
                                      int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  return dpvo_encoders_forward_hold(image_f16, weights, fmap_out, imap_out, H, W, ws, ws_bytes, nullptr, 0, stream);
+}
+
+// The same, with the stream made to wait for `hold_event` (hipEvent_t, may be NULL) in front of launch number `hold_at`
+// (0 = the first convolution ... 9 = the last): a tracker that runs the next frame's encoders on a side stream lets the first
+// launches run beside the chip-filling kernels of the current frame and holds the rest back until those are through.
+extern "C" int dpvo_encoders_forward_hold(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out,
+                                          int H, int W, void* ws, size_t ws_bytes, void* hold_event, int hold_at, void* stream) {
   if (!image_f16 || !weights || !fmap_out || !imap_out || !ws) return DPVO_E_INVALID;
   if (H <= 0 || W <= 0 || (H % 16) || (W % 16)) return DPVO_E_UNSUPPORTED;
   if (ws_bytes < dpvo_encoders_workspace_bytes(H, W)) return DPVO_E_WORKSPACE;
@@ -476,6 +503,12 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
   int rc;
   EncArgs a;
   const int cin_mode[2] = {2, 1};                         // consumer-side transform of a raw conv output: IN+relu | relu
+  int launch_no = 0;
+  auto hold = [&]() -> int {
+    if (hold_event && launch_no++ == hold_at && hipStreamWaitEvent(st, (hipEvent_t)hold_event, 0) != hipSuccess) return DPVO_E_INVALID;
+    return 0;
+  };
+#define HOLD() do { if ((rc = hold())) return rc; } while (0)
 #define STATS(z, i) (nm[z] ? Pt[z][i] : nullptr)
 
   // Residual-block outputs are formed by their first consumer (in_mode 3) and written back by it (mat_out):
@@ -487,19 +520,24 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
   };
   // conv1 (7x7 s2) -> A0 raw, stats P0; x0 = relu(norm1(A0)) is applied on the fly by its consumers      :252-254
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(nullptr, nullptr, Wp(z, 0), Wp(z, 1), A[z][0], STATS(z, 0), 0, 32, 1.0f);
+  HOLD();
   hipLaunchKernelGGL(conv1_kernel, dim3(t2, 1, 2), dim3(256), 0, st, (const _Float16*)image_f16, a, H, W, h2, w2);
 
   // ---- layer1.0 (ResidualBlock 32->32, :44-55): c1: x0 -> A1 (P1), c2 -> A2 (P2)
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][0], STATS(z, 0), Wp(z, 2), Wp(z, 3), A[z][1], STATS(z, 1), cin_mode[z], 32, 1.0f);
+  HOLD();
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][1], STATS(z, 1), Wp(z, 4), Wp(z, 5), A[z][2], STATS(z, 2), cin_mode[z], 32, 1.0f);
+  HOLD();
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   // ---- layer1.1: input X1 = relu(x0 + relu(f(A2))) formed here and written to A1; c1 -> A3 (P3), c2 -> A0 (P4)
   for (int z = 0; z < 2; ++z)
     a.e[z] = res(enc_ptrs(A[z][0], STATS(z, 0), Wp(z, 6), Wp(z, 7), A[z][3], STATS(z, 3), 3, 32, 1.0f), A[z][2], STATS(z, 2),
                  nm[z] ? 3 : 1, nm[z] ? 3 : 1, A[z][1]);
+  HOLD();
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][3], STATS(z, 3), Wp(z, 8), Wp(z, 9), A[z][0], STATS(z, 4), cin_mode[z], 32, 1.0f);
+  HOLD();
   if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   // ---- layer2.0 (32->64, stride 2): input X2 = relu(X1 + relu(f(A0))) formed here and written to A2;
   //      c1 -> B0 (P5) and, on the centre tap, downsample (1x1 stride 2) -> B2 (P7) in the same launch; c2 -> B1 (P6)
@@ -508,23 +546,29 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
                  nm[z] ? 3 : 1, A[z][2]);
     a.e[z].w2 = Wp(z, 14); a.e[z].bias2 = Wp(z, 15); a.e[z].out2 = B[z][2]; a.e[z].out2_part = STATS(z, 7);
   }
+  HOLD();
   if ((rc = launch_conv<32, 3, 2, 4, true>(a, h2, w2, h4, w4, t2, 64, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(B[z][0], STATS(z, 5), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 6), cin_mode[z], 64, 1.0f);
+  HOLD();
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
   // ---- layer2.1: input X3 = relu(norm(B2) + relu(f(B1))) formed here and written to B3; c1 -> B0 (P8), c2 -> B1 (P9)
   for (int z = 0; z < 2; ++z)
     a.e[z] = res(enc_ptrs(B[z][2], STATS(z, 7), Wp(z, 16), Wp(z, 17), B[z][0], STATS(z, 8), 3, 64, 1.0f), B[z][1], STATS(z, 6),
                  nm[z] ? 2 : 0, nm[z] ? 3 : 1, B[z][3]);
+  HOLD();
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(B[z][0], STATS(z, 8), Wp(z, 18), Wp(z, 19), B[z][1], STATS(z, 9), cin_mode[z], 64, 1.0f);
+  HOLD();
   if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
   // ---- conv2 (1x1, 64 -> 128 | 384) on X4 = relu(X3 + relu(f(B1))), output / 4.0                        :259, net.py:116-117
   a.e[0] = res(enc_ptrs(B[0][3], nullptr, Wp(0, 20), Wp(0, 21), (_Float16*)fmap_out, nullptr, 3, 128, 0.25f), B[0][1], STATS(0, 9), 0,
                nm[0] ? 3 : 1, nullptr);
   a.e[1] = res(enc_ptrs(B[1][3], nullptr, Wp(1, 20), Wp(1, 21), (_Float16*)imap_out, nullptr, 3, 384, 0.25f), B[1][1], STATS(1, 9), 0,
                nm[1] ? 3 : 1, nullptr);
+  HOLD();
   if ((rc = launch_conv<64, 1, 1, 4>(a, h4, w4, h4, w4, t4, 384, st))) return rc;
 #undef STATS
+#undef HOLD
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

@@ -271,6 +271,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   STEP(dpvo_update_forward_fused_rows(a->upd, net, a->net_rows, a->n_kept, a->imap, K.kk, (int64_t)a->pmem * M, a->corr, 896, a->plan, np_ub, ng_ub,
                                       a->coords, a->P, net, a->delta, weight, target, E, a->ws_update, a->ws_update_bytes, stream));
   if (a->ev[3] && hipEventRecord((hipEvent_t)a->ev[3], st) != hipSuccess) return DPVO_E_INVALID;
+  if (a->ev_update_done && hipEventRecord((hipEvent_t)a->ev_update_done, st) != hipSuccess) return DPVO_E_INVALID;
   // ---- two local BA iterations over the last ba_window poses (dpvo.py:351-354), point cloud (:358-360)
   int t0 = n - a->ba_window;
   if (t0 < 1) t0 = 1;

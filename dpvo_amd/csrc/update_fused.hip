@@ -1719,7 +1719,7 @@ void ws_layout(int64_t E, int64_t maxg, Ws* w) {
 #ifndef FU_DW2C
 #define FU_DW2C 6            // the chain kernels fit a 6-deep ring in 250 registers at two workgroups per CU (K1 spills beyond 3)
 #endif
-#define FU_CFG_DEFAULT 3
+#define FU_CFG_DEFAULT 1            // chains: 64-row tiles x 2 workgroups per CU; K1 and K7: 96-row tiles x 1 (A/B in the frame, round 3: cfg 1 / 3 / 0 / 2 = 828 / 817 / 814 / 800 frames/sec on one box)
 #define FU_DWPM 4
 #define FU_DWKB 6
 

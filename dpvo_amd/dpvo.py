@@ -42,6 +42,11 @@ _PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '0')
 # reads a 16-word result one frame later.  0: the round-2 path (Python-paced launches, host mirror of the index arrays).
 _FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
 # the result read-back waits on an event created with hipEventBlockingSync: the waiting thread sleeps instead of spinning
+# DPVO_ENC_AFTER_UPDATE=1: the side stream holds the next frame's encoders back until the current frame's update operator is
+# through, so that they run beside the small BA / keyframe kernels instead of beside the correlation / update kernels
+_ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '0')))
+_ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '0'))
+_STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
 
 
@@ -453,6 +458,13 @@ class DPVO:
                 assert np.array_equal(h[k], getattr(self.pg, k).cpu().numpy()), f"edge mirror diverged ({k})"
 
     # ------------------------------------------------------------------------------------------ one-call frame path
+    def _stamp(self, i):
+        """DPVO_STAMPS=1 (tools/stream_stamps.py): stream-ordered wall-clock stamps [frame counter % 256][8] on the current stream"""
+        if _STAMPS:
+            if getattr(self, "_stamp_buf", None) is None:
+                self._stamp_buf = torch.zeros(256, 8, dtype=torch.int64, device=self.device)
+            L.lib().dpvo_debug_stamp(ctypes.c_void_p(self._stamp_buf.data_ptr() + 8 * (8 * (self.counter % 256) + i)), L.stream())
+
     def _frame_call_ok(self, n=None):
         from . import net as net_mod
         n = self.n if n is None else n
@@ -578,7 +590,14 @@ class DPVO:
             a.fs, a.ev_fs, a.fs_auto = ctypes.addressof(fs), (self._fp_done.cuda_event if self._fp_done is not None else None), 1
         else:
             a.fs = a.ev_fs = None
+        if _ENC_AFTER_UPDATE:
+            if getattr(self, "_upd_done", None) is None:
+                self._upd_done = torch.cuda.Event()
+                self._upd_done.record()
+            a.ev_update_done = self._upd_done.cuda_event
+        self._stamp(3)
         L.check(L.lib().dpvo_frame_update(ctypes.byref(a), L.stream()), "dpvo_frame_update")
+        self._stamp(4)
         es.net_pending = None           # (gathered by the operator's first kernel, rewritten compact by its last one)
         ev = fu["ev"][par]
         ev.record()
@@ -778,10 +797,13 @@ class DPVO:
         appended = False
         if hip_enc and self.overlap_encoders:
             if self._enc_stream is None:
-                self._enc_stream = torch.cuda.Stream(device=self.device)
+                self._enc_stream = torch.cuda.Stream(device=self.device, priority=int(__import__("os").environ.get("DPVO_ENC_PRIO", "0")))
             side = self._enc_stream
             if self._fp_done is not None:       # the previous frame's readers of _imap_full / the encoder workspace
                 side.wait_event(self._fp_done)
+            hold_ev = None
+            if _ENC_AFTER_UPDATE and getattr(self, "_upd_done", None) is not None and self._fu_pending is not None:
+                hold_ev = self._upd_done
             # the caller's stream may still be producing / uploading the image (torch.from_numpy(img).cuda() from pageable
             # memory returns before the copy has landed): order the side stream behind it
             if image_ready is None:
@@ -791,6 +813,7 @@ class DPVO:
                 side.wait_event(image_ready)
         main_stream = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(side if side is not None else main_stream):
+            self._stamp(0)
             if hip_enc and side is not None and patch_coords is None and depth_init is None and self.P == 3:
                 # the frame's three random draws (same generator order as the serial path) depend on nothing: issued FIRST on
                 # the side stream -- behind the encoders they sat on the frame's critical path (the next frame starts when the
@@ -801,6 +824,7 @@ class DPVO:
                            torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device))
                 for t_ in pre_rng:
                     t_.record_stream(main_stream)        # allocated on the side stream, read on the main one
+            self._stamp(1)
             img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
             img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
             L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),
@@ -812,7 +836,11 @@ class DPVO:
                 slot = self._fmap1_cl[self.n % self.mem]
                 if self._imap_full is None:
                     self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
-                self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
+                if side is not None and hold_ev is not None:
+                    self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full, hold_event=hold_ev, hold_at=_ENC_HOLD_AT)
+                else:
+                    self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
+                self._stamp(2)
                 if side is not None:
                     enc_done = torch.cuda.Event()
                     enc_done.record(side)

@@ -40,8 +40,9 @@ class HipEncoders:
         self.ptrs = (ctypes.c_void_p * 44)(*[t.data_ptr() for t in self.tensors])
         self.dev = self.tensors[0].device
 
-    def __call__(self, img16, fmap_out=None, imap_out=None):
-        """img16 [3,H,W] f16 (normalised image) -> fmap [H/4,W/4,128], imap [H/4,W/4,384] (NHWC f16, already / 4)"""
+    def __call__(self, img16, fmap_out=None, imap_out=None, hold_event=None, hold_at=0):
+        """img16 [3,H,W] f16 (normalised image) -> fmap [H/4,W/4,128], imap [H/4,W/4,384] (NHWC f16, already / 4).
+        hold_event (a recorded torch.cuda.Event) / hold_at: the current stream waits for the event in front of launch hold_at."""
         assert img16.dtype == torch.float16 and img16.is_contiguous() and img16.dim() == 3
         _, H, W = img16.shape
         h, w = H // 4, W // 4
@@ -53,6 +54,8 @@ class HipEncoders:
         if nbytes == 0:
             raise L.DPVOHipError(f"encoders need H, W multiples of 16 (got {H}x{W})")
         ws = workspace.get(nbytes, self.dev, "enc")
-        L.check(L.lib().dpvo_encoders_forward(L.ptr(img16), self.ptrs, L.ptr(fmap_out), L.ptr(imap_out), L.i32(H), L.i32(W),
-                                              L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_encoders_forward")
+        L.check(L.lib().dpvo_encoders_forward_hold(L.ptr(img16), self.ptrs, L.ptr(fmap_out), L.ptr(imap_out), L.i32(H), L.i32(W),
+                                                   L.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                   ctypes.c_void_p(hold_event.cuda_event if hold_event is not None else 0),
+                                                   L.i32(hold_at), L.stream()), "dpvo_encoders_forward")
         return fmap_out, imap_out

@@ -383,7 +383,7 @@ int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* p, const fl
                                    float* net_out, float* delta, float* weight, float* target, int64_t E, void* ws,
                                    size_t ws_bytes, void* stream);
 size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups);
-int dpvo_update_fused_default_tiling(void);      /* 3 */
+int dpvo_update_fused_default_tiling(void);      /* 1 */
 int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const float* net, const void* inp,
                               const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan,
                               int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
@@ -449,6 +449,8 @@ int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream);
 typedef struct {
   dpvo_keyframe_step_t kf;          /* edge arrays, rings, decision parameters; kf.flow4 / kf.result are set by the call */
   dpvo_frame_state_t* fs; void* ev_fs;
+  void* ev_update_done;             /* hipEvent_t or NULL: recorded behind the update operator (the caller's side stream may hold the
+                                       next frame's encoders back until the two chip-filling kernels are through) */
   int32_t fs_auto;                  /* != 0: the call fills the fields of *fs that depend on the frame number (ring slots, index rows,
                                        edge arrays and counts) from kf.ring[] (order: colours, poses, patches, intrinsics, imap, gmap,
                                        fmap1, fmap2), index_map and the counters; the caller sets the per-frame inputs only */
@@ -486,6 +488,9 @@ int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream);
 size_t dpvo_encoders_workspace_bytes(int H, int W);
 int dpvo_encoders_forward(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out, int H, int W,
                           void* ws, size_t ws_bytes, void* stream);
+/* The same with the stream made to wait for hold_event (hipEvent_t or NULL) in front of launch number hold_at (0..9). */
+int dpvo_encoders_forward_hold(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out, int H, int W,
+                               void* ws, size_t ws_bytes, void* hold_event, int hold_at, void* stream);
 /* F.avg_pool2d(fmap, 4, 4) on an NHWC f16 map (dpvo/dpvo.py:438). */
 int dpvo_pool4_nhwc(const void* in, void* out, int h, int w, int C, void* stream);
 
@@ -505,6 +510,10 @@ int dpvo_gba_linearize(const float* poses, const float* patches, const float* in
 int dpvo_gba_retract(float* poses, float* patches, const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E,
                      int P, int M, int f0, int n_frames, int t0, int t1, const float* dX, void* ws, size_t ws_bytes,
                      void* stream);
+
+/* Dev aid: a one-thread kernel that stores the 100 MHz wall clock into *slot (uint64) when it executes: stream-ordered time
+ * stamps across streams without a profiler (tools/stream_stamps.py). */
+int dpvo_debug_stamp(void* slot, void* stream);
 
 #ifdef __cplusplus
 }

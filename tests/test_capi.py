@@ -112,7 +112,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
               "dpvo_ring_t": (L.Ring, ["base", "slot_bytes", "ring"]),
               "dpvo_keyframe_step_t": (L.KeyframeStep, ["ii", "weight_b", "ii_inac", "inac_room", "flow4", "keep_rows", "result_host", "ring", "n_ring",
                                                         "E", "n", "forced", "keyframe_thresh"]),
-              "dpvo_frame_update_t": (L.FrameUpdate, ["kf", "fs", "ev_fs", "fs_auto", "index_map", "net", "net_rows", "n_kept", "poses", "upd", "ws_ba", "ws_plan_bytes", "result_dev", "ev", "m", "n_buffer",
+              "dpvo_frame_update_t": (L.FrameUpdate, ["kf", "fs", "ev_fs", "ev_update_done", "fs_auto", "index_map", "net", "net_rows", "n_kept", "poses", "upd", "ws_ba", "ws_plan_bytes", "result_dev", "ev", "m", "n_buffer",
                                                       "P", "iterations", "lmbda", "mm_beta"]),
               "dpvo_update_params_t": (_UpdParams, ["c0_w", "g1_b2", "w_b"]),
               "dpvo_frame_state_t": (L.FrameState, ["fmap", "index_map", "poses", "ix", "frame_next", "n_new", "res", "mm_scale", "M",
