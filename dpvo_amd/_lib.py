@@ -60,7 +60,7 @@ class KeyframeStep(ctypes.Structure):
         "ii", "jj", "kk", "net", "target", "weight", "ii_b", "jj_b", "kk_b", "net_b", "target_b", "weight_b",
         "ii_inac", "jj_inac", "kk_inac", "target_inac", "weight_inac")] +
         [("inac_room", ctypes.c_int64)] +
-        [(k, ctypes.c_void_p) for k in ("flow4", "poses", "delta_pose", "keep_idx", "rem_idx", "keep_rows", "result", "result_host")] +
+        [(k, ctypes.c_void_p) for k in ("flow4", "poses", "delta_pose", "keep_idx", "rem_idx", "keep_rows", "result", "result_host")] + [("host_words", ctypes.c_int32)] +
         [("ring", Ring * 8), ("n_ring", ctypes.c_int32), ("E", ctypes.c_int64)] +
         [(k, ctypes.c_int32) for k in ("n", "M", "D", "keyframe_index", "removal_window", "loop_closure",
                                        "optimization_window", "forced")] +

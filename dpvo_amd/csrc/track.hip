@@ -111,14 +111,24 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe
     if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
     a.result[RES_DECISION] = d; a.result[RES_KEEP] = total[0]; a.result[RES_REM] = nrem; a.result[RES_E] = (int32_t)a.E;
     a.result[RES_OVERFLOW] = ovf; a.result[5] = a.result[6] = a.result[7] = 0;
+    if (a.result_host) {
+      // the host's copy, written straight into its pinned buffer (a 32- or 64-byte hipMemcpyAsync is another ~5 us launch in
+      // the frame's tail); `host_words` = 16: the 8 words in front of `result` (flow sums + plan counters) go along
+      volatile int32_t* h = (volatile int32_t*)a.result_host;
+      const int32_t* src = a.result - (a.host_words == 16 ? 8 : 0);
+      for (int i = 0; i < a.host_words; ++i) h[i] = src[i];
+      __threadfence_system();
+    }
   }
 }
 
 // ---- 2. the two gathers (kept -> spare set, incl. the 1.5 KB hidden-state rows; inactive -> tail of the inactive store)
-__global__ __launch_bounds__(256) void kf_gather_kernel(const dpvo_keyframe_step_t a, int nblk_keep) {
+__device__ __forceinline__ void kf_shift_body(const dpvo_keyframe_step_t& a, int blk, int blocks_per_ring);
+__global__ __launch_bounds__(256) void kf_gather_kernel(const dpvo_keyframe_step_t a, int nblk_keep, int nblk_gather, int blocks_per_ring) {
+  if ((int)blockIdx.x >= nblk_gather) { kf_shift_body(a, (int)blockIdx.x - nblk_gather, blocks_per_ring); return; }
   const Renum R = {a.result[RES_DECISION], a.n - a.keyframe_index, a.M};
   const bool keep_job = (int)blockIdx.x < nblk_keep;
-  const int64_t bid = keep_job ? blockIdx.x : blockIdx.x - nblk_keep, nblk = keep_job ? nblk_keep : gridDim.x - nblk_keep;
+  const int64_t bid = keep_job ? blockIdx.x : blockIdx.x - nblk_keep, nblk = keep_job ? nblk_keep : nblk_gather - nblk_keep;
   const int64_t gt = bid * 256 + threadIdx.x, gs = nblk * 256;
   const int32_t* __restrict__ idx = keep_job ? a.keep_idx : a.rem_idx;
   const int64_t n = keep_job ? a.result[RES_KEEP] : a.result[RES_REM];
@@ -144,15 +154,15 @@ __global__ __launch_bounds__(256) void kf_gather_kernel(const dpvo_keyframe_step
 
 // ---- 3. ring buffers: slot i <- slot i + 1 for i = k .. n - 2 (dpvo.py:289-299), only if the keyframe was dropped.  A thread
 //         owns the same 16-byte piece of every slot, so the in-place chain needs no synchronisation.
-__global__ __launch_bounds__(256) void kf_shift_kernel(const dpvo_keyframe_step_t a, int blocks_per_ring) {
+__device__ __forceinline__ void kf_shift_body(const dpvo_keyframe_step_t& a, int blk, int blocks_per_ring) {
   if (!a.result[RES_DECISION]) return;
-  const int r = blockIdx.x / blocks_per_ring;
+  const int r = blk / blocks_per_ring;
   if (r >= a.n_ring) return;
   const dpvo_ring_t G = a.ring[r];
   const int64_t units = G.slot_bytes / 16;
   const int k = a.n - a.keyframe_index;
   typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-  for (int64_t u = (int64_t)(blockIdx.x - r * blocks_per_ring) * 256 + threadIdx.x; u < units; u += (int64_t)blocks_per_ring * 256) {
+  for (int64_t u = (int64_t)(blk - r * blocks_per_ring) * 256 + threadIdx.x; u < units; u += (int64_t)blocks_per_ring * 256) {
     for (int i = k; i < a.n - 1; ++i) {
       const int64_t src = G.ring ? (i + 1) % G.ring : (i + 1), dst = G.ring ? i % G.ring : i;
       const u4v v = *reinterpret_cast<const u4v*>((const char*)G.base + src * G.slot_bytes + u * 16);
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void kf_shift_kernel(const dpvo_keyframe_step_
   }
   // (slot sizes that are not a multiple of 16 bytes: the tail, byte by byte, by the first block of the ring)
   const int64_t tail0 = units * 16;
-  if (blockIdx.x == r * blocks_per_ring)
+  if (blk == r * blocks_per_ring)
     for (int64_t b = tail0 + threadIdx.x; b < G.slot_bytes; b += 256)
       for (int i = k; i < a.n - 1; ++i) {
         const int64_t src = G.ring ? (i + 1) % G.ring : (i + 1), dst = G.ring ? i % G.ring : i;
@@ -178,6 +188,7 @@ inline unsigned blocks_for(int64_t n, int64_t cap) {
 
 extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
   if (!a || a->E < 0 || a->E >= (1ll << 31) || a->M <= 0 || a->D <= 0 || (a->D % 4) || a->n_ring < 0 || a->n_ring > 8) return DPVO_E_INVALID;
+  if (a->result_host && a->host_words != 8 && a->host_words != 16) return DPVO_E_INVALID;
   if (!a->result || !a->keep_idx || !a->rem_idx || (a->forced < 0 && !a->flow4) || !a->poses) return DPVO_E_INVALID;
   if (a->E > 0 && (!a->ii || !a->jj || !a->kk || !a->target || !a->weight || !a->ii_b || !a->jj_b || !a->kk_b || !a->target_b ||
                    !a->weight_b || !a->ii_inac || !a->jj_inac || !a->kk_inac || !a->target_inac || !a->weight_inac))
@@ -191,21 +202,20 @@ extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
   const unsigned chunks = (unsigned)(a->E > 0 ? cdiv64(a->E, KF_CHUNK) : 1);
   hipLaunchKernelGGL(kf_count_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, counts);
   hipLaunchKernelGGL(kf_select_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, (const int32_t*)counts);
-  if (a->E > 0) {
-    const unsigned gk = blocks_for(a->net_b ? a->E * (a->D / 4) : a->E, 2048), gr = blocks_for(a->E, 16);
-    hipLaunchKernelGGL(kf_gather_kernel, dim3(gk + gr), dim3(256), 0, st, *a, (int)gk);
-  }
-  if (a->n_ring > 0) {
-    int64_t mx = 0;
-    for (int r = 0; r < a->n_ring; ++r) mx = a->ring[r].slot_bytes > mx ? a->ring[r].slot_bytes : mx;
-    const unsigned bpr = blocks_for(mx / 16, 512);
-    hipLaunchKernelGGL(kf_shift_kernel, dim3(bpr * (unsigned)a->n_ring), dim3(256), 0, st, *a, (int)bpr);
+  {
+    // the two gathers and the ring shifts are independent of each other: one launch (the shift blocks leave at once unless
+    // the keyframe was dropped)
+    unsigned gk = 0, gr = 0, bpr = 0;
+    if (a->E > 0) { gk = blocks_for(a->net_b ? a->E * (a->D / 4) : a->E, 2048); gr = blocks_for(a->E, 16); }
+    if (a->n_ring > 0) {
+      int64_t mx = 0;
+      for (int r = 0; r < a->n_ring; ++r) mx = a->ring[r].slot_bytes > mx ? a->ring[r].slot_bytes : mx;
+      bpr = blocks_for(mx / 16, 512);
+    }
+    if (gk + gr + bpr * (unsigned)a->n_ring > 0)
+      hipLaunchKernelGGL(kf_gather_kernel, dim3(gk + gr + bpr * (unsigned)a->n_ring), dim3(256), 0, st, *a, (int)gk, (int)(gk + gr), (int)bpr);
   }
   DPVO_LAUNCH_CHECK();
-  if (a->result_host) {
-    hipError_t e = hipMemcpyAsync(a->result_host, a->result, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return (int)e;
-  }
   return DPVO_OK;
 }
 
@@ -286,13 +296,8 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   kf.flow4 = a->result_dev;
   kf.result = reinterpret_cast<int32_t*>(a->result_dev + 8);
   kf.poses = a->poses;
-  void* host = kf.result_host;
-  kf.result_host = nullptr;
+  kf.host_words = 16;               // the host's copy carries the flow sums and the plan counters in front of the 8 result words
   STEP(dpvo_keyframe_step(&kf, stream));
 #undef STEP
-  if (host) {
-    hipError_t e = hipMemcpyAsync(host, a->result_dev, 16 * sizeof(float), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return (int)e;
-  }
   return DPVO_OK;
 }

@@ -414,8 +414,8 @@ int dpvo_update_forward_pm(const dpvo_update_fused_params_t* params, const float
  *   3. the edges whose source frame kk / M < n' - removal_window leave to the inactive store (remove_factors(..., store=True),
  *      :305-310; with loop_closure != 0 the long-range edges of :307-308 stay), the others are compacted in order into the
  *      spare arrays (*_b).
- * result (device, 8 x int32 followed by 2 * ceil(E / 1024) ints of scratch; the 8 words are also copied to result_host if not
- * NULL -- pinned memory, asynchronous):
+ * result (device, 8 x int32 followed by 2 * ceil(E / 1024) ints of scratch; the words are also written to result_host if not
+ * NULL -- pinned host memory, see host_words):
  *   [0] decision, [1] edges kept, [2] edges moved to the inactive store, [3] E, [4] 1 if the inactive room was too small
  *   (nothing written beyond it).  The caller swaps its array sets and updates its counters when it reads the result --
  *   one frame later, if it likes: nothing on the device waits for the host. */
@@ -430,6 +430,9 @@ typedef struct {
   int64_t* keep_rows;               /* optional [E]: the kept edges' old row numbers as int64 -- with net == net_b == NULL the hidden
                                        state is NOT moved and this list is what dpvo_update_forward_fused_rows takes as net_rows */
   int32_t* result; void* result_host;
+  int32_t host_words;               /* 8: result_host receives the 8 result words; 16: also the 8 words stored in front of `result`
+                                       (dpvo_frame_update: flow sums + plan counters).  result_host is device-visible pinned host
+                                       memory: the kernel writes it itself, ordered before the completion of the call's last kernel */
   dpvo_ring_t ring[8]; int32_t n_ring;
   int64_t E;
   int32_t n, M, D, keyframe_index, removal_window, loop_closure, optimization_window, forced;
