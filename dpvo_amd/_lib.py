@@ -23,15 +23,21 @@ SYMBOLS = [
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
-    "dpvo_linear", "dpvo_layernorm", "dpvo_softagg", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target", "dpvo_update_workspace_bytes", "dpvo_update_forward",
+    "dpvo_softagg",
     "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_default_tiling",
-    "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
     "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state", "dpvo_keyframe_step", "dpvo_frame_update", "dpvo_debug_stamp",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_encoders_forward_hold", "dpvo_pool4_nhwc",
 ]
+
+
+# libdpvo_hip_cmp.so (include/dpvo_hip_cmp.h): the two COMPARATOR implementations of the update operator -- test and measurement
+# partners of the product's seven-launch operator, never loaded by the tracker (cmp_lib() below)
+CMP_LIB_PATH = os.environ.get("DPVO_HIP_CMP_LIB") or os.path.join(_HERE, "libdpvo_hip_cmp.so")
+CMP_SYMBOLS = ["dpvo_linear", "dpvo_layernorm", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target",
+               "dpvo_update_workspace_bytes", "dpvo_update_forward", "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm"]
 
 
 class DPVOHipError(RuntimeError):
@@ -102,11 +108,31 @@ def lib():
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
         for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
-                  "dpvo_gba_workspace_bytes", "dpvo_encoders_workspace_bytes", "dpvo_update_workspace_bytes",
-                  "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes", "dpvo_update_pm_workspace_bytes"):
+                  "dpvo_gba_workspace_bytes", "dpvo_encoders_workspace_bytes",
+                  "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
         _lib = L
     return _lib
+
+
+_cmp = None
+
+
+def cmp_lib():
+    """the comparator library (launch-by-launch and patch-major update operators); loaded on first use, by tests / tools only"""
+    global _cmp
+    if _cmp is None:
+        lib()                                    # (the comparator links against the product library)
+        if not os.path.exists(CMP_LIB_PATH):
+            raise DPVOHipError(f"{CMP_LIB_PATH} not found: build it with `make -C dpvo_amd/csrc`")
+        C = ctypes.CDLL(CMP_LIB_PATH)
+        for s in CMP_SYMBOLS:
+            if not hasattr(C, s):
+                raise DPVOHipError(f"libdpvo_hip_cmp.so does not export {s}")
+        for s in ("dpvo_update_workspace_bytes", "dpvo_update_pm_workspace_bytes"):
+            getattr(C, s).restype = ctypes.c_size_t
+        _cmp = C
+    return _cmp
 
 
 def check(rc, what):

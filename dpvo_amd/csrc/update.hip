@@ -9,6 +9,7 @@
 // f32 accumulate, one rounding to f16; LayerNorm -> f32; residual adds in f32.  The scatter softmax runs in
 // f32 here (the reference runs it in f16 through torch_scatter) and rounds once.
 #include "common.h"
+#include "../../include/dpvo_hip_cmp.h"
 
 namespace {
 
@@ -898,59 +899,6 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(const void* __restric
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// SoftAgg: one 384-thread block per group.  Thread (q, cq): member slice q = t / 96 (members b + q, b + q + 4, ...) and
-// channels [4 cq, 4 cq + 4) -- 8-byte loads (with one channel per thread the kernel was bound by the NUMBER of 2-byte
-// vector loads: 96 members x 12 wave-loads for a frame-pair group) and a dependent online-softmax chain of a quarter of
-// the members; the four partial (max, sum, weighted sum) triples are merged through LDS in the fixed order q = 0..3.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(384) void softagg_kernel(const _Float16* __restrict__ fg, int64_t ldfg,
-                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ off,
-                                                      const int32_t* __restrict__ n_groups, _Float16* __restrict__ y,
-                                                      int D) {
-  __shared__ float part[4][3][384];
-  const int ng = *n_groups;
-  const int q = threadIdx.x / 96, cq = threadIdx.x - 96 * q;
-  for (int g = blockIdx.x; g < ng; g += gridDim.x) {
-    const int b = off[g], e = off[g + 1];
-    float m[4], s[4], a[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; s[r] = 0.f; a[r] = 0.f; }
-    for (int p = b + q; p < e; p += 4) {
-      const _Float16* rowp = fg + (int64_t)perm[p] * ldfg + 4 * cq;
-      const h4 fx = *reinterpret_cast<const h4*>(rowp), gx = *reinterpret_cast<const h4*>(rowp + D);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float g_ = (float)gx[r];
-        const float mn = fmaxf(m[r], g_);
-        const float sc = __expf(m[r] - mn), w = __expf(g_ - mn);
-        s[r] = s[r] * sc + w;
-        a[r] = a[r] * sc + w * (float)fx[r];
-        m[r] = mn;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { part[q][0][4 * cq + r] = m[r]; part[q][1][4 * cq + r] = s[r]; part[q][2][4 * cq + r] = a[r]; }
-    __syncthreads();
-    {
-      const int c = threadIdx.x;
-      float M = part[0][0][c];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) M = fmaxf(M, part[k][0][c]);
-      float S = 0.f, A = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float mk = part[k][0][c];
-        const float sc = (mk == -INFINITY) ? 0.f : __expf(mk - M);      // an empty slice (fewer than 4 members) contributes nothing
-        S += part[k][1][c] * sc;
-        A += part[k][2][c] * sc;
-      }
-      y[(int64_t)g * D + c] = (_Float16)(A / S);
-    }
-    __syncthreads();
-  }
-}
-
 __global__ void gather_add_kernel(float* __restrict__ net, const _Float16* __restrict__ hy,
                                   const int32_t* __restrict__ group, _Float16* __restrict__ net16, int64_t E, int D) {
   const int64_t total = E * (D / 4);
@@ -1098,19 +1046,6 @@ extern "C" int dpvo_layernorm(const void* x, int x_dtype, const void* add1, cons
                               void* y_f16, int relu_f16, int64_t M, int D, void* stream) {
   return launch_layernorm(x, x_dtype, add1, add1_rows, add1_mod, nullptr, add2, gamma, beta, eps, y_f32, y_f16, relu_f16, M, D,
                           stream);
-}
-
-extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, const int32_t* off,
-                            const int32_t* n_groups, int64_t max_groups, void* y, int D, void* stream) {
-  if (max_groups < 0) return DPVO_E_INVALID;
-  if (max_groups == 0) return DPVO_OK;
-  if (D != 384 || (ldfg % 4) || ((uintptr_t)fg & 7)) return DPVO_E_UNSUPPORTED;      // 8-byte row loads
-  if (!fg || !perm || !off || !n_groups || !y) return DPVO_E_INVALID;
-  const unsigned grid = (unsigned)(max_groups < 8192 ? max_groups : 8192);
-  hipLaunchKernelGGL(softagg_kernel, dim3(grid), dim3(384), 0, (hipStream_t)stream, (const _Float16*)fg, ldfg, perm, off,
-                     n_groups, (_Float16*)y, D);
-  DPVO_LAUNCH_CHECK();
-  return DPVO_OK;
 }
 
 extern "C" int dpvo_gather_add(float* net, const void* hy, const int32_t* group, void* net16, int64_t E, int D,

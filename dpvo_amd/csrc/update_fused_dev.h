@@ -1,0 +1,442 @@
+// update_fused_dev.h -- device building blocks shared by the row-tile-resident update kernels: update_fused.hip (the seven-launch
+// operator of the product library) and update_pm.hip (the patch-major four-launch variant, comparator library).  See
+// update_fused.hip for the design notes (geometry, P order, register image, weight fragment image).
+#pragma once
+#include "common.h"
+#include <atomic>
+
+#ifdef FU_TRACE
+// per-workgroup timeline (100 MHz wall clock) for tools/fu_trace.py: [kernel id 8][block 1024][wave 4][stamp 16]
+__device__ unsigned long long* g_fu_trace = nullptr;
+#define FU_T(k, i)                                                                                                       \
+  do {                                                                                                                   \
+    if (g_fu_trace && (threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                      \
+      g_fu_trace[(((size_t)(k) * 1024 + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64();              \
+  } while (0)
+#else
+#define FU_T(k, i) do {} while (0)
+#endif
+
+namespace {
+namespace fu {
+
+// Soft start (dpvo_update_fused_start_skew): the workgroups of a launch begin in four groups, skew / 4 microseconds apart,
+// instead of all 256 CUs entering the same phase in the same microsecond.  A candidate of the autotune only: it costs a few
+// microseconds per kernel on a normal box (measured: 0 / +10 / +60 us at 4 / 10 / 20 us) and exists for the boxes on which the
+// FIRST, synchronous round of workgroups of every such kernel runs 2x slower than the second, staggered one.
+__device__ __forceinline__ void soft_start(int skew_us) {
+  if (skew_us > 0 && (blockIdx.x & 3)) {
+    const unsigned long long t0 = wall_clock64(), d = (unsigned long long)(blockIdx.x & 3) * (unsigned)skew_us * 25ull;   // 100 MHz ticks
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+constexpr int D = 384;
+constexpr int PITCH = 784;             // bytes per LDS activation row (768 + 16: ds_read_b128 / ds_write_b128 conflict free)
+constexpr int CPITCH = 272;            // bytes per LDS row of one K chunk of the correlation GEMM (256 + 16)
+constexpr int KCH = 128;               // halves per K chunk
+constexpr int KS384 = 24;              // k-steps (of 16) of a 384-wide layer
+
+template <int RT> struct Geo {
+  static constexpr int R = 32 * RT;
+  static constexpr int ACT_BYTES = R * PITCH;
+  static constexpr int RED_BYTES = R * 64;                      // LN: 2 x [R][4] floats; heads: [R][4 waves][4] floats
+  static constexpr int LDS_BYTES = ACT_BYTES + RED_BYTES;
+  static_assert(2 * R * CPITCH <= ACT_BYTES, "the two K-chunk stages of the correlation GEMM alias the activation tile");
+};
+
+struct Lane { int tid, lane, w, n, h; };
+__device__ __forceinline__ Lane lane_of() {
+  Lane l;
+  l.tid = threadIdx.x;
+  l.lane = l.tid & 63;
+  l.w = __builtin_amdgcn_readfirstlane(l.tid >> 6);
+  l.n = l.lane & 31;
+  l.h = l.lane >> 5;
+  return l;
+}
+
+// sigmoid in f32 (its result is rounded to f16 by every caller): v_exp + v_rcp, 1 ulp -- an IEEE division costs ten more VALU
+// instructions per value, a third of K7's VALU work
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+
+// ------------------------------------------------------------------------------------------------ weights
+// packed image of a [384, K] layer: [wave 4][k-step K/16][tile 3][lane 64][8 halves]
+template <int DW>
+__device__ __forceinline__ void w_preload(h8 (&wf)[DW][3], const h8* __restrict__ wp) {
+#pragma unroll
+  for (int d = 0; d < DW; ++d)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wf[d][t] = wp[(d * 3 + t) * 64];
+}
+// this lane's base into the packed image of a layer with KS k-steps
+__device__ __forceinline__ const h8* w_base(const void* img, int KS, const Lane& l) {
+  return reinterpret_cast<const h8*>(img) + (size_t)l.w * KS * 3 * 64 + l.lane;
+}
+
+// accumulators start at the bias (f16 [384], feature order): feature 96 w + 32 t + 8 j + 4 h + q.  The loads are issued
+// EARLY (next to the weight preload, before the epilogue of the previous layer): with one wave per SIMD nothing else hides
+// a dependent L2 round trip (~1 us under load) in front of the first MFMA.
+struct Bias { h4 v[3][4]; };
+__device__ __forceinline__ void bias_load(Bias& b, const _Float16* __restrict__ bias, const Lane& l) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[t][j] = *reinterpret_cast<const h4*>(bias + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+}
+// (several workgroups per CU: no early bias load, the accumulators start straight from memory)
+template <int RT>
+__device__ __forceinline__ void acc_init_mem(f16v (&acc)[RT][3], const _Float16* __restrict__ bias, const Lane& l) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    f16v v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const h4 b = *reinterpret_cast<const h4*>(bias + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[4 * j + q] = (float)b[q];
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r][t] = v;
+  }
+}
+template <int RT>
+__device__ __forceinline__ void acc_init(f16v (&acc)[RT][3], const Bias& b) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    f16v v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[4 * j + q] = (float)b.v[t][j][q];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r][t] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM over the LDS tile
+// acc[r][t] += W(wave's features, tile t) . act(rows of row tile r)^T over KS k-steps; `bl` = this lane's B-fragment
+// address of k-step 0, row tile 0 (tile base + n * pitch + 16 h); the ring holds k-steps 0 .. DW-1 on entry.
+template <int RT, int KS, int DW, int PITCH_B>
+__device__ __forceinline__ void gemm_lds(f16v (&acc)[RT][3], h8 (&wf)[DW][3], const h8* __restrict__ wp, const char* bl) {
+  h8 bf[2][RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) bf[0][r] = *reinterpret_cast<const h8*>(bl + r * 32 * PITCH_B);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + 1 < KS) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) bf[(s + 1) & 1][r] = *reinterpret_cast<const h8*>(bl + r * 32 * PITCH_B + (s + 1) * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % DW][t], bf[s & 1][r], acc[r][t], 0, 0, 0);
+    if (s + DW < KS) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wf[s % DW][t] = wp[((s + DW) * 3 + t) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);          // (keeps the scheduler from hoisting later k-steps' loads: register pressure)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ epilogue pieces
+// one rounding to f16 (what nn.Linear returns under autocast), kept in f32 registers
+template <int RT>
+__device__ __forceinline__ void round_f16(f16v (&v)[RT][3]) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[r][t][k] = (float)(_Float16)v[r][t][k];
+}
+
+// v -> f16 -> the LDS tile in P order.  ACT: 0 none, 1 relu, 2 sigmoid.  `al` = tile base + n * PITCH + 16 h (this lane's row 0)
+template <int RT, int ACT>
+__device__ __forceinline__ void to_lds(const f16v (&v)[RT][3], char* al, const Lane& l) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          _Float16 x = (_Float16)v[r][t][8 * c + i];
+          if (ACT == 1) x = x > (_Float16)0 ? x : (_Float16)0;
+          if (ACT == 2) x = (_Float16)sigm((float)x);
+          o[i] = x;
+        }
+        *reinterpret_cast<h8*>(al + r * 32 * PITCH + ((3 * l.w + t) * 2 + c) * 32) = o;
+      }
+}
+
+// v -> f16 -> global rows in P order (dst = row 0 of the tile, ld halves per row): 16-byte pieces, two lanes per 32 B
+template <int RT>
+__device__ __forceinline__ void to_rows(const f16v (&v)[RT][3], _Float16* dst, int64_t ld, int64_t row0, int64_t E, const Lane& l) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int64_t g = row0 + r * 32 + l.n;
+    if (g < E) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          h8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (_Float16)v[r][t][8 * c + i];
+          *reinterpret_cast<h8*>(dst + g * ld + ((3 * l.w + t) * 2 + c) * 16 + 8 * l.h) = o;
+        }
+    }
+  }
+}
+
+// LayerNorm over the 384 features of every row of the tile (two-pass, f32), in place.  Two barriers; the first one also
+// orders every wave's LDS reads of the preceding GEMM before whatever is written to the tile afterwards.
+template <int RT>
+__device__ __forceinline__ void layernorm_tile(f16v (&v)[RT][3], float* red, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, const Lane& l) {
+  constexpr int R = 32 * RT;
+  float* red1 = red;
+  float* red2 = red + R * 4;
+  float mean[RT], rstd[RT];
+  // the affine parameters of this lane's 48 features, requested before the statistics (their round trip hides behind the
+  // two reductions)
+  f4 gm[3][4], bt[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = 96 * l.w + 32 * t + 8 * j + 4 * l.h;
+      gm[t][j] = *reinterpret_cast<const f4*>(gamma + f);
+      bt[t][j] = *reinterpret_cast<const f4*>(beta + f);
+    }
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += v[r][t][k];
+    s += xhalf(s);
+    if (l.h == 0) red1[(r * 32 + l.n) * 4 + l.w] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const f4 p = *reinterpret_cast<const f4*>(red1 + (r * 32 + l.n) * 4);
+    mean[r] = ((p[0] + p[1]) + (p[2] + p[3])) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float d = v[r][t][k] - mean[r]; q += d * d; }
+    q += xhalf(q);
+    if (l.h == 0) red2[(r * 32 + l.n) * 4 + l.w] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const f4 p = *reinterpret_cast<const f4*>(red2 + (r * 32 + l.n) * 4);
+    rstd[r] = rsqrtf(((p[0] + p[1]) + (p[2] + p[3])) * (1.0f / D) + 1e-3f);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          v[r][t][4 * j + q] = (v[r][t][4 * j + q] - mean[r]) * rstd[r] * gm[t][j][q] + bt[t][j][q];
+}
+
+// same, affine parameters in LDS (gb: [gamma 384 | beta 384] f32, feature order; copied once per persistent workgroup):
+// no 96-register parameter block while the 144-register state is live
+template <int RT>
+__device__ __forceinline__ void layernorm_tile_late(f16v (&v)[RT][3], float* red, const float* gp, const float* bp, const Lane& l);
+template <int RT>
+__device__ __forceinline__ void layernorm_tile_lds(f16v (&v)[RT][3], float* red, const float* gb, const Lane& l) {
+  layernorm_tile_late<RT>(v, red, gb, gb + D, l);
+}
+// (also with the parameters in global memory when several workgroups share a CU and cover each other's round trips)
+template <int RT>
+__device__ __forceinline__ void layernorm_tile_late(f16v (&v)[RT][3], float* red, const float* gp, const float* bp, const Lane& l) {
+  constexpr int R = 32 * RT;
+  float* red1 = red;
+  float* red2 = red + R * 4;
+  float mean[RT], rstd[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += v[r][t][k];
+    s += xhalf(s);
+    if (l.h == 0) red1[(r * 32 + l.n) * 4 + l.w] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const f4 p = *reinterpret_cast<const f4*>(red1 + (r * 32 + l.n) * 4);
+    mean[r] = ((p[0] + p[1]) + (p[2] + p[3])) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float d = v[r][t][k] - mean[r]; q += d * d; }
+    q += xhalf(q);
+    if (l.h == 0) red2[(r * 32 + l.n) * 4 + l.w] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const f4 p = *reinterpret_cast<const f4*>(red2 + (r * 32 + l.n) * 4);
+    rstd[r] = rsqrtf(((p[0] + p[1]) + (p[2] + p[3])) * (1.0f / D) + 1e-3f);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = 96 * l.w + 32 * t + 8 * j + 4 * l.h;
+      const f4 g = *reinterpret_cast<const f4*>(gp + f), b = *reinterpret_cast<const f4*>(bp + f);
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[r][t][4 * j + q] = (v[r][t][4 * j + q] - mean[r]) * rstd[r] * g[q] + b[q];
+    }
+}
+
+// register image of the f32 hidden state: [32-row tile][wave][t][j] x 1 KB (independent of RT: kernels may tile differently)
+constexpr int IMG_RT_STRIDE = 4 * 3 * 4 * 256;       // floats per 32-row tile
+template <int RT>
+__device__ __forceinline__ float* img_ptr(float* img, int64_t tile, const Lane& l) {
+  return img + (size_t)(tile * RT) * IMG_RT_STRIDE + l.w * (3 * 4 * 256) + l.lane * 4;
+}
+// the image is requested one GEMM ahead of the epilogue that adds it (144 registers at RT = 3: this is what the one wave
+// per SIMD configuration has them for) ...
+template <int RT> struct Img { f4 v[RT][3][4]; };
+template <int RT>
+__device__ __forceinline__ void img_load(Img<RT>& m, const float* ip) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m.v[r][t][j] = *reinterpret_cast<const f4*>(ip + r * IMG_RT_STRIDE + (t * 4 + j) * 256);
+}
+template <int RT>
+__device__ __forceinline__ void img_add(f16v (&v)[RT][3], const Img<RT>& m) {        // ... v += image
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[r][t][4 * j + q] += m.v[r][t][j][q];
+}
+template <int RT>
+__device__ __forceinline__ void img_store(const f16v (&v)[RT][3], float* ip) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f4 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = v[r][t][4 * j + q];
+        *reinterpret_cast<f4*>(ip + r * IMG_RT_STRIDE + (t * 4 + j) * 256) = x;
+      }
+}
+
+// two workgroups per CU: no registers for an image in flight under a GEMM (and the other workgroup covers the latency):
+// v += image, image = v, one 32-row tile at a time
+template <int RT>
+__device__ __forceinline__ void img_add_store_stream(f16v (&v)[RT][3], float* ip) {
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    Img<1> m;
+    img_load<1>(m, ip + r * IMG_RT_STRIDE);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f4 x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[r][t][4 * j + q] += m.v[0][t][j][q]; x[q] = v[r][t][4 * j + q]; }
+        *reinterpret_cast<f4*>(ip + r * IMG_RT_STRIDE + (t * 4 + j) * 256) = x;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// rows of a P-order f16 matrix [., 384] -> the LDS tile.  rows == nullptr: row0 + i; an index < 0 or a row >= E: zeros.
+// The row indices are read ONCE per row (one coalesced load, through `sidx`: 32 RT ints of LDS that are free at this point)
+// instead of once per 16-byte piece: 18 dependent 4-byte loads per thread in front of the data loads were a third of the
+// gather's 9-11 us.  Contains one barrier.
+template <int RT>
+__device__ __forceinline__ void gather_rows(char* act, const _Float16* __restrict__ src, const int32_t* __restrict__ rows,
+                                            int64_t row0, int64_t E, int tid, int32_t* sidx) {
+  constexpr int N = RT * 6;                      // 32 RT rows x 48 pieces of 16 B over 256 threads
+  if (tid < 32 * RT) {
+    const int64_t g = row0 + tid;
+    sidx[tid] = g < E ? (rows ? rows[g] : (int32_t)g) : -1;
+  }
+  __syncthreads();
+  h8 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
+    const int32_t sr = sidx[row];
+    v[i] = sr >= 0 ? *reinterpret_cast<const h8*>(src + (int64_t)sr * D + ch * 8) : (h8)(_Float16)0;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
+    *reinterpret_cast<h8*>(act + row * PITCH + ch * 16) = v[i];
+  }
+}
+// the LDS tile -> rows [row0, row0 + R) of a P-order f16 matrix [E, 384]
+template <int RT>
+__device__ __forceinline__ void scatter_rows(const char* act, _Float16* __restrict__ dst, int64_t row0, int64_t E, int tid) {
+  constexpr int N = RT * 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int idx = tid + 256 * i, row = idx / 48, ch = idx - 48 * row;
+    const h8 v = *reinterpret_cast<const h8*>(act + row * PITCH + ch * 16);
+    if (row0 + row < E) *reinterpret_cast<h8*>(dst + (row0 + row) * D + ch * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ parameter blocks
+struct Lin { const void* w; const _Float16* b; };     // packed image + f16 bias
+
+// The kernel is a non-type template parameter, so every kernel instantiation owns its flag word: bit d = the dynamic-LDS
+// attribute has been set on device d (relaxed atomics: setting it twice is harmless, it only must not be skipped).
+template <auto KERN, typename P>
+int launch(int64_t tiles, int lds, const P& p, hipStream_t st) {
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DPVO_E_INVALID;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
+    if (hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPVO_E_UNSUPPORTED;
+    attr_done.fetch_or(bit, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(KERN, dim3((unsigned)tiles), dim3(256), (size_t)lds, st, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace fu
+}  // namespace

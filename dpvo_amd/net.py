@@ -1,6 +1,7 @@
 """VONet / Update / Patchifier with the reference's module tree and state-dict keys (dpvo/net.py:27-184,
-dpvo/blocks.py:15-48), so `dpvo.pth` loads unchanged, and `Update.forward` executed by the HIP kernels of
-dpvo_amd/csrc/update.hip instead of ~60 torch / torch_scatter launches.
+dpvo/blocks.py:15-48), so `dpvo.pth` loads unchanged, and `Update.forward` executed by the seven HIP kernels of
+dpvo_amd/csrc/update_fused.hip instead of ~60 torch / torch_scatter launches.  (`fused=False` / `fused="pm"` / `composite=False`
+run the comparator implementations of libdpvo_hip_cmp.so instead: tests and measurements only.)
 
 The nn.Module parameters are the single source of truth; `Update.pack()` derives the f16 operand images the
 kernels consume (what autocast's per-call weight casts produce in the reference, dpvo/dpvo.py:332).
@@ -43,7 +44,7 @@ def linear(A, W, bias, out=None, epilogue=EPI_NONE, rows=None, gate=None, n_spli
         assert out is not None and out.dtype == torch.float32
     elif out is None:
         out = torch.empty(M, N, dtype=torch.float16, device=A.device)
-    L.check(L.lib().dpvo_linear(L.ptr(A), L.i32(L.dtype_code(A.dtype)), L.i64(A.stride(0)), L.ptr(rows), L.ptr(W),
+    L.check(L.cmp_lib().dpvo_linear(L.ptr(A), L.i32(L.dtype_code(A.dtype)), L.i64(A.stride(0)), L.ptr(rows), L.ptr(W),
                                 L.i64(W.stride(0)), L.ptr(bias), L.ptr(out), L.i64(out.stride(0)), L.ptr(gate),
                                 L.i64(gate.stride(0) if gate is not None else 0), L.ptr(out16),
                                 L.i64(out16.stride(0) if out16 is not None else 0), L.i32(epilogue), L.i32(n_split),
@@ -55,7 +56,7 @@ def layernorm(x, gamma, beta, eps=1e-3, add1=None, add1_rows=None, add1_mod=0, a
               relu_f16=False):
     M, D = x.shape
     assert x.is_contiguous()
-    L.check(L.lib().dpvo_layernorm(L.ptr(x), L.i32(L.dtype_code(x.dtype)), L.ptr(add1), L.ptr(add1_rows),
+    L.check(L.cmp_lib().dpvo_layernorm(L.ptr(x), L.i32(L.dtype_code(x.dtype)), L.ptr(add1), L.ptr(add1_rows),
                                    L.i64(add1_mod), L.ptr(add2), L.ptr(gamma), L.ptr(beta), L.f32(eps), L.ptr(y_f32),
                                    L.ptr(y_f16), L.i32(1 if relu_f16 else 0), L.i64(M), L.i32(D), L.stream()),
             "dpvo_layernorm")
@@ -69,7 +70,7 @@ def softagg(fg, perm, off, n_groups_dev, n_groups):
 
 
 def gather_add(net, hy, group, net16=None):
-    L.check(L.lib().dpvo_gather_add(L.ptr(net), L.ptr(hy), L.ptr(group), L.ptr(net16), L.i64(net.shape[0]), L.i32(DIM),
+    L.check(L.cmp_lib().dpvo_gather_add(L.ptr(net), L.ptr(hy), L.ptr(group), L.ptr(net16), L.i64(net.shape[0]), L.i32(DIM),
                                     L.stream()), "dpvo_gather_add")
 
 
@@ -81,11 +82,11 @@ def heads(net, Wd, bd, Ww, bw, coords=None, target_out=None, weight_out=None):
     weight = weight_out if weight_out is not None else torch.empty(E, 2, dtype=torch.float32, device=net.device)
     if coords is not None:
         assert coords.is_contiguous() and coords.dtype == torch.float32 and target_out is not None
-        L.check(L.lib().dpvo_heads_target(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(coords),
+        L.check(L.cmp_lib().dpvo_heads_target(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(coords),
                                           L.i32(coords.shape[-1]), L.ptr(delta), L.ptr(weight), L.ptr(target_out), L.i64(E),
                                           L.i32(DIM), L.stream()), "dpvo_heads_target")
     else:
-        L.check(L.lib().dpvo_heads(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight),
+        L.check(L.cmp_lib().dpvo_heads(L.ptr(net), L.ptr(Wd), L.ptr(bd), L.ptr(Ww), L.ptr(bw), L.ptr(delta), L.ptr(weight),
                                    L.i64(E), L.i32(DIM), L.stream()), "dpvo_heads")
     return delta, weight
 
@@ -269,6 +270,10 @@ class Update(nn.Module):
             corr2 = buf
 
         net2 = net.reshape(E, DIM)
+        if net2.dtype != torch.float32 and composite:
+            # the reference's hidden state is f16 until its first update (dpvo.py:220); here it is f32 from the start (same
+            # values): a half tensor is promoted instead of being routed to another implementation
+            net2 = net2.float()
         if not net2.is_contiguous():
             net2 = net2.contiguous()
         inp2 = inp.reshape(-1, DIM)
@@ -318,10 +323,10 @@ class Update(nn.Module):
                 if ub is None:
                     ub = int(torch.bincount(kk.reshape(-1) - kk.min()).max().item())
                 if 0 < ub <= 96 and 2 * ((E + 95) // 96) + 48 <= 2048:
-                    nbytes = L.lib().dpvo_update_pm_workspace_bytes(L.i64(E), L.i64(maxg))
+                    nbytes = L.cmp_lib().dpvo_update_pm_workspace_bytes(L.i64(E), L.i64(maxg))
                     ws = workspace.get(nbytes, dev, "update_pm")
                     st = workspace.get(4, dev, "update_pm_status")
-                    L.check(L.lib().dpvo_update_forward_pm(
+                    L.check(L.cmp_lib().dpvo_update_forward_pm(
                         ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
                         L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(ub),
                         L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
@@ -343,9 +348,9 @@ class Update(nn.Module):
                     L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
                     ctypes.c_size_t(ws.numel()), L.stream()), "dpvo_update_forward_fused_rows")
                 return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
-            nbytes = L.lib().dpvo_update_workspace_bytes(L.i64(E), L.i64(maxg))
+            nbytes = L.cmp_lib().dpvo_update_workspace_bytes(L.i64(E), L.i64(maxg))
             ws = workspace.get(nbytes, dev, "update")
-            L.check(L.lib().dpvo_update_forward(
+            L.check(L.cmp_lib().dpvo_update_forward(
                 ctypes.byref(P["_params"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
                 L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
                 L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta), L.ptr(weight),

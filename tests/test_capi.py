@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "dpvo_hip.h")).read()
+def _declared(header="dpvo_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dpvo_[a-z0-9_]+)\s*\(", src)))
 
@@ -28,6 +28,17 @@ def test_header_symbols_exported():
     assert sorted(_lib.SYMBOLS) == names, "dpvo_amd/_lib.py SYMBOLS out of sync with include/dpvo_hip.h"
     lib.dpvo_abi_version.restype = ctypes.c_int
     assert lib.dpvo_abi_version() >= 1
+    # the comparator library (two more implementations of the update operator: test / measurement partners) exports what its
+    # own header declares, and the product library does NOT carry those entries
+    cmp_names = _declared("dpvo_hip_cmp.h")
+    cmp = ctypes.CDLL(_lib.CMP_LIB_PATH)
+    assert sorted(_lib.CMP_SYMBOLS) == cmp_names
+    for n in cmp_names:
+        assert hasattr(cmp, n), f"libdpvo_hip_cmp.so does not export {n}"
+    import subprocess
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    for n in cmp_names:
+        assert f" {n}\n" not in exported, f"{n} (a comparator entry) is defined in the product library"
 
 
 def test_layout_and_workspace_queries_are_host_only():
@@ -69,11 +80,17 @@ def test_argument_validation_is_host_only():
     (the reference calls exit(1) in block_e.cu:20-27 and ba.cpp:151-152)"""
     from dpvo_amd import _lib as L
     lib = L.lib()
+    cmp = L.cmp_lib()
     null = ctypes.c_void_p(0)
     INVALID, UNSUPPORTED = -1, -2
-    assert lib.dpvo_update_workspace_bytes(L.i64(45312), L.i64(2300)) > 45312 * 384 * 2 * 5
-    assert lib.dpvo_update_workspace_bytes(L.i64(-1), L.i64(0)) == 0
-    assert lib.dpvo_update_forward(null, null, null, null, L.i64(0), null, L.i64(896), null, L.i64(1), L.i64(1), null, L.i32(3),
+    assert lib.dpvo_update_fused_workspace_bytes(L.i64(45312), L.i64(2300)) > 45312 * 384 * 2 * 5
+    assert lib.dpvo_update_fused_workspace_bytes(L.i64(-1), L.i64(0)) == 0
+    assert lib.dpvo_update_forward_fused(null, null, null, null, L.i64(0), null, L.i64(896), null, L.i64(1), L.i64(1), null, L.i32(3),
+                                         null, null, null, null, L.i64(10), null, ctypes.c_size_t(0), null) == INVALID
+    assert lib.dpvo_keyframe_step(null, null) == INVALID and lib.dpvo_frame_update(null, null) == INVALID
+    assert cmp.dpvo_update_workspace_bytes(L.i64(45312), L.i64(2300)) > 45312 * 384 * 2 * 5
+    assert cmp.dpvo_update_workspace_bytes(L.i64(-1), L.i64(0)) == 0
+    assert cmp.dpvo_update_forward(null, null, null, null, L.i64(0), null, L.i64(896), null, L.i64(1), L.i64(1), null, L.i32(3),
                                    null, null, null, null, L.i64(10), null, ctypes.c_size_t(0), null) == INVALID
     assert lib.dpvo_plan_build_ranged(null, null, null, L.i64(-1), null, null, ctypes.c_size_t(0), L.i64(0), L.i64(0), null) == INVALID
     assert lib.dpvo_frame_patches(null, null, null, null, null, null, null, null, L.f32(4.0), null, null, null, null, null, null,
@@ -82,9 +99,9 @@ def test_argument_validation_is_host_only():
     assert lib.dpvo_frame_patches(null, null, null, null, null, null, null, null, L.f32(4.0), null, null, null, null, null, null,
                                   null, null, L.i32(4), L.i32(1), L.i32(1), L.i32(4), L.i32(4), L.i32(128), L.i32(384), L.i32(5),
                                   L.i64(0), L.i64(0), null) == UNSUPPORTED
-    assert lib.dpvo_heads_target(null, null, null, null, null, null, L.i32(3), null, null, null, L.i64(-3), L.i32(384), null) == INVALID
-    assert lib.dpvo_heads_target(null, null, null, null, null, null, L.i32(3), null, null, null, L.i64(0), L.i32(384), null) == 0
-    assert lib.dpvo_linear(null, L.i32(0), L.i64(384), null, null, L.i64(384), null, null, L.i64(384), null, L.i64(0), null, L.i64(0),
+    assert cmp.dpvo_heads_target(null, null, null, null, null, null, L.i32(3), null, null, null, L.i64(-3), L.i32(384), null) == INVALID
+    assert cmp.dpvo_heads_target(null, null, null, null, null, null, L.i32(3), null, null, null, L.i64(0), L.i32(384), null) == 0
+    assert cmp.dpvo_linear(null, L.i32(0), L.i64(384), null, null, L.i64(384), null, null, L.i64(384), null, L.i64(0), null, L.i64(0),
                            L.i32(0), L.i32(0), L.i64(0), L.i32(384), L.i32(384), null) == 0       # M = 0: nothing to do
     assert lib.dpvo_encoders_workspace_bytes(L.i32(480), L.i32(640)) > 0
     assert lib.dpvo_encoders_workspace_bytes(L.i32(481), L.i32(640)) == 0                          # H, W multiples of 16
@@ -117,7 +134,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
               "dpvo_update_params_t": (_UpdParams, ["c0_w", "g1_b2", "w_b"]),
               "dpvo_frame_state_t": (L.FrameState, ["fmap", "index_map", "poses", "ix", "frame_next", "n_new", "res", "mm_scale", "M",
                                                     "P", "mm_n", "D"])}
-    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dpvo_hip.h"', 'int main(void) {']
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dpvo_hip_cmp.h"', 'int main(void) {']
     for cname, (_, fields) in probes.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
         for f in fields:

@@ -333,3 +333,30 @@ def test_patchgraph_edges_loop_and_normalize_match_the_reference(dev):
     H.assert_close(pg.patches_[:n].cpu().numpy(), g["pg_norm_patches"], 2e-5, 2e-5, "normalize: patches")
     H.assert_close(pg.points_[:n * M].cpu().numpy(), g["pg_norm_points"], 2e-4, 2e-4, "normalize: points")
     H.assert_close(pg.delta[7][1].data.cpu().numpy(), g["pg_norm_delta"], 2e-6, 2e-6, "normalize: delta")
+
+
+def test_tracker_does_not_load_the_comparator_library(dev):
+    """the product path is libdpvo_hip.so alone: a tracker run (initialisation, steady-state frames through the one-call frame
+    path, terminate) never maps libdpvo_hip_cmp.so (the launch-by-launch / patch-major update operators are test partners)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import torch
+from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML
+from dpvo_amd.dpvo import DPVO
+from dpvo_amd.net import VONet
+cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML); cfg.PATCHES_PER_FRAME = 16; cfg.BUFFER_SIZE = 128
+torch.manual_seed(0)
+slam = DPVO(cfg, VONet(), ht=96, wd=128, device=torch.device("cuda:0"), defer_keyframe=True, overlap_encoders=True)
+slam.motion_probe = lambda: 1e9
+g = torch.Generator().manual_seed(0)
+intr = torch.tensor([100.0, 100.0, 64.0, 48.0], device="cuda:0")
+for t in range(24):
+    slam(float(t), torch.randint(0, 255, (3, 96, 128), generator=g, dtype=torch.uint8).cuda(), intr)
+poses, _ = slam.terminate()
+maps = open("/proc/self/maps").read()
+assert "libdpvo_hip.so" in maps and "libdpvo_hip_cmp" not in maps, "comparator library mapped"
+print("ok", poses.shape)
+"""
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

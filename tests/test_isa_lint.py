@@ -29,9 +29,10 @@ def test_pattern_matches_only_the_faulting_selects():
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(isa_lint.LLVM, "llvm-objdump")), reason="ROCm LLVM tools not installed")
-def test_library_is_free_of_the_faulting_form():
-    lib = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip.so")
+@pytest.mark.parametrize("name", ["libdpvo_hip.so", "libdpvo_hip_cmp.so"])
+def test_library_is_free_of_the_faulting_form(name):
+    lib = os.path.join(ROOT, "dpvo_amd", name)
     assert os.path.exists(lib), "build the library first (__graft_entry__.build())"
     n_pk, hits = isa_lint.lint(lib)
-    assert n_pk > 1000          # packed ops are in use (update operator), so the check is not vacuous
+    assert n_pk > 1000          # packed ops are in use (update operators), so the check is not vacuous
     assert hits == []
