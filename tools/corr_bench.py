@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""corr_pyramid_kernel alone on the BASELINE config-2 tensors (E = 47 712 as inside update(), all edges in bounds pattern of
+dpvo_amd.synthetic): HIP-event time per launch and a checksum (variants must agree bit for bit).  Dev tool: DPVO_CORR_STAGED /
+DPVO_CORR_OCC select the variant (read once per process)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dpvo_amd import altcorr, synthetic as S
+from tests import helpers as H
+dev = torch.device("cuda:0")
+ii, jj, kk = S.replay_graph(40)
+E = ii.numel()
+gmap, f0, f1, _ = S.make_features()
+coords = S.make_coords(E).to(dev)
+us, vs = (kk % 3456).to(dev), (jj % 36).to(dev)
+g, a, b = H.gmap_cl(gmap).to(dev), H.to_cl(f0).to(dev), H.to_cl(f1).to(dev)
+out = torch.empty(E, 896, dtype=torch.float16, device=dev)
+for _ in range(5):
+    altcorr.corr_pyramid(g, a, b, coords, us, vs, out=out)
+torch.cuda.synchronize()
+reps = int(os.environ.get("REPS", "40"))
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(reps):
+    altcorr.corr_pyramid(g, a, b, coords, us, vs, out=out)
+e.record(); torch.cuda.synchronize()
+print(f"E={E} staged={os.environ.get('DPVO_CORR_STAGED', '0')} occ={os.environ.get('DPVO_CORR_OCC', '3')}: "
+      f"{s.elapsed_time(e) / reps * 1e3:.1f} us per launch; checksum {out[:, :882].float().abs().sum().item():.6f} "
+      f"{out[:, :882].view(torch.int16).to(torch.int64).sum().item()}")
