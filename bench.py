@@ -54,14 +54,14 @@ MFMA_PEAK_TFLOPS = 2500.0                                       # dense f16 MFMA
 UPDATE_FLOP_EDGE = 2 * (882 * 384 + 16 * 384 * 384 + 2 * 384 * 2)    # Update.forward per edge: 5.40 MFLOP
 
 
-def pmc_traffic():
+def pmc_traffic(config="default"):
     """HBM-side bytes per corr_pyramid_kernel launch from the newest committed PMC pass (tools/pmc_corr.sh, two separate
     rocprofv3 --pmc runs of this same command; corrected as MI355X_MICROARCH.md prescribes) -- but only if that pass measured
     THIS kernel: the file carries the SHA-256 of dpvo_amd/csrc/corr.hip it was taken with, and a file whose fingerprint does not
     match the source in the tree (or has none) is refused.  Returns (bytes or None, reason)."""
     import glob
     import hashlib
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corr_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corr_pmc.json" if config == "default" else f"r*_corr_pmc_{config}.json")))
     if not files:
         return None, "no PMC pass committed"
     try:
@@ -265,7 +265,7 @@ def main():
         avg_ms = sum(corr_ms) / len(corr_ms)
         avg_E = sum(corr_edges) / len(corr_edges)
         streaming = avg_E * B_EDGE / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic() if args.config == "default" else (None, "the committed PMC pass is of the default config")
+        traffic, traffic_src = pmc_traffic(args.config)
         # every byte touched once: live part of the pyramid (34 of 36 frames, both levels) + templates + coords + indices + output
         compulsory_bytes = (34.0 / 36.0) * 36 * 128 * 2 * (120 * 160 + 30 * 40) + 22 * 96 * 9 * 128 * 2 + avg_E * (144 + 32 + 1792)
         counter = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None

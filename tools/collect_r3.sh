@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/collect_r3.sh <tag>: the round-3 profile set in one GPU call (~5 min).  Output: gpurun_out/<tag>/ (copy to profiles/).
+tag=${1:-r3}; root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
+python bench.py > $out/bench.json 2> $out/bench.err; tail -c 300 $out/bench.json; echo
+python bench.py --no-cpu-baseline --config fast > $out/bench_fast.json 2>> $out/bench.err
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && DPVO_BENCH_NO_DROP_LEG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> /tmp/ks.err )
+f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv; python tools/kstats.py $f 45 > $out/kernel_stats_short.txt
+t=$(find /tmp/ks -name "*kernel_trace.csv" | head -1); python tools/frame_timeline.py $t 3 > $out/frame_timeline.txt
+python tools/kernel_tail_avg.py $t corr_pyramid 20 > $out/corr_steady_state.txt
+python tools/stream_stamps.py 2>&1 | grep -v amdgpu > $out/stream_stamps.txt
+bash tools/pmc_corr.sh > $out/pmc_corr.log 2>&1; cp gpurun_out/corr_pmc.json $out/corr_pmc.json
+CONFIG=fast bash tools/pmc_corr.sh > $out/pmc_corr_fast.log 2>&1; cp gpurun_out/corr_pmc_fast.json $out/corr_pmc_fast.json
+bash tools/pmc_update.sh > $out/update_pmc_sq.txt 2>&1
+bash tools/pmc_update_mem.sh > $out/update_pmc_mem.txt 2>&1
+if [ -f dpvo_amd/libdpvo_hip_trace.so ]; then DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_trace.so MODE=seven python tools/fu_trace.py 2>&1 | grep -v amdgpu > $out/trace_seven.txt; fi
+WHICH=both python tools/update_bench.py 2>&1 | grep -v amdgpu > $out/update_bench.txt
+python tools/corr_bench.py 2>&1 | grep -v amdgpu > $out/corr_bench.txt
+python tools/ba_bench.py 2>&1 | grep -v amdgpu > $out/ba_bench.txt
+python tools/host_time.py tottime 2>&1 | grep -v amdgpu | head -30 > $out/host_profile.txt
+python -m pytest tests/test_gpu_ref.py -q -s -m gpu 2>&1 | grep -v amdgpu > $out/ref_parity.txt
+ls -la $out

@@ -2,24 +2,27 @@
 # Two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE cannot share one) over a short bench run; writes the per-launch means of
 # corr_pyramid_kernel to gpurun_out/corr_pmc.json (copy it to profiles/rNN_corr_pmc.json: bench.py reports it as
 # roofline.traffic).  Kernel-trace only, as the GPU pool requires for counter collection.
+# CONFIG=fast: the same for config/fast.yaml -> gpurun_out/corr_pmc_fast.json (profiles/rNN_corr_pmc_fast.json).
 set -e
-root=$(pwd); out=$root/gpurun_out/pmc_corr; mkdir -p $out
+cfg=${CONFIG:-default}; sfx=""; [ "$cfg" != "default" ] && sfx="_$cfg"
+root=$(pwd); out=$root/gpurun_out/pmc_corr$sfx; mkdir -p $out
+export DPVO_BENCH_NO_DROP_LEG=1 PMC_OUT=$out PMC_SFX=$sfx
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd $root && DPVO_BENCH_SYNC_EVERY_FRAME=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python bench.py --steps 8 --warmup 45 > $out/$c.log 2>&1)
+  (cd $root && DPVO_BENCH_SYNC_EVERY_FRAME=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python bench.py --steps 8 --warmup 45 --no-cpu-baseline --config $cfg > $out/$c.log 2>&1)
 done
 cd $root
 python - <<'PY'
-import csv, glob, hashlib, json
-res = {"corr_hip_sha256": hashlib.sha256(open("dpvo_amd/csrc/corr.hip", "rb").read()).hexdigest()}   # bench.py ignores the file once the kernel source changes
+import csv, glob, hashlib, json, os
+res = {"config": os.environ.get("CONFIG", "default"), "corr_hip_sha256": hashlib.sha256(open("dpvo_amd/csrc/corr.hip", "rb").read()).hexdigest()}   # bench.py ignores the file once the kernel source changes
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"gpurun_out/pmc_corr/{c}/**/*counter_collection.csv", recursive=True)[0]
+    f = glob.glob(os.environ["PMC_OUT"] + f"/{c}/**/*counter_collection.csv", recursive=True)[0]
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "corr_pyramid_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
     v = v[len(v) // 2:]                      # steady-state launches only
     res[c + "_KB_per_launch"] = sum(v) / len(v); res[c + "_launches"] = len(v)
 # MI355X_MICROARCH.md, HBM section: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
 res["traffic_bytes_per_launch"] = res["FETCH_SIZE_KB_per_launch"] * 1024 * 2 + res["WRITE_SIZE_KB_per_launch"] * 1024
 res["correction"] = "bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)"
-json.dump(res, open("gpurun_out/corr_pmc.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/corr_pmc" + os.environ["PMC_SFX"] + ".json", "w"), indent=1)
 print(res)
 PY
