@@ -37,7 +37,8 @@ SYMBOLS = [
 # partners of the product's seven-launch operator, never loaded by the tracker (cmp_lib() below)
 CMP_LIB_PATH = os.environ.get("DPVO_HIP_CMP_LIB") or os.path.join(_HERE, "libdpvo_hip_cmp.so")
 CMP_SYMBOLS = ["dpvo_linear", "dpvo_layernorm", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target",
-               "dpvo_update_workspace_bytes", "dpvo_update_forward", "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm"]
+               "dpvo_update_workspace_bytes", "dpvo_update_forward", "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm",
+               "dpvo_update_pm2_workspace_bytes", "dpvo_update_forward_pm2"]
 
 
 class DPVOHipError(RuntimeError):
@@ -129,7 +130,7 @@ def cmp_lib():
         for s in CMP_SYMBOLS:
             if not hasattr(C, s):
                 raise DPVOHipError(f"libdpvo_hip_cmp.so does not export {s}")
-        for s in ("dpvo_update_workspace_bytes", "dpvo_update_pm_workspace_bytes"):
+        for s in ("dpvo_update_workspace_bytes", "dpvo_update_pm_workspace_bytes", "dpvo_update_pm2_workspace_bytes"):
             getattr(C, s).restype = ctypes.c_size_t
         _cmp = C
     return _cmp

@@ -282,7 +282,7 @@ class Update(nn.Module):
         inp2 = inp2.contiguous()
 
         if net_rows is not None:
-            seven = composite and net2.dtype == torch.float32 and (fused is True or (fused is None and FUSED_DEFAULT)) and not PM_DEFAULT
+            seven = composite and net2.dtype == torch.float32 and (fused is True or fused == "pm2" or (fused is None and FUSED_DEFAULT)) and not PM_DEFAULT
             if not seven:
                 rows, n_kept, src = net_rows
                 tmp = workspace.get(E * DIM * 4, dev, "net_gather")[:E * DIM * 4].view(torch.float32).view(E, DIM)
@@ -316,6 +316,20 @@ class Update(nn.Module):
             maxg = max(plan.n_patches_host, plan.n_pairs_host)
             if fused is None:
                 fused = FUSED_DEFAULT
+            if fused == "pm2":
+                # four launches over 64-row tiles of whole patches packed by size (update_pm2.hip)
+                nbytes = L.cmp_lib().dpvo_update_pm2_workspace_bytes(L.i64(E), L.i64(maxg))
+                ws = workspace.get(nbytes, dev, "update_pm2")
+                st = workspace.get(4, dev, "update_pm2_status")
+                rows, n_kept = net_rows[:2] if net_rows is not None else (None, 0)
+                L.check(L.cmp_lib().dpvo_update_forward_pm2(
+                    ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(rows), L.i64(n_kept), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod),
+                    L.ptr(corr2), L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
+                    L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
+                    L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
+                    ctypes.c_size_t(ws.numel()), L.ptr(st), L.stream()), "dpvo_update_forward_pm2")
+                self.pm_status = st
+                return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
             if fused == "pm" or (fused is True and PM_DEFAULT):
                 # four launches, edges in per-patch order (update_fused.hip, "patch-major"): needs an upper bound on the
                 # number of edges of one patch (DPVO passes 2 * PATCH_LIFETIME - 1; computed here, with a sync, otherwise)

@@ -86,6 +86,16 @@ int dpvo_update_forward_pm(const dpvo_update_fused_params_t* params, const float
                            int64_t n_pairs_ub, int64_t patch_edges_ub, const float* coords, int P, float* net_out, float* delta,
                            float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, int32_t* status, void* stream);
 
+/* Four launches over 64-row tiles of whole patches packed by size, f32 state in registers from the first layer to the last
+ * (update_pm2.hip).  Contract of dpvo_update_forward_fused_rows; status (device int32, may be NULL) = 1 if the graph does not fit
+ * the packing (a patch with more than 64 edges, more than 4096 patches). */
+size_t dpvo_update_pm2_workspace_bytes(int64_t E, int64_t max_groups);
+int dpvo_update_forward_pm2(const dpvo_update_fused_params_t* params, const float* net, const int64_t* net_rows, int64_t n_kept,
+                            const void* inp, const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr,
+                            const int32_t* plan, int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
+                            float* delta, float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, int32_t* status,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["DPVO_HIP_LIB"] = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_trace.so")
+if os.environ.get("MODE", "pm") == "pm2":
+    os.environ["DPVO_HIP_CMP_LIB"] = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_cmp_trace.so")
 sys.path.insert(0, ROOT)
 import ctypes          # noqa: E402
 
@@ -56,15 +58,16 @@ def main():
     mode = os.environ.get("MODE", "pm")
     N.PM_DEFAULT = False
     run = lambda: upd(net, imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True,
-                      fused=("pm" if mode == "pm" else True), patch_edges_ub=25)
+                      fused=(mode if mode in ("pm", "pm2") else True), patch_edges_ub=25)
+    setter = L.cmp_lib().dpvo_debug_pm2_trace_buffer if mode == "pm2" else L.lib().dpvo_debug_fu_trace_buffer
     for _ in range(3):
         run()
     buf = torch.zeros(8 * 1024 * 4 * 16, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-    assert L.lib().dpvo_debug_fu_trace_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
+    assert setter(ctypes.c_void_p(buf.data_ptr())) == 0
     run()
     torch.cuda.synchronize()
-    L.lib().dpvo_debug_fu_trace_buffer(ctypes.c_void_p(0))
+    setter(ctypes.c_void_p(0))
     t = buf.cpu().numpy().reshape(8, 1024, 4, 16).astype(np.int64)
     kb = t[6, :256, 0]
     ok = (kb[:, 13] > kb[:, 12]) & (kb[:, 4] > kb[:, 0])
@@ -73,9 +76,14 @@ def main():
         print(f"shader clock during KB (s_memtime ticks per us of wall clock): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
     t[6, :, :, 12:] = 0
     nb = (E + 95) // 96
+    if mode == "pm2":
+        NAMES[5] = ("KA2 (64-row tiles of whole patches)", ["corr GEMM 896", "c2 + LN", "c5 + net/inp + LN", "c1, c2 (4 GEMMs)", "f, g of agg_kk",
+                                                             "softmax-sum", "h + expand + img", "f, g of agg_ij + rows out"])
+        NAMES[6] = ("KB2", ["y rows + GEMM h + img", "LN + gated residual 0", "LN + gated residual 1", "net out + heads"])
+        NAMES.pop(7, None)
     for k, (name, phases) in NAMES.items():
         if k >= 5:
-            nb = 256                                   # persistent workgroups: the stamps are those of the LAST tile of each
+            nb = 256 if mode != "pm2" else 700         # (pm: the first 256 tiles; pm2: ~730 tiles, the trace holds 1024)
         a = t[k, :nb]                                  # [block, wave, stamp]
         used = [i for i in range(16) if (a[:, 0, i] != 0).any()]
         if not used:

@@ -53,7 +53,7 @@ def main():
         kw = dict(plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True)
         flops = 2 * E * (896 * 384 + 16 * 384 * 384)
         out = {}
-        for name, fz in (("pm", "pm"), ("fused", True), ("unfused", False)):
+        for name, fz in (("pm2", "pm2"), ("pm", "pm"), ("fused", True), ("unfused", False)):
             if which not in ("both", name):
                 continue
             N.PM_DEFAULT = False
@@ -62,7 +62,7 @@ def main():
             out[name] = upd(net, imap[None], corr[None], None, ii, jj, kk, fused=fz, **kw)
             print(f"E={E} {name:8s} {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s (reference FLOPs)  "
                   f"{flops / ms / 1e9 / 2500:.3f} of dense f16 peak")
-        for nm in ("pm", "fused"):
+        for nm in ("pm2", "pm", "fused"):
             if nm not in out or "unfused" not in out:
                 continue
             a, b = out[nm], out["unfused"]
