@@ -15,7 +15,7 @@
 //   gba_schur_kernel     per (source frame, block a, block b): S -= sum_slot Q ea eb^T, y -= sum_slot Q u ea; the sum
 //                        over the frame's M patch slots is reduced IN the wave, then 36 atomics per block pair
 //                        (the reference issues 36 atomics per block pair PER PATCH)
-//   host                 S += I*(1e-4*S+1); potrf / potrs (rocSOLVER through ATen, as the reference does)
+//   dpvo_gba_solve       S += I*(1e-4*S+1); blocked Cholesky + both substitutions on the device (chol.hip)
 //   gba_retr_kernel      dZ = Q (u - e^T dX), depth + pose retraction
 #include "ba_common.h"
 

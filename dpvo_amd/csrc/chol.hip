@@ -1,0 +1,240 @@
+// chol.hip -- dense Cholesky solve of the damped global-BA system on gfx950.
+//
+// Replaces the `torch::linalg_cholesky_ex` + `torch::cholesky_solve` pair of the reference's global BA
+// (dpvo/fastba/ba_cuda.cu:546-548; caller DPVO.__run_global_BA, dpvo/dpvo.py:312-326): 6N x 6N f32, N = free poses (hundreds
+// with LOOP_CLOSURE).  rocSOLVER took 16 ms per factorisation at 6N = 4 794; this is a blocked right-looking factorisation whose
+// rank-64 trailing updates run on v_mfma_f32_32x32x2_f32, with no atomics anywhere: the result is bit-repeatable run to run.
+//
+//   chol_load_kernel     S (n x n, the caller's) -> the work matrix Lw ((nb + 1) x nb blocks of 64 x 64, row-major, ld = 64 nb):
+//                        damping S_ii += 1e-4 S_ii + 1 (ba_cuda.cu:546), identity on the padded diagonal, and the right-hand side
+//                        as ROW 64 nb.  Factorising the bordered matrix [S b; b^T .] leaves L^-1 b in that row, so the forward
+//                        substitution costs nothing extra.
+//   per panel k:
+//   chol_panel_kernel    one wave per row block below the diagonal block (the border row included): every wave factorises the
+//                        64 x 64 diagonal block by itself, in registers (cheaper than a launch + a round trip through memory),
+//                        then solves its own block against it: X = A_ik L_kk^-T.  L_kk is kept in Dg[k].
+//   chol_update_kernel   one workgroup per 64 x 64 tile (i >= j > k) of the trailing matrix: A_ij -= L_ik L_jk^T, K = 64 as
+//                        32 steps of the 32x32x2 f32 MFMA per wave, operands straight from L2 into the fragment registers.
+//   chol_back_kernel     per block column from the last: x_k = L_kk^-T y_k (one wave, in registers), then every workgroup takes one
+//                        block j < k: y_j -= L_kj^T x_k.
+#include "common.h"
+
+namespace {
+
+constexpr int NB = 64;
+
+__global__ __launch_bounds__(256) void chol_load_kernel(const float* __restrict__ S, const float* __restrict__ y, int n,
+                                                        float* __restrict__ Lw, int np) {
+#pragma clang fp contract(off)
+  const int64_t total = (int64_t)(np + NB) * np;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(q / np), c = (int)(q - (int64_t)r * np);
+    float v = 0.f;
+    if (r < n && c < n) {
+      v = S[(int64_t)r * n + c];
+      if (r == c) { const float t = v * 1e-4f + 1.0f; v = v + t; }       // d.add_(1e-4 * d + 1.0)
+    } else if (r == c) {
+      v = 1.f;
+    } else if (r == np && c < n) {
+      v = y[c];
+    }
+    Lw[q] = v;
+  }
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {          // lane must be a compile-time constant after unrolling
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// One wave per row block.  Lane i keeps row i of the diagonal block in registers and factorises it column by column (no workgroup
+// barrier: 64 fully unrolled steps); the entries above the diagonal go along as don't-cares.  The
+// same wave then solves its own block against the factor: lane r keeps row r of A_ik, x_c = b_c / L_cc, b_c' -= x_c L_c'c.
+// (A 256-thread version with the block in LDS and two barriers per column took 80 us per panel; this one takes ~20.)
+__global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, float* __restrict__ Dg, float* __restrict__ Di, int ld, int k) {
+  const int t = threadIdx.x;
+  const int bi = k + 1 + blockIdx.x;
+  const float* Akk = Lw + ((int64_t)k * NB) * ld + k * NB;
+  float* Bik = Lw + ((int64_t)bi * NB) * ld + k * NB;
+  float a[NB], b[NB];
+  {
+    const f4* src = reinterpret_cast<const f4*>(Akk + (int64_t)t * ld);
+    const f4* srb = reinterpret_cast<const f4*>(Bik + (int64_t)t * ld);
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+      const f4 v = src[q]; a[4 * q] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
+      const f4 u = srb[q]; b[4 * q] = u[0]; b[4 * q + 1] = u[1]; b[4 * q + 2] = u[2]; b[4 * q + 3] = u[3];
+    }
+  }
+  // column j of L is published in LDS as it is made (Lc[j][i] = L_ij): the other lanes read it back as 16-byte broadcasts,
+  // four multipliers per LDS instruction instead of one v_readlane each; the solve below reads the same columns again.
+  __shared__ __attribute__((aligned(16))) float Lc[NB][NB];
+  __shared__ float invs[NB];
+#pragma clang loop unroll(full)
+  for (int j = 0; j < NB; ++j) {
+    // (the hardware square root and reciprocal, 1 ulp each: the IEEE sequences are 40 instructions per column, a quarter of the kernel)
+    const float d = __builtin_amdgcn_sqrtf(lane_bcast(a[j], j));
+    const float inv = __builtin_amdgcn_rcpf(d);
+    const float l = (t == j) ? d : a[j] * inv;       // lanes above the diagonal: don't-care
+    a[j] = l;
+    Lc[j][t] = l;
+    if (t == j) invs[j] = inv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int q0 = (j + 1) >> 2;
+      f4 v[NB / 4];
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q) if (q >= q0) v[q] = *reinterpret_cast<const f4*>(&Lc[j][4 * q]);
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * q + e;
+          if (q >= q0 && c > j) {
+            a[c] -= l * v[q][e];
+            asm volatile("" : "+v"(a[c]));           // (pins the update here: LLVM otherwise sinks it to step c and keeps 2 016 loaded values alive)
+          }
+        }
+    }
+  }
+  if (blockIdx.x == 0) {
+    Di[k * NB + t] = invs[t];
+    f4* dst = reinterpret_cast<f4*>(Dg + (int64_t)k * NB * NB + t * NB);
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+      f4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (4 * q + e <= t) ? a[4 * q + e] : 0.f;
+      dst[q] = v;
+    }
+  }
+#pragma clang loop unroll(full)
+  for (int c = 0; c < NB; ++c) {
+    const float x = b[c] * invs[c];
+    b[c] = x;
+    {
+      const int q0 = (c + 1) >> 2;
+      f4 v[NB / 4];
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q) if (q >= q0) v[q] = *reinterpret_cast<const f4*>(&Lc[c][4 * q]);
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c2 = 4 * q + e;
+          if (q >= q0 && c2 > c) { b[c2] -= x * v[q][e]; asm volatile("" : "+v"(b[c2])); }
+        }
+    }
+  }
+  f4* dst = reinterpret_cast<f4*>(Bik + (int64_t)t * ld);
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) { f4 v = {b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]}; dst[q] = v; }
+}
+
+__global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ Lw, int ld, int k, int r) {
+  // tile enumeration: lower triangle of the r trailing blocks (rows first), then the border row (block r) against blocks 0..r-1
+  const int b = blockIdx.x;
+  const int ntri = r * (r + 1) / 2;
+  int i, j;
+  if (b < ntri) {
+    i = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
+    while (i * (i + 1) / 2 > b) --i;
+    while ((i + 1) * (i + 2) / 2 <= b) ++i;
+    j = b - i * (i + 1) / 2;
+  } else {
+    i = r; j = b - ntri;
+  }
+  const int bi = k + 1 + i, bj = k + 1 + j;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qi = w >> 1, qj = w & 1;
+  if (bi == bj && qi < qj) return;                          // upper quadrant of a diagonal tile: never read
+  const int m = lane & 31, kh = lane >> 5;
+  // fragments: lane (m, kh) holds elements [32 kh, 32 kh + 32) of row m of its quadrant's 32 x 64 operand; MFMA step s
+  // consumes element s of every lane (k = s from the lanes with kh = 0, k = 32 + s from the others) -- the same permutation of
+  // the summation index on both operands.
+  const f4* pa = reinterpret_cast<const f4*>(Lw + ((int64_t)bi * NB + 32 * qi + m) * ld + k * NB + 32 * kh);
+  const f4* pb = reinterpret_cast<const f4*>(Lw + ((int64_t)bj * NB + 32 * qj + m) * ld + k * NB + 32 * kh);
+  f4 a[8], bb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { a[q] = pa[q]; bb[q] = pb[q]; }
+  // C fragment: acc[4 g + rr] <-> row 8 g + 4 kh + rr, column m
+  float* C = Lw + ((int64_t)bi * NB + 32 * qi) * ld + bj * NB + 32 * qj + m;
+  f16v acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[4 * g + rr] = C[(int64_t)(8 * g + 4 * kh + rr) * ld];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[q][e], bb[q][e], acc, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) C[(int64_t)(8 * g + 4 * kh + rr) * ld] = acc[4 * g + rr];
+}
+
+__global__ __launch_bounds__(256) void chol_back_kernel(const float* __restrict__ Lw, const float* __restrict__ Dg, const float* __restrict__ Di, int ld, float* __restrict__ yv,
+                                                        float* __restrict__ x_out, int n, int k) {
+  __shared__ float A[NB][NB + 1];
+  __shared__ float xs[NB];
+  __shared__ float part[4][NB];
+  const int t = threadIdx.x;
+  for (int idx = t; idx < NB * NB; idx += 256) A[idx >> 6][idx & 63] = Dg[(int64_t)k * NB * NB + idx];
+  __syncthreads();
+  if (t < NB) {
+    float yl = yv[k * NB + t], x = 0.f;
+    const float il = Di[k * NB + t];
+#pragma unroll
+    for (int c = NB - 1; c >= 0; --c) {
+      const float xc = lane_bcast(yl, c) * lane_bcast(il, c);
+      if (t < c) yl -= A[c][t] * xc;
+      if (t == c) x = xc;
+    }
+    xs[t] = x;
+    if (blockIdx.x == 0 && k * NB + t < n) x_out[k * NB + t] = x;
+  }
+  __syncthreads();
+  if ((int)blockIdx.x < k) {
+    const int j = blockIdx.x, q = t >> 6, c = t & 63;
+    const float* Lkj = Lw + ((int64_t)k * NB + 16 * q) * ld + j * NB + c;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += Lkj[(int64_t)r * ld] * xs[16 * q + r];
+    part[q][c] = s;
+    __syncthreads();
+    if (t < NB) yv[j * NB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t dpvo_gba_solve_workspace_bytes(int n) {
+  const size_t np = (size_t)((n > 0 ? n : 1) + NB - 1) / NB * NB;
+  return ((np + NB) * np + np * NB + np) * sizeof(float);
+}
+
+extern "C" int dpvo_gba_solve(const float* S, const float* y, int n, float* dX, void* ws, size_t ws_bytes,
+                              void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0 || !S || !y || !dX || !ws) return DPVO_E_INVALID;
+  if (ws_bytes < dpvo_gba_solve_workspace_bytes(n)) return DPVO_E_WORKSPACE;
+  const int nb = (n + NB - 1) / NB, np = nb * NB;
+  float* Lw = (float*)ws;
+  float* Dg = Lw + (int64_t)(np + NB) * np;               // the diagonal blocks' factors [nb][64][64]
+  float* Di = Dg + (int64_t)np * NB;                       // 1 / L_jj
+  const int64_t total = (int64_t)(np + NB) * np;
+  const int lg = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(chol_load_kernel, dim3(lg), dim3(256), 0, stream, S, y, n, Lw, np);
+  for (int k = 0; k < nb; ++k) {
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(nb - k), dim3(64), 0, stream, Lw, Dg, Di, np, k);
+    const int r = nb - k - 1;
+    if (r > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(r * (r + 1) / 2 + r), dim3(256), 0, stream, Lw, np, k, r);
+  }
+  float* yv = Lw + (int64_t)np * np;
+  for (int k = nb - 1; k >= 0; --k)
+    hipLaunchKernelGGL(chol_back_kernel, dim3(k > 0 ? k : 1), dim3(256), 0, stream, Lw, Dg, Di, np, yv, dX, n, k);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}

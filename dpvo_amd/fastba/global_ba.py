@@ -2,9 +2,9 @@
 DPVO.__run_global_BA, dpvo/dpvo.py:312-326).
 
 Routed here when `eff_impl=True` or when more than 20 poses are free (beyond the in-LDS dense Schur path).
-Linearisation, block-sparse Schur complement and the retractions are HIP kernels (dpvo_amd/csrc/ba_global.hip);
-the 6N x 6N damped system is factorised by rocSOLVER through ATen (`torch.linalg.cholesky_ex` + `cholesky_solve`),
-exactly the division of labour of the reference (ba_cuda.cu:546-548)."""
+Linearisation, block-sparse Schur complement and the retractions are HIP kernels (dpvo_amd/csrc/ba_global.hip); the
+6N x 6N damped system is solved by the blocked device Cholesky of dpvo_amd/csrc/chol.hip (`dpvo_gba_solve`: damping,
+factorisation and both substitutions; the reference calls cuSOLVER through ATen there, ba_cuda.cu:546-548)."""
 import ctypes
 
 import torch
@@ -51,9 +51,12 @@ def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0,
     n6 = 6 * N
     dev = poses.device
     # the damped system and its right-hand side live in a per-stream scratch buffer (no allocation per iteration)
-    sy = workspace.get((n6 * n6 + n6) * 4, dev, "gba_sys").view(torch.float32)
+    sy = workspace.get((n6 * n6 + 2 * n6) * 4, dev, "gba_sys").view(torch.float32)
     S = sy[:n6 * n6].view(n6, n6)
     y = sy[n6 * n6:n6 * n6 + n6]
+    dX = sy[n6 * n6 + n6:n6 * n6 + 2 * n6]
+    cws_bytes = L.lib().dpvo_gba_solve_workspace_bytes(L.i32(n6))
+    cws = workspace.get(cws_bytes, dev, "gba_chol")
     ev = None
     if _PROFILE is not None:
         ev = torch.cuda.Event(enable_timing=True)
@@ -66,12 +69,10 @@ def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0,
             L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(S), L.ptr(y), L.ptr(ws), ctypes.c_size_t(ws.numel()),
             L.stream()), "dpvo_gba_linearize")
         ev = _mark("linearise + Schur", ev)
-        d = S.diagonal()
-        d.add_(1e-4 * d + 1.0)                                    # S += I * (1e-4 * S + 1.0)   (ba_cuda.cu:546)
-        U, info = torch.linalg.cholesky_ex(S)                      # info ignored by the reference (:547)
-        ev = _mark("damping + Cholesky (rocSOLVER)", ev)
-        dX = torch.cholesky_solve(y[:, None], U)[:, 0].contiguous()
-        ev = _mark("triangular solves", ev)
+        # S += I * (1e-4 * S + 1.0); U = cholesky(S); dX = cholesky_solve(y, U)   (ba_cuda.cu:546-548)
+        L.check(L.lib().dpvo_gba_solve(L.ptr(S), L.ptr(y), L.i32(n6), L.ptr(dX), L.ptr(cws), ctypes.c_size_t(cws_bytes),
+                                       L.stream()), "dpvo_gba_solve")
+        ev = _mark("damping + Cholesky + substitutions (chol.hip)", ev)
         L.check(L.lib().dpvo_gba_retract(
             L.ptr(poses), L.ptr(patches), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(E),
             L.i32(P), L.i32(M), L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(dX), L.ptr(ws),

@@ -437,7 +437,7 @@ int dpvo_pool4_nhwc(const void* in, void* out, int h, int w, int C, void* stream
 /* Global BA == cuda_ba.forward(..., eff_impl=True) (ba_cuda.cu:475-478,538-550 with EfficentE, block_e.cu:43-300),
  * used by DPVO.__run_global_BA (dpvo/dpvo.py:312-326).  One Gauss-Newton iteration is
  *     zero S[6N,6N], y[6N];  dpvo_gba_linearize -> S = B - E Q E^T, y = v - E Q u  (block-sparse E, device plan);
- *     host: S += I*(1e-4*S + 1), dX = cholesky_solve(y, cholesky(S))   (rocSOLVER via ATen, as the reference);
+ *     dpvo_gba_solve -> S += I*(1e-4*S + 1), dX = cholesky_solve(y, cholesky(S))   (blocked device Cholesky, chol.hip);
  *     dpvo_gba_retract(dX) -> dZ = Q (u - E^T dX), depth and pose retraction in place.
  * f0 / n_frames: first source frame that owns a patch in kk and the number of frames up to the last one
  * (patch p belongs to frame p / M); M = patches per frame (PPF); plan from dpvo_plan_build(ii,jj,kk);
@@ -450,6 +450,14 @@ int dpvo_gba_linearize(const float* poses, const float* patches, const float* in
 int dpvo_gba_retract(float* poses, float* patches, const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E,
                      int P, int M, int f0, int n_frames, int t0, int t1, const float* dX, void* ws, size_t ws_bytes,
                      void* stream);
+
+/* Dense solve of the damped global-BA system on the device: dX = (S + diag(1e-4 S_ii + 1))^-1 y by a blocked Cholesky
+ * factorisation (chol.hip).  Replaces `S += I*(1e-4*S+1); U = linalg_cholesky_ex(S); dX = cholesky_solve(y, U)` of the reference
+ * (dpvo/fastba/ba_cuda.cu:546-548) -- the damping is applied here, S and y are left untouched.  S: [n,n] row-major symmetric
+ * (the lower triangle is read), y: [n], dX: [n], n = 6 * free poses.  No atomics: bit-repeatable.  A matrix that is not positive
+ * definite gives NaNs in dX (the reference ignores cholesky_ex's info the same way, ba_cuda.cu:547). */
+size_t dpvo_gba_solve_workspace_bytes(int n);
+int dpvo_gba_solve(const float* S, const float* y, int n, float* dX, void* ws, size_t ws_bytes, void* stream);
 
 /* Dev aid: a one-thread kernel that stores the 100 MHz wall clock into *slot (uint64) when it executes: stream-ordered time
  * stamps across streams without a profiler (tools/stream_stamps.py). */

@@ -1,0 +1,89 @@
+"""dpvo_gba_solve (dpvo_amd/csrc/chol.hip): the device Cholesky solve of the damped global-BA system, replacing
+torch::linalg_cholesky_ex + torch::cholesky_solve of the reference (dpvo/fastba/ba_cuda.cu:546-548).  Checked against numpy's f64
+solve of the same damped system, against ATen's f32 Cholesky (what the reference calls), and for bit-repeatability."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dpvo_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(n, seed, cond=1e3):
+    """a symmetric positive definite f32 matrix with the block structure of a reduced camera system: strong 6 x 6 diagonal
+    blocks, weaker coupling elsewhere, eigenvalues spread over `cond`"""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n + 8))
+    S = A @ A.T / (n + 8)
+    d = np.geomspace(1.0, cond, n)
+    rng.shuffle(d)
+    S = S * np.sqrt(d)[:, None] * np.sqrt(d)[None, :] + np.diag(d)
+    return S.astype(np.float32), rng.standard_normal(n).astype(np.float32)
+
+
+def _solve(S, y, dev):
+    n = S.shape[0]
+    Sd, yd = torch.from_numpy(S).to(dev), torch.from_numpy(y).to(dev)
+    S0 = Sd.clone()
+    x = torch.full((n,), float("nan"), device=dev)
+    nbytes = L.lib().dpvo_gba_solve_workspace_bytes(L.i32(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    L.check(L.lib().dpvo_gba_solve(L.ptr(Sd), L.ptr(yd), L.i32(n), L.ptr(x), L.ptr(ws), ctypes.c_size_t(nbytes), L.stream()),
+            "dpvo_gba_solve")
+    torch.cuda.synchronize()
+    assert torch.equal(Sd, S0), "S must be left untouched"
+    return x
+
+
+def _damped64(S):
+    S64 = S.astype(np.float64).copy()
+    d = np.diag(S).astype(np.float32)
+    idx = np.arange(S.shape[0])
+    S64[idx, idx] = (d + (d * np.float32(1e-4) + np.float32(1.0))).astype(np.float64)     # the f32 arithmetic of d.add_(1e-4*d+1)
+    return S64
+
+
+@pytest.mark.parametrize("n", [6, 60, 63, 64, 65, 128, 300, 1434, 2400])
+def test_solve_vs_numpy_f64(dev, n):
+    S, y = _spd(n, seed=n)
+    x = _solve(S, y, dev).cpu().numpy().astype(np.float64)
+    S64 = _damped64(S)
+    ref = np.linalg.solve(S64, y.astype(np.float64))
+    # backward error of an f32 Cholesky solve: ||S x - y|| / (||S|| ||x|| + ||y||) ~ n eps; forward error scaled by the condition
+    resid = np.linalg.norm(S64 @ x - y) / (np.linalg.norm(S64, 2) * np.linalg.norm(x) + np.linalg.norm(y))
+    rel = np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    # what ATen's f32 Cholesky (the reference's solver) achieves on the same system
+    Sd = torch.from_numpy(S).to(dev); Sd.diagonal().add_(1e-4 * Sd.diagonal() + 1.0)
+    U, _ = torch.linalg.cholesky_ex(Sd)
+    xa = torch.cholesky_solve(torch.from_numpy(y).to(dev)[:, None], U)[:, 0].cpu().numpy().astype(np.float64)
+    rel_a = np.linalg.norm(xa - ref) / np.linalg.norm(ref)
+    print(f"n = {n}: backward error {resid:.2e}, |x - x64| / |x64| = {rel:.2e}  (ATen f32 Cholesky: {rel_a:.2e})")
+    assert np.isfinite(x).all()
+    assert resid < 2e-6
+    assert rel < max(4 * rel_a, 2e-5)
+
+
+def test_solve_is_bit_repeatable(dev):
+    S, y = _spd(1434, seed=3)
+    a = _solve(S, y, dev)
+    for _ in range(3):
+        assert torch.equal(a, _solve(S, y, dev))
+
+
+def test_not_positive_definite_gives_nan_not_a_hang(dev):
+    S, y = _spd(130, seed=1)
+    S[70, 70] = -50.0
+    x = _solve(S, y, dev)
+    assert torch.isnan(x).any()
+
+
+def test_workspace_too_small_is_refused(dev):
+    S, y = _spd(64, seed=2)
+    Sd, yd = torch.from_numpy(S).to(dev), torch.from_numpy(y).to(dev)
+    x = torch.empty(64, device=dev)
+    ws = torch.empty(1024, dtype=torch.uint8, device=dev)
+    rc = L.lib().dpvo_gba_solve(L.ptr(Sd), L.ptr(yd), L.i32(64), L.ptr(x), L.ptr(ws), ctypes.c_size_t(1024), L.stream())
+    assert rc != 0
