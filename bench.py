@@ -32,6 +32,7 @@ The JSON line also carries
                   of the whole operator (HIP events around it on the launch stream) against the 2.5 PFLOP/s dense f16 MFMA peak;
   cpu_baseline -- the CPU oracle ("port": oracle/liboracle.so + oracle/update_ref.py) timed on rank 0 at N = 1 on
                   two full hot-path steps (reproject, corr, update, 2 BA iterations at E = 45 312), ~10 s;
+  box          -- the shader clock this box sustains under a full-chip / quarter-chip MFMA load (tools/probes/clock_probe.hip);
   state        -- whether the tracker state after the run is sane (finite poses, fraction of edges that project in
                   bounds): with random weights nothing guarantees that, and a diverged state would make the correlation
                   kernel skip its work; such a run carries an "error" field.
@@ -85,6 +86,22 @@ def make_stream(n_frames, ht, wd, device, seed=1234):
         dx, dy = (3 * t) % 256, (2 * t) % 256
         frames.append(tex[:, dy:dy + ht, dx:dx + wd])
     return torch.stack(frames).to(device)
+
+
+def box_clock():
+    """Shader clock this box sustains under a full-chip MFMA load (tools/probes/clock_probe.hip, built by
+    __graft_entry__.build(); ~1 s after the timed region): the same build measures +-3 % frames/sec from box to box, and this is
+    the box-side number next to it.  None when the probe binary is missing."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "probes", "clock_probe.bin")
+    if not os.path.isfile(exe):
+        return None
+    try:
+        torch.cuda.synchronize()
+        r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=60)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:          # noqa: BLE001  (telemetry only)
+        return {"error": str(e)[:200]}
 
 
 def cpu_baseline():
@@ -321,6 +338,8 @@ def main():
                            "net_sum": float(slam.pg.net.double().abs().sum().item()), "in_bounds": round(inb, 4),
                            "ptr": {k: hex(getattr(slam, k).data_ptr()) for k in ("_fmap1_cl", "_fmap2_cl", "_gmap_cl", "imap_")},
                            "corr_ms_minmax": [round(min(corr_ms), 4), round(max(corr_ms), 4)]}
+        if world == 1:
+            out["box"] = box_clock()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
