@@ -1,7 +1,9 @@
 """Feature encoders of the Patchifier (reference dpvo/extractor.py:6-55,200-264).
 
-NOT on the north-star hot path ("next #1"): plain torch.nn modules whose convolutions run on
-MIOpen through PyTorch-ROCm.  Module / parameter names follow the reference so `dpvo.pth` state dicts load."""
+The weight containers: plain torch.nn modules whose names / parameter names follow the reference so that `dpvo.pth` state dicts load
+strictly.  The tracker does NOT run their forward: dpvo_amd/encoders.py packs their weights once and runs both towers through the HIP
+implicit-GEMM kernels of csrc/encoder.hip.  The torch forward below (MIOpen convolutions through PyTorch-ROCm) is
+what tests/test_gpu_encoders.py and the reference-generated goldens compare those kernels with."""
 import torch
 import torch.nn as nn
 

@@ -413,7 +413,8 @@ class Update(nn.Module):
 
 
 class Patchifier(nn.Module):
-    """Patch extraction (net.py:95-157).  Encoders run on MIOpen via PyTorch-ROCm (out of the hot path, 8f)."""
+    """Patch extraction (net.py:95-157).  In the tracker the encoders run through csrc/encoder.hip (dpvo_amd/encoders.py) and the
+    gathers through dpvo_frame_patches; this module's forward is the API-parity path (torch convolutions) used by the tests."""
 
     def __init__(self, patch_size=3):
         super().__init__()
