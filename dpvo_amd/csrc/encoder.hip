@@ -20,6 +20,18 @@
 namespace {
 
 constexpr int TH = 8, TW = 32;           // output tile (pixels)
+#ifndef ENC_TH2
+#define ENC_TH2 4
+#endif
+#ifndef ENC_WN2
+#define ENC_WN2 2
+#endif
+#ifndef ENC_WN1
+#define ENC_WN1 2
+#endif
+#ifndef ENC_PD
+#define ENC_PD 5
+#endif
 constexpr float kInEps = 1e-5f;          // nn.InstanceNorm2d default eps
 constexpr int kStatCopies = 16;          // accumulator copies per statistics set: spreads the same-address f64 atomics
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -62,26 +74,46 @@ __device__ __forceinline__ int swz4(int px) { return (0x78 >> (2 * ((px >> 2) & 
 // f64 atomic per channel per workgroup (hardware global_atomic_add_f64) into copy blockIdx.x % kStatCopies -- a few
 // hundred workgroups hitting the same 128 addresses serialise in L2 otherwise; summation order effects are ~1e-16
 // relative, far below the f32 statistics derived here.
-template <int CIN>
-__device__ __forceinline__ void reduce_stats(const double* acc, int /*unused*/, float inv_n, float* s_mean, float* s_rstd) {
-  for (int c = threadIdx.x; c < CIN; c += blockDim.x) {
-    double s1 = 0.0, s2 = 0.0;
+// (two halves: the loads are issued before the halo loads of the workgroup -- they come back first -- and the arithmetic runs
+//  while the halo loads are in flight.  Two lanes per channel, 8 copies each: 32 registers instead of 64 across the halo loads.)
+constexpr int kStatHalf = kStatCopies / 2;
+struct StatRaw { double v1[kStatHalf], v2[kStatHalf]; };
+// t: index inside the set's 2 * CIN threads (channel t >> 1, half t & 1)
+__device__ __forceinline__ void stats_load(const double* acc, int t, StatRaw& r) {
+  const int c = t >> 1, h = t & 1;
 #pragma unroll
-    for (int k = 0; k < kStatCopies; ++k) { s1 += acc[k * 128 + c]; s2 += acc[k * 128 + 64 + c]; }
+  for (int k = 0; k < kStatHalf; ++k) { r.v1[k] = acc[(h * kStatHalf + k) * 128 + c]; r.v2[k] = acc[(h * kStatHalf + k) * 128 + 64 + c]; }
+}
+__device__ __forceinline__ void stats_finish(const StatRaw& r, int t, float inv_n, float* s_mean, float* s_rstd) {
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < kStatHalf; ++k) { s1 += r.v1[k]; s2 += r.v2[k]; }
+  // copies 0..7 + copies 8..15 (lane pair 2c, 2c + 1)
+  const double o1 = __shfl_xor(s1, 1), o2 = __shfl_xor(s2, 1);
+  if ((t & 1) == 0) {
+    s1 += o1; s2 += o2;
     const double mean = s1 * (double)inv_n;
     const double var = s2 * (double)inv_n - mean * mean;
-    s_mean[c] = (float)mean;
-    s_rstd[c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)kInEps));
+    s_mean[t >> 1] = (float)mean;
+    s_rstd[t >> 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)kInEps));
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // conv KSxKS (KS = 3 pad 1, or KS = 1 pad 0), stride S, Cin in {32,64}, 64 output channels per workgroup (blockIdx.y)
 // ---------------------------------------------------------------------------------------------------
-template <int CIN, int KS, int S, int NT, bool DS = false>
+// THT: rows of the output tile, 8 (wave w owns rows 2w, 2w + 1) or 4 (wave w owns row w).  The quarter-resolution layers have only
+// 75 tiles of 8 x 32 per tower -- 150 workgroups on 256 CUs, each a ~15 us dependent chain; 4 x 32 tiles make it 300 shorter ones.
+template <int CIN, int KS, int S, int NT, bool DS = false, int THT = TH, int WN = 1>
 __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Win, int Hout, int Wout, int n_part_in) {
   constexpr int PAD = KS / 2;
-  constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+  // the four waves tile the workgroup's [THT rows] x [16 NT channels] output as WM x WN: wave (wm, wc) owns rows [wm RPW, +RPW) and
+  // N-tiles [wc NTW, +NTW).  WN = 2 halves the weight fragments every wave streams from L2 (each wave would otherwise load the whole
+  // filter bank: the k-loop of the quarter-resolution layers was bound by that stream) for twice the LDS reads per MFMA.
+  constexpr int WM = 4 / WN, NTW = NT / WN, RPW = THT / WM;
+  constexpr int MT = RPW * 2;                               // 16-pixel M-tiles per wave
+  static_assert(WN == 1 || WN == 2, "waves along N"); static_assert(THT % WM == 0 && NT % WN == 0, "tile split");
+  constexpr int IH = (THT - 1) * S + KS, IW = (TW - 1) * S + KS;
   constexpr int CPP = CIN / 8;                              // 16-byte chunks per pixel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16* halo = reinterpret_cast<_Float16*>(smem_raw);   // [IH][IW][CIN] swizzled
@@ -96,14 +128,43 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   if (n0 >= P.cout) return;
   const int tiles_x = (Wout + TW - 1) / TW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int oy0 = ty * THT, ox0 = tx * TW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wc = wave % WN;
+  const int n0w = n0 + wc * NTW * 16;                       // first output channel of this wave
 
   ENC_T(0);
-  if (P.in_mode == 2 || (P.in_mode == 3 && P.x_mode >= 2)) reduce_stats<CIN>(P.in_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean, s_rstd);
-  if (P.in_mode == 3 && P.y_mode >= 2) reduce_stats<CIN>(P.in2_part, n_part_in, 1.0f / (float)(Hin * Win), s_mean2, s_rstd2);
-  __syncthreads();
-  ENC_T(1);
+  // the epilogue's bias fragments are requested now: loaded where they are used they were an exposed round trip (~1.5 us of a 17 us
+  // workgroup) in front of the output stores
+  // (LEAN: the 32-channel stride-1 kernel runs 600 workgroups and must stay at three per CU, i.e. <= 112 VGPRs: it keeps the
+  //  statistics in front of the halo loads and fetches its bias in the epilogue; early requests cost it 9-40 registers and its
+  //  third workgroup: 16.6 -> 18.0 us)
+  constexpr bool HALF = (CIN == 32 && KS == 3 && S == 1);       // the half-resolution 3x3 layers: 600 workgroups, three per CU wanted
+  constexpr bool LEAN = HALF && WN == 1;
+  constexpr bool EARLY_STATS = !HALF;
+  h4 bias_pf[NTW];
+  auto bias_load = [&]() {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = n0w + j * 16 + (lane >> 4) * 4;
+      bias_pf[j] = (n < P.cout) ? *reinterpret_cast<const h4*>(P.bias + n) : (h4)(_Float16)0;
+    }
+  };
+  if constexpr (!LEAN) bias_load();
+  // the producers' statistics: threads [0, 2 CIN) request set 1, [2 CIN, 4 CIN) set 2 (whole waves either way), BEFORE the halo
+  // loads; the arithmetic follows once the halo loads have been issued
+  const bool st1 = P.in_mode == 2 || (P.in_mode == 3 && P.x_mode >= 2), st2 = P.in_mode == 3 && P.y_mode >= 2;
+  const bool need_stats = st1 || st2;
+  const bool my1 = st1 && tid < 2 * CIN, my2 = st2 && tid >= 2 * CIN && tid < 4 * CIN;
+  StatRaw sraw;
+  if (my1) stats_load(P.in_part, tid, sraw);
+  if (my2) stats_load(P.in2_part, tid - 2 * CIN, sraw);
+  auto stats = [&]() {
+    if (my1) stats_finish(sraw, tid, 1.0f / (float)(Hin * Win), s_mean, s_rstd);
+    if (my2) stats_finish(sraw, tid - 2 * CIN, 1.0f / (float)(Hin * Win), s_mean2, s_rstd2);
+    if (need_stats) __syncthreads();
+  };
+  if constexpr (!EARLY_STATS) { stats(); ENC_T(1); }
 
   // ---- stage the input halo (producer's norm + relu applied here; zero padding applies to the transformed tensor)
   const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
@@ -129,6 +190,9 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
         inimg |= 1u << k;
       }
     }
+    // the producer's statistics are reduced AFTER this thread's halo loads have been issued: two independent round trips side
+    // by side instead of one after the other
+    if constexpr (EARLY_STATS) { if (!dual) { stats(); ENC_T(1); } }
     if (dual) {
       // relu(fx(x) + relu(fy(y))): the arithmetic and its f16 rounding points are those of the reference's f16 tensors
       // (extractor.py:44-55).  Both operands of a batch of KB chunks are requested before anything is consumed; batches keep
@@ -151,6 +215,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
             pg[kk] = *reinterpret_cast<const h8*>(P.in2 + o);
           }
         }
+        if constexpr (EARLY_STATS) { if (k0 == 0) { stats(); ENC_T(1); } }
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
           const int k = k0 + kk;
@@ -174,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
               }
               // the tile's own pixels of the block output go back to memory for its other readers (the skip connection of
               // the next block, the second convolution of a stride-2 block): every pixel is the interior of exactly one tile
-              if (P.mat_out && blockIdx.y == 0 && ly >= PAD && ly < PAD + TH * S && lx >= PAD && lx < PAD + TW * S)
+              if (P.mat_out && blockIdx.y == 0 && ly >= PAD && ly < PAD + THT * S && lx >= PAD && lx < PAD + TW * S)
                 *reinterpret_cast<h8*>(P.mat_out + ((int64_t)(iy0 + ly) * Win + (ix0 + lx)) * CIN + ch * 8) = v;
             }
             const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
@@ -212,23 +277,25 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
 
   ENC_T(2);
   // ---- implicit GEMM: wave w owns output rows 2w, 2w+1 (4 M-tiles of 16 pixels), 4 N-tiles (64 channels)
-  f4 acc[4][NT];
+  f4 acc[MT][NTW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f4)0.f;
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f4)0.f;
+  // M-tile i of this wave: output row / 16-pixel half of the tile
+  auto row_of = [&](int i) { return wm * RPW + (i >> 1); };
   const int m = lane & 15, kg = lane >> 4;
   const int ncout = P.cout;
   static_assert(!DS || (KS == 3 && CIN == 32), "centre-tap second convolution: 3x3, one 32-channel k-step");
   constexpr int K = KS * KS * CIN;
   // flat k-steps t = (kh*KS + kw)*(CIN/32) + kc; the filter fragments of step t+2 are fetched (L2) while step t runs:
   // un-prefetched they were a dependent ~0.5 us round trip per step (9 us of a 23 us workgroup for 2 us of MFMA)
-  constexpr int KC = CIN / 32, T = KS * KS * KC, PD = 2;
-  h8 fwr[PD + 1][NT];
-  auto wload = [&](int t, h8 (&dst)[NT]) {
+  constexpr int KC = CIN / 32, T = KS * KS * KC, PD = HALF ? 2 : ENC_PD;       // (the non-LEAN kernels run one workgroup per CU: registers to spare)
+  h8 fwr[PD + 1][NTW];
+  auto wload = [&](int t, h8 (&dst)[NTW]) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + m;
+    for (int j = 0; j < NTW; ++j) {
+      const int n = n0w + j * 16 + m;
       dst[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w + ((int64_t)t * ncout + n) * 32 + kg * 8) : (h8)(_Float16)0;
     }
   };
@@ -236,38 +303,40 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   for (int t = 0; t < PD && t < T; ++t) wload(t, fwr[t]);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
+#ifndef ENC_PROBE_NOW
     if (t + PD < T) wload(t + PD, fwr[(t + PD) % (PD + 1)]);
+#endif
     const int kc = t % KC, kw = (t / KC) % KS, kh = t / (KC * KS);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ly = (2 * wave + (i >> 1)) * S + kh, lx = ((i & 1) * 16 + m) * S + kw;
+    for (int i = 0; i < MT; ++i) {
+      const int ly = row_of(i) * S + kh, lx = ((i & 1) * 16 + m) * S + kw;
       const int ch = kc * 4 + kg;
       const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
+#ifdef ENC_PROBE_NOLDS
+      h8 fa = fwr[t % (PD + 1)][i % NTW];
+#else
       const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
+#endif
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % (PD + 1)][j], fa, acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % (PD + 1)][j], fa, acc[i][j], 0, 0, 0);
     }
   }
 
   ENC_T(3);
   // ---- epilogue: bias, f16 rounding, NHWC store, per-channel partial statistics of the ROUNDED values
-  auto epilogue = [&](auto& A, const _Float16* bias, _Float16* out, double* out_part) {
-  float ssum[NT][4], ssq[NT][4];
-  h4 bias4[NT];
+  auto epilogue = [&](auto& A, const h4 (&bias4)[NTW], _Float16* out, double* out_part) {
+  float ssum[NTW][4], ssq[NTW][4];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 16 + kg * 4;
-    bias4[j] = (n < ncout) ? *reinterpret_cast<const h4*>(bias + n) : (h4)(_Float16)0;
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
-  }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int oy = oy0 + 2 * wave + (i >> 1), ox = ox0 + (i & 1) * 16 + m;
+  for (int i = 0; i < MT; ++i) {
+    const int oy = oy0 + row_of(i), ox = ox0 + (i & 1) * 16 + m;
     const bool inb = oy < Hout && ox < Wout;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + kg * 4;
+    for (int j = 0; j < NTW; ++j) {
+      const int n = n0w + j * 16 + kg * 4;
       if (n >= ncout) continue;
       const h4 bv = bias4[j];
       h4 hv;
@@ -284,45 +353,49 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   if (out_part) {
     // reduce over the 16 pixel lanes (xor 1,2,4,8 keeps kg), then over the 4 waves through LDS, fixed order
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float a = ssum[j][r], b = ssq[j][r];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        if (m == 0) { s_red[(wave * 2 + 0) * 64 + j * 16 + kg * 4 + r] = a; s_red[(wave * 2 + 1) * 64 + j * 16 + kg * 4 + r] = b; }
+        const int cr = (wc * NTW + j) * 16 + kg * 4 + r;              // channel relative to n0
+        if (m == 0) { s_red[(wm * 2 + 0) * 64 + cr] = a; s_red[(wm * 2 + 1) * 64 + cr] = b; }
       }
     __syncthreads();
     if (tid < 128) {
       const int which = tid >> 6, c = tid & 63;
       if (c < 16 * NT && n0 + c < ncout) {
-        const float v = ((s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c]) +
-                         (s_red[(2 * 2 + which) * 64 + c] + s_red[(3 * 2 + which) * 64 + c]));
+        float v = s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c];
+        if constexpr (WM == 4) v = v + (s_red[(2 * 2 + which) * 64 + c] + s_red[(3 * 2 + which) * 64 + c]);
         unsafeAtomicAdd(&out_part[(blockIdx.x % kStatCopies) * 128 + which * 64 + n0 + c], (double)v);
       }
     }
     __syncthreads();                        // (s_red is reused by a second epilogue)
   }
   };
-  epilogue(acc, P.bias, P.out, P.out_part);
+  if constexpr (LEAN) bias_load();
+  epilogue(acc, bias_pf, P.out, P.out_part);
   if constexpr (DS) {
     // the second, 1x1 convolution (layer2.0.downsample) = one k-step on the centre tap of the halo that is still in LDS; the
     // accumulators are reused (carrying both sets through the main loop cost the kernel its second workgroup per CU)
-    h8 fw2[NT];
+    h8 fw2[NTW];
+    h4 bias2_pf[NTW];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + m;
+    for (int j = 0; j < NTW; ++j) {
+      const int n = n0w + j * 16 + m, nb = n0w + j * 16 + kg * 4;
       fw2[j] = (n < ncout) ? *reinterpret_cast<const h8*>(P.w2 + (int64_t)n * 32 + kg * 8) : (h8)(_Float16)0;
+      bias2_pf[j] = (nb < ncout) ? *reinterpret_cast<const h4*>(P.bias2 + nb) : (h4)(_Float16)0;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ly = (2 * wave + (i >> 1)) * S + KS / 2, lx = ((i & 1) * 16 + m) * S + KS / 2;
+    for (int i = 0; i < MT; ++i) {
+      const int ly = row_of(i) * S + KS / 2, lx = ((i & 1) * 16 + m) * S + KS / 2;
       const int sch = kg ^ swz4(lx);
       const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw2[j], fa, (f4)0.f, 0, 0, 0);
+      for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw2[j], fa, (f4)0.f, 0, 0, 0);
     }
-    epilogue(acc, P.bias2, P.out2, P.out2_part);
+    epilogue(acc, bias2_pf, P.out2, P.out2_part);
   }
   ENC_T(5);
 }
@@ -431,13 +504,13 @@ __global__ __launch_bounds__(256) void conv1_kernel(const _Float16* __restrict__
   }
 }
 
-template <int CIN, int KS, int S, int NT, bool DS = false>
+template <int CIN, int KS, int S, int NT, bool DS = false, int THT = TH, int WN = 1>
 int launch_conv(const EncArgs& a, int Hin, int Win, int Hout, int Wout, int n_part_in, int cout_max, hipStream_t st) {
-  constexpr int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+  constexpr int IH = (THT - 1) * S + KS, IW = (TW - 1) * S + KS;
   const size_t sh = (size_t)IH * IW * CIN * 2 + (4 * CIN + 4 * 2 * 64) * 4;
-  (void)hipFuncSetAttribute((const void*)conv_kernel<CIN, KS, S, NT, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  const int tiles = ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW);
-  hipLaunchKernelGGL((conv_kernel<CIN, KS, S, NT, DS>), dim3(tiles, (cout_max + 16 * NT - 1) / (16 * NT), 2), dim3(256), sh, st, a, Hin, Win,
+  (void)hipFuncSetAttribute((const void*)conv_kernel<CIN, KS, S, NT, DS, THT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  const int tiles = ((Hout + THT - 1) / THT) * ((Wout + TW - 1) / TW);
+  hipLaunchKernelGGL((conv_kernel<CIN, KS, S, NT, DS, THT, WN>), dim3(tiles, (cout_max + 16 * NT - 1) / (16 * NT), 2), dim3(256), sh, st, a, Hin, Win,
                      Hout, Wout, n_part_in);
   return (int)hipGetLastError();
 }
@@ -526,19 +599,19 @@ extern "C" int dpvo_encoders_forward_hold(const void* image_f16, const void* con
   // ---- layer1.0 (ResidualBlock 32->32, :44-55): c1: x0 -> A1 (P1), c2 -> A2 (P2)
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][0], STATS(z, 0), Wp(z, 2), Wp(z, 3), A[z][1], STATS(z, 1), cin_mode[z], 32, 1.0f);
   HOLD();
-  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  if ((rc = launch_conv<32, 3, 1, 2, false, TH, ENC_WN1>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][1], STATS(z, 1), Wp(z, 4), Wp(z, 5), A[z][2], STATS(z, 2), cin_mode[z], 32, 1.0f);
   HOLD();
-  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  if ((rc = launch_conv<32, 3, 1, 2, false, TH, ENC_WN1>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   // ---- layer1.1: input X1 = relu(x0 + relu(f(A2))) formed here and written to A1; c1 -> A3 (P3), c2 -> A0 (P4)
   for (int z = 0; z < 2; ++z)
     a.e[z] = res(enc_ptrs(A[z][0], STATS(z, 0), Wp(z, 6), Wp(z, 7), A[z][3], STATS(z, 3), 3, 32, 1.0f), A[z][2], STATS(z, 2),
                  nm[z] ? 3 : 1, nm[z] ? 3 : 1, A[z][1]);
   HOLD();
-  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  if ((rc = launch_conv<32, 3, 1, 2, false, TH, ENC_WN1>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(A[z][3], STATS(z, 3), Wp(z, 8), Wp(z, 9), A[z][0], STATS(z, 4), cin_mode[z], 32, 1.0f);
   HOLD();
-  if ((rc = launch_conv<32, 3, 1, 2>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
+  if ((rc = launch_conv<32, 3, 1, 2, false, TH, ENC_WN1>(a, h2, w2, h2, w2, t2, 32, st))) return rc;
   // ---- layer2.0 (32->64, stride 2): input X2 = relu(X1 + relu(f(A0))) formed here and written to A2;
   //      c1 -> B0 (P5) and, on the centre tap, downsample (1x1 stride 2) -> B2 (P7) in the same launch; c2 -> B1 (P6)
   for (int z = 0; z < 2; ++z) {
@@ -547,19 +620,19 @@ extern "C" int dpvo_encoders_forward_hold(const void* image_f16, const void* con
     a.e[z].w2 = Wp(z, 14); a.e[z].bias2 = Wp(z, 15); a.e[z].out2 = B[z][2]; a.e[z].out2_part = STATS(z, 7);
   }
   HOLD();
-  if ((rc = launch_conv<32, 3, 2, 4, true>(a, h2, w2, h4, w4, t2, 64, st))) return rc;
+  if ((rc = launch_conv<32, 3, 2, 4, true, ENC_TH2, ENC_WN2>(a, h2, w2, h4, w4, t2, 64, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(B[z][0], STATS(z, 5), Wp(z, 12), Wp(z, 13), B[z][1], STATS(z, 6), cin_mode[z], 64, 1.0f);
   HOLD();
-  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
+  if ((rc = launch_conv<64, 3, 1, 4, false, ENC_TH2, ENC_WN2>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
   // ---- layer2.1: input X3 = relu(norm(B2) + relu(f(B1))) formed here and written to B3; c1 -> B0 (P8), c2 -> B1 (P9)
   for (int z = 0; z < 2; ++z)
     a.e[z] = res(enc_ptrs(B[z][2], STATS(z, 7), Wp(z, 16), Wp(z, 17), B[z][0], STATS(z, 8), 3, 64, 1.0f), B[z][1], STATS(z, 6),
                  nm[z] ? 2 : 0, nm[z] ? 3 : 1, B[z][3]);
   HOLD();
-  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
+  if ((rc = launch_conv<64, 3, 1, 4, false, ENC_TH2, ENC_WN2>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
   for (int z = 0; z < 2; ++z) a.e[z] = enc_ptrs(B[z][0], STATS(z, 8), Wp(z, 18), Wp(z, 19), B[z][1], STATS(z, 9), cin_mode[z], 64, 1.0f);
   HOLD();
-  if ((rc = launch_conv<64, 3, 1, 4>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
+  if ((rc = launch_conv<64, 3, 1, 4, false, ENC_TH2, ENC_WN2>(a, h4, w4, h4, w4, t4, 64, st))) return rc;
   // ---- conv2 (1x1, 64 -> 128 | 384) on X4 = relu(X3 + relu(f(B1))), output / 4.0                        :259, net.py:116-117
   a.e[0] = res(enc_ptrs(B[0][3], nullptr, Wp(0, 20), Wp(0, 21), (_Float16*)fmap_out, nullptr, 3, 128, 0.25f), B[0][1], STATS(0, 9), 0,
                nm[0] ? 3 : 1, nullptr);
