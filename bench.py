@@ -332,6 +332,16 @@ def main():
         out["state"] = {"finite": bool(torch.isfinite(slam.pg.poses_[:slam.n]).all().item()), "edges_in_bounds": round(inb, 4)}
         if not out["state"]["finite"] or inb < 0.5:
             out["error"] = "tracker state diverged during the run: the timing above is not a valid measurement"
+        if os.environ.get("DPVO_BENCH_THREADS"):           # CPU seconds per thread of this process (who burns the host time?)
+            th = {}
+            for t_ in os.listdir("/proc/self/task"):
+                try:
+                    f_ = open(f"/proc/self/task/{t_}/stat").read().rsplit(")", 1)[1].split()
+                    nm_ = open(f"/proc/self/task/{t_}/comm").read().strip()
+                    th[f"{t_}:{nm_}"] = round((int(f_[11]) + int(f_[12])) / os.sysconf("SC_CLK_TCK"), 2)
+                except OSError:
+                    pass
+            out["threads_cpu_s"] = th
         if os.environ.get("DPVO_BENCH_DIAG"):              # state fingerprint + buffer addresses (run-to-run comparisons)
             out["diag"] = {"pose_sum": float(slam.pg.poses_[:slam.n].double().abs().sum().item()),
                            "depth_sum": float(slam.pg.patches_[:slam.n, :, 2].double().abs().sum().item()),

@@ -63,7 +63,14 @@ __host__ __device__ inline EncPtrs enc_ptrs(const _Float16* in, const double* in
 struct EncArgs { EncPtrs e[2]; };
 #ifdef ENC_TRACE
 __device__ unsigned long long g_enc_trace[2048][8];
-#define ENC_T(i) do { if (CIN == 64 && KS == 3 && threadIdx.x == 0 && blockIdx.z == 0) g_enc_trace[blockIdx.x][i] = wall_clock64(); } while (0)
+#ifndef ENC_TRACE_CIN
+#define ENC_TRACE_CIN 64
+#define ENC_TRACE_KS 3
+#endif
+#ifndef ENC_TRACE_Z
+#define ENC_TRACE_Z 0
+#endif
+#define ENC_T(i) do { if (CIN == ENC_TRACE_CIN && KS == ENC_TRACE_KS && threadIdx.x == 0 && blockIdx.z == ENC_TRACE_Z && blockIdx.y == 0) g_enc_trace[blockIdx.x][i] = wall_clock64(); } while (0)
 #else
 #define ENC_T(i) do {} while (0)
 #endif
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       // relu(fx(x) + relu(fy(y))): the arithmetic and its f16 rounding points are those of the reference's f16 tensors
       // (extractor.py:44-55).  Both operands of a batch of KB chunks are requested before anything is consumed; batches keep
       // the staging registers at 2 x KB x 4 (the 17 x 65 halo of the stride-2 kernel is 18 chunks per thread)
-      constexpr int KB = 6;
+      constexpr int KB = (NPT <= 8) ? NPT : 6;          // (the 1x1 layer's 8 chunks per thread go in one batch: one round trip)
 #pragma unroll
       for (int k0 = 0; k0 < NPT; k0 += KB) {
         h8 px[KB], pg[KB];
@@ -291,7 +298,8 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   // flat k-steps t = (kh*KS + kw)*(CIN/32) + kc; the filter fragments of step t+2 are fetched (L2) while step t runs:
   // un-prefetched they were a dependent ~0.5 us round trip per step (9 us of a 23 us workgroup for 2 us of MFMA)
   constexpr int KC = CIN / 32, T = KS * KS * KC, PD = HALF ? 2 : ENC_PD;       // (the non-LEAN kernels run one workgroup per CU: registers to spare)
-  h8 fwr[PD + 1][NTW];
+  constexpr int RING = (PD + 1 < T) ? PD + 1 : T;
+  h8 fwr[RING][NTW];
   auto wload = [&](int t, h8 (&dst)[NTW]) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
 #pragma unroll
   for (int t = 0; t < T; ++t) {
 #ifndef ENC_PROBE_NOW
-    if (t + PD < T) wload(t + PD, fwr[(t + PD) % (PD + 1)]);
+    if (t + PD < T) wload(t + PD, fwr[(t + PD) % RING]);
 #endif
     const int kc = t % KC, kw = (t / KC) % KS, kh = t / (KC * KS);
 #pragma unroll
@@ -313,12 +321,12 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
       const int ch = kc * 4 + kg;
       const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
 #ifdef ENC_PROBE_NOLDS
-      h8 fa = fwr[t % (PD + 1)][i % NTW];
+      h8 fa = fwr[t % RING][i % NTW];
 #else
       const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
 #endif
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % (PD + 1)][j], fa, acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % RING][j], fa, acc[i][j], 0, 0, 0);
     }
   }
 
@@ -547,6 +555,10 @@ extern "C" int dpvo_encoders_forward(const void* image_f16, const void* const* w
 // The same, with the stream made to wait for `hold_event` (hipEvent_t, may be NULL) in front of launch number `hold_at`
 // (0 = the first convolution ... 9 = the last): a tracker that runs the next frame's encoders on a side stream lets the first
 // launches run beside the chip-filling kernels of the current frame and holds the rest back until those are through.
+// (Measured alternatives to the event, round 3: hipStreamWaitValue32 on signal memory slows the OTHER queue's kernels by 15 %
+//  while it polls; a one-lane kernel parked on a flag keeps one CU from hosting the update operator's 512-register workgroups --
+//  K7's 256 persistent workgroups then need a second round.  The event's own cost: while the wait is pending, a thread of the HIP
+//  runtime burns CPU, 0.7 ms per frame if the encoders are enqueued a whole update operator ahead.)
 extern "C" int dpvo_encoders_forward_hold(const void* image_f16, const void* const* weights, void* fmap_out, void* imap_out,
                                           int H, int W, void* ws, size_t ws_bytes, void* hold_event, int hold_at, void* stream) {
   if (!image_f16 || !weights || !fmap_out || !imap_out || !ws) return DPVO_E_INVALID;
@@ -639,7 +651,7 @@ extern "C" int dpvo_encoders_forward_hold(const void* image_f16, const void* con
   a.e[1] = res(enc_ptrs(B[1][3], nullptr, Wp(1, 20), Wp(1, 21), (_Float16*)imap_out, nullptr, 3, 384, 0.25f), B[1][1], STATS(1, 9), 0,
                nm[1] ? 3 : 1, nullptr);
   HOLD();
-  if ((rc = launch_conv<64, 1, 1, 4>(a, h4, w4, h4, w4, t4, 384, st))) return rc;
+  if ((rc = launch_conv<64, 1, 1, 4, false, TH, ENC_WN1>(a, h4, w4, h4, w4, t4, 384, st))) return rc;
 #undef STATS
 #undef HOLD
   DPVO_LAUNCH_CHECK();

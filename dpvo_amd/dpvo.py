@@ -44,8 +44,14 @@ _FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
 # the result read-back waits on an event created with hipEventBlockingSync: the waiting thread sleeps instead of spinning
 # DPVO_ENC_AFTER_UPDATE=1: the side stream holds the next frame's encoders back until the current frame's update operator is
 # through, so that they run beside the small BA / keyframe kernels instead of beside the correlation / update kernels
-_ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '0')))
+# The hold is a hipStreamWaitEvent, and while such a wait is pending a thread of the HIP runtime burns CPU (0.7 ms per frame when
+# the encoders are enqueued right behind the frame call).  The host therefore enqueues the side stream's work LATE: it sleeps until
+# DPVO_ENC_LEAD_US before the expected end of the update operator (= the running mean of the frame's duration minus DPVO_ENC_TAIL_US,
+# the BA / keyframe tail), so that the wait is pending for ~0.1 ms only.
+_ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '1')))
 _ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '0'))
+_ENC_TAIL_US = float(__import__('os').environ.get('DPVO_ENC_TAIL_US', '200'))
+_ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '120'))
 _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
 
@@ -804,6 +810,12 @@ class DPVO:
             hold_ev = None
             if _ENC_AFTER_UPDATE and getattr(self, "_upd_done", None) is not None and self._fu_pending is not None:
                 hold_ev = self._upd_done
+                ema_ = self._fu["wait_ema"]
+                if ema_ > 0 and _ENC_LEAD_US >= 0:
+                    import time
+                    rest_ = self._fu_pending[5] + ema_ - 1e-6 * (_ENC_TAIL_US + _ENC_LEAD_US) - time.perf_counter()
+                    if rest_ > 6e-5:
+                        time.sleep(rest_ - 5e-5)
             # the caller's stream may still be producing / uploading the image (torch.from_numpy(img).cuda() from pageable
             # memory returns before the copy has landed): order the side stream behind it
             if image_ready is None:
