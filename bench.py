@@ -195,6 +195,8 @@ def main():
     from dpvo_amd.net import VONet
     from dpvo_amd import net as net_mod
 
+    if os.environ.get("DPVO_BENCH_MAIN_PRIO"):       # experiment: the tracker's main stream with a HIP stream priority
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ["DPVO_BENCH_MAIN_PRIO"])))
     cfg = base_cfg.clone()
     cfg.merge_from_dict(DEFAULT_YAML if args.config == "default" else FAST_YAML)
     cfg.KEYFRAME_THRESH = -1.0                       # keep every keyframe (see module docstring)

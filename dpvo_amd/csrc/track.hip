@@ -60,6 +60,17 @@ __device__ __forceinline__ int kf_class(const dpvo_keyframe_step_t& a, int d, in
   if (a.loop_closure && rem) rem = !(((j - i) > 30) && (j > (n_after - a.optimization_window)));      // dpvo.py:307-308
   return rem ? 2 : 1;
 }
+// the host's copy of the result, written straight into its pinned buffer by one thread (a 32- or 64-byte hipMemcpyAsync is another
+// ~5 us launch in the frame's tail); `host_words` = 16: the 8 words in front of `result` (flow sums + plan counters) go along.
+// Issued by one thread of the gather kernel: inside the select kernel the 16 PCIe writes and their system-scope fence sat on the
+// frame's critical path (select 17 us, of which ~10 were this), here they travel while the gather runs; the host waits for the
+// stream's event, i.e. for the end of that kernel, anyway.
+__device__ __forceinline__ void kf_host_copy(const dpvo_keyframe_step_t& a) {
+  volatile int32_t* h = (volatile int32_t*)a.result_host;
+  const int32_t* src = a.result - (a.host_words == 16 ? 8 : 0);
+  for (int i = 0; i < a.host_words; ++i) h[i] = src[i];
+  __threadfence_system();
+}
 constexpr int KF_CHUNK = 1024;
 __global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts) {
   __shared__ int wsum[2][16];
@@ -111,20 +122,15 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe
     if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
     a.result[RES_DECISION] = d; a.result[RES_KEEP] = total[0]; a.result[RES_REM] = nrem; a.result[RES_E] = (int32_t)a.E;
     a.result[RES_OVERFLOW] = ovf; a.result[5] = a.result[6] = a.result[7] = 0;
-    if (a.result_host) {
-      // the host's copy, written straight into its pinned buffer (a 32- or 64-byte hipMemcpyAsync is another ~5 us launch in
-      // the frame's tail); `host_words` = 16: the 8 words in front of `result` (flow sums + plan counters) go along
-      volatile int32_t* h = (volatile int32_t*)a.result_host;
-      const int32_t* src = a.result - (a.host_words == 16 ? 8 : 0);
-      for (int i = 0; i < a.host_words; ++i) h[i] = src[i];
-      __threadfence_system();
-    }
+    // (the host's copy is written by the gather kernel that follows -- kf_host_copy -- unless there is none to launch)
+    if (a.result_host && a.E == 0 && a.n_ring == 0) kf_host_copy(a);
   }
 }
 
 // ---- 2. the two gathers (kept -> spare set, incl. the 1.5 KB hidden-state rows; inactive -> tail of the inactive store)
 __device__ __forceinline__ void kf_shift_body(const dpvo_keyframe_step_t& a, int blk, int blocks_per_ring);
 __global__ __launch_bounds__(256) void kf_gather_kernel(const dpvo_keyframe_step_t a, int nblk_keep, int nblk_gather, int blocks_per_ring) {
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255 && a.result_host) kf_host_copy(a);
   if ((int)blockIdx.x >= nblk_gather) { kf_shift_body(a, (int)blockIdx.x - nblk_gather, blocks_per_ring); return; }
   const Renum R = {a.result[RES_DECISION], a.n - a.keyframe_index, a.M};
   const bool keep_job = (int)blockIdx.x < nblk_keep;

@@ -49,7 +49,8 @@ _FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
 # DPVO_ENC_LEAD_US before the expected end of the update operator (= the running mean of the frame's duration minus DPVO_ENC_TAIL_US,
 # the BA / keyframe tail), so that the wait is pending for ~0.1 ms only.
 _ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '1')))
-_ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '0'))
+_ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '-1'))     # -1: the whole side-stream batch (random draws, image
+#   normalisation, encoders) waits; k >= 0: only the encoder launches from number k on
 _ENC_TAIL_US = float(__import__('os').environ.get('DPVO_ENC_TAIL_US', '200'))
 _ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '120'))
 _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
@@ -816,6 +817,9 @@ class DPVO:
                     rest_ = self._fu_pending[5] + ema_ - 1e-6 * (_ENC_TAIL_US + _ENC_LEAD_US) - time.perf_counter()
                     if rest_ > 6e-5:
                         time.sleep(rest_ - 5e-5)
+                if _ENC_HOLD_AT < 0:
+                    side.wait_event(hold_ev)
+                    hold_ev = None
             # the caller's stream may still be producing / uploading the image (torch.from_numpy(img).cuda() from pageable
             # memory returns before the copy has landed): order the side stream behind it
             if image_ready is None:
