@@ -85,6 +85,8 @@ class DPVO:
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:     # "cuda" -> "cuda:<current>": tensors carry an index, and
+            self.device = torch.device("cuda", torch.cuda.current_device())   # `t.device != torch.device("cuda")` is always True
         self.load_weights(network)
         self.is_initialized = False
         self.enable_timing = False

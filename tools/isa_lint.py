@@ -10,7 +10,8 @@ The compiler picks that form freely when it packs scalar FP32 code, so every shi
 a unit that trips this is compiled without packed-FP32 ops (csrc/Makefile, NOPK).  Exit status 1 on a hit.
 """
 import os, re, subprocess, sys, tempfile
-LLVM = "/opt/rocm/lib/llvm/bin"
+# LLVM tools: $DPVO_LLVM_BIN, else $ROCM_PATH/lib/llvm/bin, else /opt/rocm/lib/llvm/bin
+LLVM = os.environ.get("DPVO_LLVM_BIN") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 BAD = re.compile(r"\bv_pk_(mul|add|fma)_f32\b.*\bop_sel:\[0,1")
 
@@ -46,6 +47,12 @@ def lint(path):
 
 if __name__ == "__main__":
     rc = 0
+    missing = [t for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump") if not os.path.isfile(os.path.join(LLVM, t))]
+    if missing:
+        # exit status 2 = "could not check" (distinct from 1 = "the faulting form is present"); the Makefile treats both as fatal:
+        # an unchecked library must not ship
+        print(f"isa_lint: {', '.join(missing)} not found under {LLVM} (set DPVO_LLVM_BIN or ROCM_PATH)", file=sys.stderr)
+        sys.exit(2)
     for p in sys.argv[1:]:
         n_pk, hits = lint(p)
         print(f"{p}: {n_pk} packed instructions, {len(hits)} of the faulting form")
