@@ -350,7 +350,7 @@ def main():
                            "net_sum": float(slam.pg.net.double().abs().sum().item()), "in_bounds": round(inb, 4),
                            "ptr": {k: hex(getattr(slam, k).data_ptr()) for k in ("_fmap1_cl", "_fmap2_cl", "_gmap_cl", "imap_")},
                            "corr_ms_minmax": [round(min(corr_ms), 4), round(max(corr_ms), 4)]}
-        if world == 1:
+        if world == 1 and not os.environ.get("DPVO_BENCH_NO_BOX"):     # (skipped under rocprofv3: the probe is a child process)
             out["box"] = box_clock()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

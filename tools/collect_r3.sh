@@ -3,7 +3,7 @@
 tag=${1:-r3}; root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 300 $out/bench.json; echo
 python bench.py --no-cpu-baseline --config fast > $out/bench_fast.json 2>> $out/bench.err
-( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && DPVO_BENCH_NO_DROP_LEG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> /tmp/ks.err )
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && DPVO_BENCH_NO_BOX=1 DPVO_BENCH_NO_DROP_LEG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> /tmp/ks.err )
 f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv; python tools/kstats.py $f 45 > $out/kernel_stats_short.txt
 t=$(find /tmp/ks -name "*kernel_trace.csv" | head -1); python tools/frame_timeline.py $t 3 > $out/frame_timeline.txt
 python tools/kernel_tail_avg.py $t corr_pyramid 20 > $out/corr_steady_state.txt
@@ -18,4 +18,8 @@ python tools/corr_bench.py 2>&1 | grep -v amdgpu > $out/corr_bench.txt
 python tools/ba_bench.py 2>&1 | grep -v amdgpu > $out/ba_bench.txt
 python tools/host_time.py tottime 2>&1 | grep -v amdgpu | head -30 > $out/host_profile.txt
 python -m pytest tests/test_gpu_ref.py -q -s -m gpu 2>&1 | grep -v amdgpu > $out/ref_parity.txt
+python tools/enc_bench.py 2>&1 | grep -v amdgpu > $out/enc_bench.txt
+python tools/gba_bench.py 2>&1 | grep -v amdgpu > $out/gba.txt
+[ -x tools/probes/clock_probe.bin ] && tools/probes/clock_probe.bin > $out/clock_probe.txt 2>&1
+python -m pytest tests -q -m gpu 2>&1 | tail -3 > $out/pytest_gpu.txt
 ls -la $out
