@@ -36,3 +36,13 @@ def test_library_is_free_of_the_faulting_form(name):
     n_pk, hits = isa_lint.lint(lib)
     assert n_pk > 1000          # packed ops are in use (update operators), so the check is not vacuous
     assert hits == []
+
+
+def test_missing_tools_are_reported_as_such():
+    """exit status 2 ("could not check") is distinct from 1 ("the faulting form is present"): tools/isa_lint.py, csrc/Makefile"""
+    import subprocess
+    import sys
+    env = dict(os.environ, DPVO_LLVM_BIN="/nonexistent/llvm/bin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), os.path.join(ROOT, "dpvo_amd", "libdpvo_hip.so")],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "not found" in r.stderr
