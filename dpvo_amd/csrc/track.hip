@@ -280,7 +280,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   STEP(dpvo_corr_pyramid_forward(a->gmap, a->fmap1, a->fmap2, a->coords, K.kk, K.jj, nullptr, a->corr, 896, E, 128, a->P,
                                  (int64_t)a->pmem * M, a->mem, a->H0, a->W0, a->H1, a->W1, 3, stream));
   if (a->ev[1] && hipEventRecord((hipEvent_t)a->ev[1], st) != hipSuccess) return DPVO_E_INVALID;
-  if (a->ev[2] && hipEventRecord((hipEvent_t)a->ev[2], st) != hipSuccess) return DPVO_E_INVALID;
+  if (a->ev[2] && a->ev[2] != a->ev[1] && hipEventRecord((hipEvent_t)a->ev[2], st) != hipSuccess) return DPVO_E_INVALID;   // (one record serves both)
   float* net = a->net;
   float* target = const_cast<float*>(K.target);
   float* weight = const_cast<float*>(K.weight);

@@ -54,6 +54,7 @@ _ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '-1'))     #
 _ENC_TAIL_US = float(__import__('os').environ.get('DPVO_ENC_TAIL_US', '200'))
 _ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '120'))
 _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
+_PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
 
 
@@ -579,9 +580,13 @@ class DPVO:
             a.net_rows, a.n_kept = es.net_pending[0].data_ptr(), es.net_pending[1]
         else:
             a.net_rows, a.n_kept = None, 0
+        # bench.py: HIP events around the correlation kernel / the update operator.  Every hipEventRecord is a marker the stream stalls
+        # on for ~5 us, so they are taken on every DPVO_PROFILE_EVERY-th frame only, and the end of the correlation doubles as the
+        # start of the update operator (3 records instead of 4)
+        sample = _PROFILE_EVERY <= 1 or (self.counter % _PROFILE_EVERY) == 0
         for i, lst in enumerate((corr_mod.PROFILE, net_mod.PROFILE)):
-            if lst is not None:         # bench.py: HIP events around the correlation kernel / the update operator, from a pool whose
-                pool = fu["evpool"]     # handles exist already (the call re-records them in place)
+            if lst is not None and sample:
+                pool = fu["evpool"]     # a pool whose handles exist already (the call re-records them in place)
                 if pool is None:
                     pool = fu["evpool"] = [torch.cuda.Event(enable_timing=True) for _ in range(512)]
                 if not pool[0].cuda_event:
@@ -590,13 +595,19 @@ class DPVO:
                 pos = fu["evpos"]
                 fu["evpos"] = (pos + 2) % len(pool)
                 e0, e1 = pool[pos], pool[pos + 1]
+                if i == 1 and corr_mod.PROFILE is not None:
+                    e0 = fu["ev_corr_end"]                      # (recorded once, read by both)
                 a.ev[2 * i], a.ev[2 * i + 1] = e0.cuda_event, e1.cuda_event
+                if i == 0:
+                    fu["ev_corr_end"] = e1
                 lst.append((e0, e1, E))
-            elif a.ev[2 * i]:
+            elif a.ev[2 * i] or a.ev[2 * i + 1]:
                 a.ev[2 * i] = a.ev[2 * i + 1] = None
         a.m = self.m
         if fs is not None:
-            a.fs, a.ev_fs, a.fs_auto = ctypes.addressof(fs), (self._fp_done.cuda_event if self._fp_done is not None else None), 1
+            # ev_fs ("the frame state has read the encoder outputs"): what the NEXT frame's side-stream batch waits for before it
+            # overwrites them -- unless that batch is held behind this call's update operator anyway (one marker less in the stream)
+            a.fs, a.ev_fs, a.fs_auto = ctypes.addressof(fs), (self._fp_done.cuda_event if (self._fp_done is not None and not _ENC_AFTER_UPDATE) else None), 1
         else:
             a.fs = a.ev_fs = None
         if _ENC_AFTER_UPDATE:
