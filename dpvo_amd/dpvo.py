@@ -600,6 +600,8 @@ class DPVO:
                 a.ev[2 * i], a.ev[2 * i + 1] = e0.cuda_event, e1.cuda_event
                 if i == 0:
                     fu["ev_corr_end"] = e1
+                else:
+                    fu["ev_upd_end"] = e1
                 lst.append((e0, e1, E))
             elif a.ev[2 * i] or a.ev[2 * i + 1]:
                 a.ev[2 * i] = a.ev[2 * i + 1] = None
@@ -614,7 +616,10 @@ class DPVO:
             if getattr(self, "_upd_done", None) is None:
                 self._upd_done = torch.cuda.Event()
                 self._upd_done.record()
-            a.ev_update_done = self._upd_done.cuda_event
+            if a.ev[3]:                 # the profiling event behind the update operator is the same point in the stream: one record
+                a.ev_update_done, self._hold_event = None, fu["ev_upd_end"]
+            else:
+                a.ev_update_done, self._hold_event = self._upd_done.cuda_event, self._upd_done
         self._stamp(3)
         L.check(L.lib().dpvo_frame_update(ctypes.byref(a), L.stream()), "dpvo_frame_update")
         self._stamp(4)
@@ -822,8 +827,8 @@ class DPVO:
             if self._fp_done is not None:       # the previous frame's readers of _imap_full / the encoder workspace
                 side.wait_event(self._fp_done)
             hold_ev = None
-            if _ENC_AFTER_UPDATE and getattr(self, "_upd_done", None) is not None and self._fu_pending is not None:
-                hold_ev = self._upd_done
+            if _ENC_AFTER_UPDATE and getattr(self, "_hold_event", None) is not None and self._fu_pending is not None:
+                hold_ev = self._hold_event
                 ema_ = self._fu["wait_ema"]
                 if ema_ > 0 and _ENC_LEAD_US >= 0:
                     import time
