@@ -19,7 +19,7 @@ F16, F32 = 0, 1
 SYMBOLS = [
     "dpvo_abi_version",
     "dpvo_corr_forward", "dpvo_corr_pyramid_forward", "dpvo_patchify_forward", "dpvo_patchify_bilinear",
-    "dpvo_reproject", "dpvo_flow_mag", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud",
+    "dpvo_reproject", "dpvo_flow_mag", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud", "dpvo_point_cloud_motionmag",
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",

@@ -235,14 +235,19 @@ __global__ __launch_bounds__(1024) void motionmag_kernel(const float* __restrict
 
 // plan variant: the two frame pairs are looked up in the plan's pair list and only their
 // ~2 x 96 edges are touched (the scan above reads all E index triples: 60 us at E = 47 712 vs ~6 us here)
-__global__ __launch_bounds__(256) void motionmag_plan_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
-                                                             const float* __restrict__ intr, const int64_t* __restrict__ kk,
-                                                             const int32_t* __restrict__ perm_p,
-                                                             const int32_t* __restrict__ pair_off,
-                                                             const int32_t* __restrict__ pair_ij,
-                                                             const int32_t* __restrict__ n_pairs, int P, int qi, int qj,
-                                                             float beta, float* __restrict__ out,
-                                                             float* __restrict__ status) {
+struct MotionPlanArgs {
+  const float *poses, *patches, *intr; const int64_t* kk;
+  const int32_t *perm_p, *pair_off, *pair_ij, *n_pairs;
+  int P, qi, qj; float beta; float *out, *status;
+};
+__device__ __forceinline__ void motionmag_plan_body(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                    const float* __restrict__ intr, const int64_t* __restrict__ kk,
+                                                    const int32_t* __restrict__ perm_p,
+                                                    const int32_t* __restrict__ pair_off,
+                                                    const int32_t* __restrict__ pair_ij,
+                                                    const int32_t* __restrict__ n_pairs, int P, int qi, int qj,
+                                                    float beta, float* __restrict__ out,
+                                                    float* __restrict__ status) {
   __shared__ float red[4][1024];
   __shared__ int found[2];
   const int ng = *n_pairs;
@@ -273,13 +278,16 @@ __global__ __launch_bounds__(256) void motionmag_plan_kernel(const float* __rest
   }
   block_reduce4(s, red, out);
 }
+__global__ __launch_bounds__(256) void motionmag_plan_kernel(MotionPlanArgs A) {
+  motionmag_plan_body(A.poses, A.patches, A.intr, A.kk, A.perm_p, A.pair_off, A.pair_ij, A.n_pairs, A.P, A.qi, A.qj, A.beta, A.out, A.status);
+}
 
 // pops.point_cloud centre pixel, dpvo.py:358-360.
-__global__ void point_cloud_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
-                                   const float* __restrict__ intr, const int64_t* __restrict__ ix,
-                                   float* __restrict__ points, int64_t m, int P) {
+__device__ __forceinline__ void point_cloud_body(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                 const float* __restrict__ intr, const int64_t* __restrict__ ix,
+                                                 float* __restrict__ points, int64_t m, int P, int64_t bid, int64_t nblk) {
   const int PP = P * P, c = (P / 2) * P + P / 2;
-  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < m; k += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t k = bid * (int64_t)blockDim.x + threadIdx.x; k < m; k += nblk * blockDim.x) {
     const int64_t f = ix[k];
     const Pose Ginv = se3_inv(load_pose(poses + 7 * f));
     const float* K = intr + 4 * f;
@@ -289,6 +297,22 @@ __global__ void point_cloud_kernel(const float* __restrict__ poses, const float*
     se3_act4(Ginv, X0, X1);
     points[3 * k + 0] = X1[0] / X1[3]; points[3 * k + 1] = X1[1] / X1[3]; points[3 * k + 2] = X1[2] / X1[3];
   }
+}
+
+__global__ void point_cloud_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                   const float* __restrict__ intr, const int64_t* __restrict__ ix,
+                                   float* __restrict__ points, int64_t m, int P) {
+  point_cloud_body(poses, patches, intr, ix, points, m, P, blockIdx.x, gridDim.x);
+}
+// point cloud + flow test in ONE launch (the tail of a frame: both read the poses / patches the bundle adjustment has just
+// written and nothing else depends on either): the last block is the flow test, the others the point cloud
+__global__ __launch_bounds__(256) void point_cloud_motionmag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                                    const float* __restrict__ intr, const int64_t* __restrict__ ix,
+                                                                    float* __restrict__ points, int64_t m, int P, MotionPlanArgs A) {
+  if (blockIdx.x == gridDim.x - 1)
+    motionmag_plan_body(A.poses, A.patches, A.intr, A.kk, A.perm_p, A.pair_off, A.pair_ij, A.n_pairs, A.P, A.qi, A.qj, A.beta, A.out, A.status);
+  else
+    point_cloud_body(poses, patches, intr, ix, points, m, P, blockIdx.x, gridDim.x - 1);
 }
 
 inline unsigned grid_for(int64_t n) {
@@ -361,12 +385,26 @@ extern "C" int dpvo_motionmag_status(const float* poses, const float* patches, c
   if (plan && E > 0) {
     dpvo_plan_layout_t PL;
     dpvo_plan_layout(E, &PL);
-    hipLaunchKernelGGL(motionmag_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, poses, patches, intrinsics, kk,
-                       plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, plan + PL.counts + 1, P, (int)i, (int)j, beta,
-                       out4, status4);
+    const MotionPlanArgs A = {poses, patches, intrinsics, kk, plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, plan + PL.counts + 1,
+                              P, (int)i, (int)j, beta, out4, status4};
+    hipLaunchKernelGGL(motionmag_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
   } else
   hipLaunchKernelGGL(motionmag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
                      kk, E, P, i, j, beta, out4);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_point_cloud_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                                          float* points, int64_t m, const int64_t* kk, const int32_t* plan, int64_t E, int P,
+                                          int64_t i, int64_t j, float beta, float* out4, float* status4, void* stream) {
+  if (m <= 0 || E <= 0 || P <= 0 || !poses || !patches || !intrinsics || !ix || !points || !kk || !plan || !out4) return DPVO_E_INVALID;
+  dpvo_plan_layout_t PL;
+  dpvo_plan_layout(E, &PL);
+  const MotionPlanArgs A = {poses, patches, intrinsics, kk, plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, plan + PL.counts + 1,
+                            P, (int)i, (int)j, beta, out4, status4};
+  hipLaunchKernelGGL(point_cloud_motionmag_kernel, dim3(grid_for(m) + 1), dim3(256), 0, (hipStream_t)stream, poses, patches,
+                     intrinsics, ix, points, m, P, A);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

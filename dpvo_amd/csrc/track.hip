@@ -293,11 +293,11 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (t0 < 1) t0 = 1;
   STEP(dpvo_ba(a->poses, a->patches, a->intrinsics, target, weight, a->lmbda, K.ii, K.jj, K.kk, a->plan, np_ub, ng_ub, E, a->P, t0, n,
                a->iterations, nullptr, a->ws_ba, a->ws_ba_bytes, stream));
-  STEP(dpvo_point_cloud(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, a->P, stream));
-  // ---- keyframe: flow test between frames k - 1 and k + 1 (dpvo.py:266-269), then everything else on the device
+  // ---- point cloud, and the keyframe's flow test between frames k - 1 and k + 1 (dpvo.py:266-269), in one launch; then everything
+  //      else of the keyframe step on the device
   const int k = n - K.keyframe_index;
-  STEP(dpvo_motionmag_status(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->plan, E, a->P, k - 1, k + 1, a->mm_beta,
-                             a->result_dev, a->result_dev + 4, stream));
+  STEP(dpvo_point_cloud_motionmag(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, K.kk, a->plan, E, a->P, k - 1, k + 1,
+                                  a->mm_beta, a->result_dev, a->result_dev + 4, stream));
   dpvo_keyframe_step_t kf = K;
   kf.flow4 = a->result_dev;
   kf.result = reinterpret_cast<int32_t*>(a->result_dev + 8);

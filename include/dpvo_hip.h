@@ -118,6 +118,10 @@ int dpvo_motionmag(const float* poses, const float* patches, const float* intrin
 int dpvo_motionmag_status(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                           const int64_t* jj, const int64_t* kk, const int32_t* plan, int64_t E, int P, int64_t i, int64_t j,
                           float beta, float* out4, float* status4, void* stream);
+/* dpvo_point_cloud and dpvo_motionmag_status (plan variant) in ONE launch: the tail of a frame (dpvo.py:358-360, 266-269). */
+int dpvo_point_cloud_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix, float* points,
+                               int64_t m, const int64_t* kk, const int32_t* plan, int64_t E, int P, int64_t i, int64_t j, float beta,
+                               float* out4, float* status4, void* stream);
 
 /* pops.point_cloud centre pixel (projective_ops.py:115-117, dpvo.py:358-360): points[m,3]. */
 int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
