@@ -54,6 +54,7 @@ _ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '-1'))     #
 _ENC_TAIL_US = float(__import__('os').environ.get('DPVO_ENC_TAIL_US', '200'))
 _ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '120'))
 _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
+_HOST_TRACE = [] if __import__('os').environ.get('DPVO_HOST_TRACE') else None      # (dev aid: host time stamps around the frame call)
 _PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
 
@@ -513,6 +514,8 @@ class DPVO:
               "dpose": torch.zeros(2, 7, dtype=f32, device=dev),
               "ev": [torch.cuda.Event() for _ in range(2)], "wait_ema": 0.0,
               "args": [L.FrameUpdate(), L.FrameUpdate()]}
+        fu["host_i"] = [h.view(torch.int32).numpy() for h in fu["host"]]       # (views of the same pinned memory)
+        fu["host_f"] = [h.numpy() for h in fu["host"]]
         for e_ in (fu["evpool"] or ()):
             e_.record()                 # (creates the HIP event handle)
         dp = lambda t: t.data_ptr()
@@ -558,6 +561,7 @@ class DPVO:
         """DPVO.update() + DPVO.keyframe() (dpvo.py:328-360,266-310) of a steady-state frame as one library call (with `fs`, a
         filled dpvo_frame_state_t, also the new frame's state stores and edges in front of it); the keyframe decision is taken
         and executed on the device, its result is consumed by flush() -- at the start of the next call."""
+        if _HOST_TRACE is not None: _HOST_TRACE.append(("fuc", __import__("time").perf_counter()))
         from . import net as net_mod
         from .altcorr import correlation as corr_mod
         es, inac, cfg = self.pg.edges, self.pg.edges_inac, self.cfg
@@ -621,7 +625,9 @@ class DPVO:
             else:
                 a.ev_update_done, self._hold_event = self._upd_done.cuda_event, self._upd_done
         self._stamp(3)
+        if _HOST_TRACE is not None: _HOST_TRACE.append(("call", __import__("time").perf_counter()))
         L.check(L.lib().dpvo_frame_update(ctypes.byref(a), L.stream()), "dpvo_frame_update")
+        if _HOST_TRACE is not None: _HOST_TRACE.append(("ret", __import__("time").perf_counter()))
         self._stamp(4)
         es.net_pending = None           # (gathered by the operator's first kernel, rewritten compact by its last one)
         ev = fu["ev"][par]
@@ -641,13 +647,15 @@ class DPVO:
             if rest > 2.5e-4:
                 time.sleep(rest - 2.0e-4)
         ev.synchronize()
+        if _HOST_TRACE is not None: _HOST_TRACE.append(("sync", time.perf_counter()))
         fu["wait_ema"] = 0.8 * fu["wait_ema"] + 0.2 * (time.perf_counter() - t_enq) if fu["wait_ema"] else (time.perf_counter() - t_enq)
-        res = host.view(torch.int32)[8:13].tolist()
-        decision, n_keep, n_rem, e_in, overflow = res
+        # (numpy views of the pinned record: this stretch of host code runs while the GPU has nothing to do)
+        hi = fu["host_i"][flip]
+        decision, n_keep, n_rem, e_in, overflow = int(hi[8]), int(hi[9]), int(hi[10]), int(hi[11]), int(hi[12])
         if e_in != E or overflow:
-            raise L.DPVOHipError(f"dpvo_keyframe_step: inconsistent result {res} for E = {E}")
-        st = [int(v) for v in host[4:8].tolist()]
-        if st[3] != 0 and not getattr(self, "_plan_exact", False):
+            raise L.DPVOHipError(f"dpvo_keyframe_step: inconsistent result {hi[8:13].tolist()} for E = {E}")
+        if fu["host_f"][flip][7] != 0 and not getattr(self, "_plan_exact", False):
+            st = [int(v) for v in host[4:8].tolist()]
             import warnings
             warnings.warn("dpvo_amd: an edge fell outside the window the graph plan was sized for "
                           f"(counters {st}); switching to exact plans", RuntimeWarning)
@@ -663,11 +671,12 @@ class DPVO:
             self.m -= self.M
         es.a, es.b = es.b, es.a
         es.a["net"], es.b["net"] = es.b["net"], es.a["net"]       # the state stays where it is ...
-        es.net_pending = (fu["keep_rows"][:n_keep], n_keep)        # ... until the next update operator gathers it (or a reader asks)
+        es.net_pending = (fu["keep_rows"], n_keep)                 # ... until the next update operator gathers it (or a reader asks)
         es.E = n_keep
         inac.E += n_rem
         es.invalidate_host()
         self._plan = None
+        if _HOST_TRACE is not None: _HOST_TRACE.append(("fin", __import__("time").perf_counter()))
 
     def __run_global_BA(self):
         """ Global bundle adjustment
@@ -880,15 +889,16 @@ class DPVO:
                     enc_done.record(side)
         if hip_enc:
             n_spec = self.n
-            self.flush()                        # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
             if side is not None:
-                main_stream.wait_event(enc_done)
+                main_stream.wait_event(enc_done)    # (issued before the host blocks: nothing that runs after the wake-up is free)
+            self.flush()                        # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
             if self.n != n_spec:                # that keyframe was dropped: the new frame lives one slot lower
                 self._fmap1_cl[self.n % self.mem].copy_(slot)
                 slot = self._fmap1_cl[self.n % self.mem]
             maps = (slot, self._imap_full)
         self.flush()
 
+        if _HOST_TRACE is not None: _HOST_TRACE.append(("fast", __import__("time").perf_counter()))
         fast = maps is not None and self.P == 3 and (patch_coords is None or patch_coords.numel() == 2 * self.M)
         if fast:
             # Patchifier's gathers + every per-frame state store in ONE launch (dpvo_frame_patches); the three random
@@ -922,6 +932,7 @@ class DPVO:
             if n > 1 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
                 *_, a, b, c = [1] * 3 + self.tlist
                 fac = (c - b) / (b - a)
+            if _HOST_TRACE is not None: _HOST_TRACE.append(("comp", __import__("time").perf_counter()))
             if composite:
                 es = self.pg.edges
                 total = es.frame_edge_count(n + 1, self.M, self.cfg.PATCH_LIFETIME)
