@@ -930,7 +930,7 @@ class DPVO:
                          and n > 1 and 3 * self.M * self.P * self.P <= 4096)
             fac = None
             if n > 1 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
-                *_, a, b, c = [1] * 3 + self.tlist
+                a, b, c = ([1, 1, 1] + self.tlist[-3:])[-3:]          # (the last three time stamps, padded with 1 like the reference's [1]*3 + tlist)
                 fac = (c - b) / (b - a)
             if _HOST_TRACE is not None: _HOST_TRACE.append(("comp", __import__("time").perf_counter()))
             if composite:
@@ -1023,7 +1023,7 @@ class DPVO:
             if self.n > 1:
                 if self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
                     # To deal with varying camera hz
-                    *_, a, b, c = [1] * 3 + self.tlist
+                    a, b, c = ([1, 1, 1] + self.tlist[-3:])[-3:]          # (the last three time stamps, padded with 1 like the reference's [1]*3 + tlist)
                     fac = (c - b) / (b - a)
                     # poses_[n] = Exp(MOTION_DAMPING * fac * Log(P1 * P2^-1)) * P1: one kernel (was ~8 lietorch launches)
                     L.check(L.lib().dpvo_motion_model(L.ptr(self.pg.poses_), L.i32(self.n),
