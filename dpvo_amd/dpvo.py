@@ -889,9 +889,11 @@ class DPVO:
                     enc_done.record(side)
         if hip_enc:
             n_spec = self.n
-            if side is not None:
-                main_stream.wait_event(enc_done)    # (issued before the host blocks: nothing that runs after the wake-up is free)
             self.flush()                        # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
+            if side is not None:
+                # (after the host has waited, when the encoders are through: issued earlier, the wait would be PENDING for the
+                #  encoders' whole run and a cross-stream wait that is pending costs a runtime thread its CPU time, 0.3 ms per frame)
+                main_stream.wait_event(enc_done)
             if self.n != n_spec:                # that keyframe was dropped: the new frame lives one slot lower
                 self._fmap1_cl[self.n % self.mem].copy_(slot)
                 slot = self._fmap1_cl[self.n % self.mem]
