@@ -69,7 +69,8 @@ __device__ __forceinline__ void kf_host_copy(const dpvo_keyframe_step_t& a) {
   volatile int32_t* h = (volatile int32_t*)a.result_host;
   const int32_t* src = a.result - (a.host_words == 16 ? 8 : 0);
   for (int i = 0; i < a.host_words; ++i) h[i] = src[i];
-  __threadfence_system();
+  // (no __threadfence_system(): it parks the wave until the PCIe writes are acknowledged, ~8 us at the very end of the frame.  The
+  //  host reads the record only after synchronising with an event recorded behind this kernel, which orders the writes.)
 }
 constexpr int KF_CHUNK = 1024;
 __global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts) {
