@@ -32,6 +32,10 @@ The JSON line also carries
                   of the whole operator (HIP events around it on the launch stream) against the 2.5 PFLOP/s dense f16 MFMA peak;
   cpu_baseline -- the CPU oracle ("port": oracle/liboracle.so + oracle/update_ref.py) timed on rank 0 at N = 1 on
                   two full hot-path steps (reproject, corr, update, 2 BA iterations at E = 45 312), ~10 s;
+  ref_baseline -- the REFERENCE's own tracker (its Python + its CUDA kernels compiled for gfx950 by oracle/build_ref.py, with torch
+                  stand-ins for torch_scatter / lietorch_backends: oracle/ref_pipeline.py) on the same box, same stream, same weights,
+                  same steady state (E = 45 312): frames/sec over 20 frames, rank 0 at N = 1 only; null when oracle/_ref is absent.
+                  A reported baseline (the only same-node comparator north_star's ">= reference frames/sec" has), never `value`;
   box          -- the shader clock this box sustains under a full-chip / quarter-chip MFMA load (tools/probes/clock_probe.hip);
   state        -- whether the tracker state after the run is sane (finite poses, fraction of edges that project in
                   bounds): with random weights nothing guarantees that, and a diverged state would make the correlation
@@ -145,12 +149,34 @@ def cpu_baseline():
                       f"{dt:.1f} s per step"}
 
 
+def ref_baseline(device, ht, wd, cfg, frames, intr, seed, warm=53, timed=20):
+    """frames/sec of the reference's own tracker on this box (test infrastructure used as a comparator, like cpu_baseline)"""
+    try:
+        from oracle import ref_pipeline as RP
+        if not RP.available():
+            return {"frames_per_sec": None, "reason": "oracle/_ref not built (needs /root/reference at build time)"}
+        from dpvo_amd.net import VONet
+        torch.manual_seed(seed)
+        sd = {k: v.detach().clone() for k, v in VONet().state_dict().items()}
+        slam = RP.make_tracker(RP.make_cfg(cfg), sd, ht, wd, accept_probe=True)
+        fps, dt = RP.throughput(slam, frames, intr, warm, timed, seed=seed)
+        E = int(slam.pg.ii.numel())
+        finite = bool(torch.isfinite(slam.pg.poses_[:slam.n]).all().item())
+        return {"frames_per_sec": round(fps, 2), "ms_per_frame": round(1e3 * dt / timed, 2), "frames": timed, "edges": E, "finite": finite,
+                "kind": "reference Python (dpvo/dpvo.py, net.py, ...) + reference kernels (cuda_corr, cuda_ba) hipified for gfx950, torch "
+                        "stand-ins for torch_scatter / lietorch_backends, torch-MIOpen encoders under autocast; same box, same stream, "
+                        "same weights, same steady state"}
+    except Exception as e:          # noqa: BLE001  (a comparator must never take the measurement down)
+        return {"frames_per_sec": None, "error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=45)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-baseline", action="store_true")
     ap.add_argument("--config", default="default", choices=["default", "fast"])
     ap.add_argument("--seed-offset", type=int, default=None, help="sequence / weight seed offset (default: the rank)")
     ap.add_argument("--drop-every", type=int, default=0,
@@ -352,6 +378,10 @@ def main():
                            "corr_ms_minmax": [round(min(corr_ms), 4), round(max(corr_ms), 4)]}
         if world == 1 and not os.environ.get("DPVO_BENCH_NO_BOX"):     # (skipped under rocprofv3: the probe is a child process)
             out["box"] = box_clock()
+        if world == 1 and not args.no_ref_baseline and args.config == "default":
+            out["ref_baseline"] = ref_baseline(device, ht, wd, cfg, frames, intr, 1234 + seed_off)
+            if out["ref_baseline"].get("frames_per_sec"):
+                out["ref_baseline"]["speedup"] = round(out["value"] / out["ref_baseline"]["frames_per_sec"], 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPVO_HIP_LIB") or os.path.join(_HERE, "libdpvo_hip.so")      # (override: development builds)
 
 F16, F32 = 0, 1
+ABI_VERSION = 4         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
 
 # every symbol include/dpvo_hip.h declares (tests/test_capi.py checks the .so exports all of them)
 SYMBOLS = [
@@ -112,6 +113,10 @@ def lib():
                   "dpvo_gba_workspace_bytes", "dpvo_gba_solve_workspace_bytes", "dpvo_encoders_workspace_bytes",
                   "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
+        L.dpvo_abi_version.restype = ctypes.c_int
+        if L.dpvo_abi_version() != ABI_VERSION:
+            raise DPVOHipError(f"{LIB_PATH} has ABI version {L.dpvo_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                               "(`make -C dpvo_amd/csrc`)")
         _lib = L
     return _lib
 

@@ -1,6 +1,6 @@
 // capi.hip -- ABI bookkeeping of libdpvo_hip.so
 #include "common.h"
-extern "C" int dpvo_abi_version(void) { return 1; }
+extern "C" int dpvo_abi_version(void) { return DPVO_ABI_VERSION; }
 
 // dpvo_debug_stamp: a one-thread kernel that writes the 100 MHz wall clock into slot[0] when it EXECUTES -- a stream-ordered
 // time stamp for timelines across streams without a profiler attached (tools/stream_stamps.py).  Dev aid, not on any hot path.

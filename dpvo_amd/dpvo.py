@@ -41,7 +41,8 @@ _PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '0')
 # decision, the edge removal, the renumbering and the ring-buffer shifts happen on the device (dpvo_keyframe_step); the host
 # reads a 16-word result one frame later.  0: the round-2 path (Python-paced launches, host mirror of the index arrays).
 _FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
-# the result read-back waits on an event created with hipEventBlockingSync: the waiting thread sleeps instead of spinning
+# DPVO_BLOCKING_SYNC=1: the result read-back sleeps through most of the frame's expected rest (running mean of the GPU-bound waits)
+# before it synchronises with the frame's (plain torch.cuda) event, instead of spinning on it from the start
 # DPVO_ENC_AFTER_UPDATE=1: the side stream holds the next frame's encoders back until the current frame's update operator is
 # through, so that they run beside the small BA / keyframe kernels instead of beside the correlation / update kernels
 # The hold is a hipStreamWaitEvent, and while such a wait is pending a thread of the HIP runtime burns CPU (0.7 ms per frame when
@@ -57,6 +58,8 @@ _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
 _HOST_TRACE = [] if __import__('os').environ.get('DPVO_HOST_TRACE') else None      # (dev aid: host time stamps around the frame call)
 _PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
+_MAX_SLEEP_S = 2.0e-3      # no single pacing sleep is longer than this, whatever the running mean says
+_MAX_FRAME_S = 4.0e-3      # a wait longer than this is not a frame's GPU time (first frames, a paused caller): clamped in the mean
 
 
 class DPVO:
@@ -86,6 +89,7 @@ class DPVO:
         # dpvo.py:266-270 (True = drop keyframe n - KEYFRAME_INDEX); the test kernel and its read-back still run.  For workloads
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
+        self.last_keyframe = None   # (decision, (sum_ij, count_ij, sum_ji, count_ji)) of the last resolved keyframe test
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:     # "cuda" -> "cuda:<current>": tensors carry an index, and
             self.device = torch.device("cuda", torch.cuda.current_device())   # `t.device != torch.device("cuda")` is always True
@@ -424,6 +428,7 @@ class DPVO:
             self._plan = None
 
         drop = (m / 2 < self.cfg.KEYFRAME_THRESH) if forced is None else forced
+        self.last_keyframe = (int(bool(drop)), (m_ij, 1.0, m_ji, 1.0))
         if drop:
             k = self.n - self.cfg.KEYFRAME_INDEX
             t0 = self.pg.tstamps_[k - 1]
@@ -588,6 +593,8 @@ class DPVO:
         # on for ~5 us, so they are taken on every DPVO_PROFILE_EVERY-th frame only, and the end of the correlation doubles as the
         # start of the update operator (3 records instead of 4)
         sample = _PROFILE_EVERY <= 1 or (self.counter % _PROFILE_EVERY) == 0
+        if not corr_mod.PROFILE and not net_mod.PROFILE:
+            fu["evpos"] = 0                     # fresh (or no) PROFILE lists: nothing refers to the pool's events any more
         for i, lst in enumerate((corr_mod.PROFILE, net_mod.PROFILE)):
             if lst is not None and sample:
                 pool = fu["evpool"]     # a pool whose handles exist already (the call re-records them in place)
@@ -597,7 +604,12 @@ class DPVO:
                     for e_ in pool:
                         e_.record()
                 pos = fu["evpos"]
-                fu["evpos"] = (pos + 2) % len(pool)
+                if pos + 2 > len(pool):         # never hand out an event a PROFILE entry still refers to: grow instead of wrapping
+                    more = [torch.cuda.Event(enable_timing=True) for _ in range(256)]
+                    for e_ in more:
+                        e_.record()
+                    pool.extend(more)
+                fu["evpos"] = pos + 2
                 e0, e1 = pool[pos], pool[pos + 1]
                 if i == 1 and corr_mod.PROFILE is not None:
                     e0 = fu["ev_corr_end"]                      # (recorded once, read by both)
@@ -642,16 +654,23 @@ class DPVO:
         # the start would burn a host core per tracker for nothing.
         import time
         fu = self._fu
-        if _BLOCKING_SYNC and not ev.query():
-            rest = fu["wait_ema"] - (time.perf_counter() - t_enq)
+        # (the running mean only ever holds GPU-bound durations: a sample is taken when the host actually had to wait, and is
+        #  clamped -- a caller that pauses between frames must not teach the tracker to sleep through its next frames)
+        waited = not ev.query()
+        if _BLOCKING_SYNC and waited:
+            rest = min(fu["wait_ema"] - (time.perf_counter() - t_enq), _MAX_SLEEP_S)
             if rest > 2.5e-4:
                 time.sleep(rest - 2.0e-4)
         ev.synchronize()
         if _HOST_TRACE is not None: _HOST_TRACE.append(("sync", time.perf_counter()))
-        fu["wait_ema"] = 0.8 * fu["wait_ema"] + 0.2 * (time.perf_counter() - t_enq) if fu["wait_ema"] else (time.perf_counter() - t_enq)
+        if waited:
+            sample = min(time.perf_counter() - t_enq, _MAX_FRAME_S)
+            fu["wait_ema"] = 0.8 * fu["wait_ema"] + 0.2 * sample if fu["wait_ema"] else sample
         # (numpy views of the pinned record: this stretch of host code runs while the GPU has nothing to do)
         hi = fu["host_i"][flip]
         decision, n_keep, n_rem, e_in, overflow = int(hi[8]), int(hi[9]), int(hi[10]), int(hi[11]), int(hi[12])
+        # what the device decided on: the flow test's sums and counts for (i -> j) and (j -> i) (dpvo.py:266-270), for diagnostics
+        self.last_keyframe = (decision, tuple(fu["host_f"][flip][0:4].tolist()))
         if e_in != E or overflow:
             raise L.DPVOHipError(f"dpvo_keyframe_step: inconsistent result {hi[8:13].tolist()} for E = {E}")
         if fu["host_f"][flip][7] != 0 and not getattr(self, "_plan_exact", False):
@@ -839,9 +858,9 @@ class DPVO:
             if _ENC_AFTER_UPDATE and getattr(self, "_hold_event", None) is not None and self._fu_pending is not None:
                 hold_ev = self._hold_event
                 ema_ = self._fu["wait_ema"]
-                if ema_ > 0 and _ENC_LEAD_US >= 0:
+                if ema_ > 0 and _ENC_LEAD_US >= 0 and not hold_ev.query():      # (already through: nothing to wait out)
                     import time
-                    rest_ = self._fu_pending[5] + ema_ - 1e-6 * (_ENC_TAIL_US + _ENC_LEAD_US) - time.perf_counter()
+                    rest_ = min(self._fu_pending[5] + ema_ - 1e-6 * (_ENC_TAIL_US + _ENC_LEAD_US) - time.perf_counter(), _MAX_SLEEP_S)
                     if rest_ > 6e-5:
                         time.sleep(rest_ - 5e-5)
                 if _ENC_HOLD_AT < 0:

@@ -36,7 +36,9 @@ extern "C" {
 #define DPVO_F16 0
 #define DPVO_F32 1
 
-/* ABI version: bumped on any signature change. */
+/* ABI version: bumped on ANY change of a signature, a struct layout or the exported set (round 3 changed all three without a
+ * bump: ADVICE r3).  The Python binding refuses a library whose version differs from the one it was written against. */
+#define DPVO_ABI_VERSION 4
 int dpvo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -19,6 +19,11 @@ What is built (nothing of the reference is copied into the repository; patched c
   round 3).  The staged copy declares `float Jj[6]` and copies the same six expressions into it; no arithmetic changes.
 * lietorch_backends needs real Eigen (quaternion / matrix types throughout so3.h / se3.h): not buildable here, stays out.
 
+* pyref/dpvo_reference/ = the reference's Python package around those kernels (dpvo/{dpvo,net,patchgraph,projective_ops,blocks,
+  extractor,utils,ba}.py, lietorch/*.py, altcorr/, fastba/, loop_closure/optim_utils.py), staged UNMODIFIED under another package
+  name so that oracle/ref_pipeline.py can run the reference's own `DPVO` class on the GPU box (where /root/reference does not
+  exist) with the stand-ins of oracle/ref_standins.py for torch_scatter / lietorch_backends / numba.  Git-ignored like the .so files.
+
 torch.utils.cpp_extension hipifies the sources (cuda* -> hip* renames; the kernels' arithmetic is untouched) and
 drives hipcc for gfx950; it needs no GPU.  The modules are loaded by tests only (`oracle.ref_native()`).
 """
@@ -95,10 +100,24 @@ def _stage_ba(d):
     return [os.path.join(d, "ba.cpp"), os.path.join(d, "ba_cuda.cu"), os.path.join(d, "block_e.cu")]
 
 
+PY_FILES = ["__init__.py", "dpvo.py", "net.py", "patchgraph.py", "projective_ops.py", "blocks.py", "extractor.py", "utils.py", "ba.py",
+            "lietorch/__init__.py", "lietorch/groups.py", "lietorch/group_ops.py", "lietorch/broadcasting.py",
+            "altcorr/__init__.py", "altcorr/correlation.py", "fastba/__init__.py", "fastba/ba.py", "loop_closure/optim_utils.py"]
+
+
+def stage_python():
+    """the reference's Python package, unmodified, as oracle/_ref/pyref/dpvo_reference/ (see module docstring)"""
+    dst = os.path.join(OUT, "pyref", "dpvo_reference")
+    for rel in PY_FILES:
+        _write(os.path.join(dst, rel), _read("dpvo/" + rel))
+    return dst
+
+
 def build(verbose=False):
     """Returns the list of built files; raises if /root/reference is absent (the GPU box uses the prebuilt files)."""
     if not os.path.isdir(os.path.join(REF, "dpvo", "altcorr")):
         raise FileNotFoundError(f"reference sources not found under {REF}")
+    stage_python()
     os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
     os.environ.setdefault("MAX_JOBS", "4")
     from torch.utils import cpp_extension as ce

@@ -27,7 +27,9 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"libdpvo_hip.so does not export {n}"
     assert sorted(_lib.SYMBOLS) == names, "dpvo_amd/_lib.py SYMBOLS out of sync with include/dpvo_hip.h"
     lib.dpvo_abi_version.restype = ctypes.c_int
-    assert lib.dpvo_abi_version() >= 1
+    hdr = open(os.path.join(ROOT, "include", "dpvo_hip.h")).read()
+    from dpvo_amd import _lib as L_
+    assert lib.dpvo_abi_version() == L_.ABI_VERSION == int(re.search(r"#define DPVO_ABI_VERSION (\d+)", hdr).group(1))
     # the comparator library (two more implementations of the update operator: test / measurement partners) exports what its
     # own header declares, and the product library does NOT carry those entries
     cmp_names = _declared("dpvo_hip_cmp.h")

@@ -295,3 +295,45 @@ def test_f16_rounding_and_reference_arithmetic_emulation(oracle):
     print("f16-arithmetic emulation vs exact: max %.2e  rms %.2e  (|corr| rms %.2f)" % (err.max(), np.sqrt((err ** 2).mean()),
                                                                                          np.sqrt((exact ** 2).mean())))
     assert 1e-4 < err.max() < 2e-2
+
+
+def test_ref_standins_lietorch_and_scatter(oracle):
+    """oracle/ref_standins.py (the torch stand-ins the reference's own Python runs on, oracle/ref_pipeline.py): the SE3 ops against
+    the C restatement in f64 and against lietorch's identities (run_tests.py:16-52); the scatter composites against a per-group loop"""
+    from oracle import ref_standins as RS
+    g = torch.Generator().manual_seed(3)
+    a = .3 * torch.randn(200, 6, generator=g, dtype=torch.float64)
+    a[0] = 0; a[1, 3:] = 1e-9; a[2, :3] = 1.0; a[2, 3:] = 0
+    X = RS.se3_exp(3, a)
+    assert np.allclose(X.numpy(), oracle.se3_exp(a.numpy()), atol=1e-13)
+    assert np.allclose(RS.se3_log(3, X).numpy(), oracle.se3_log(X.numpy()), atol=1e-12)
+    assert np.allclose(RS.se3_log(3, X).numpy(), a.numpy(), atol=1e-8)                      # test_exp_log
+    Y = RS.se3_exp(3, torch.randn(200, 6, generator=g, dtype=torch.float64))
+    Y[:, 3:] *= 1.7                                                                          # un-normalised input: constructors normalise
+    assert np.allclose(RS.se3_inv(3, Y).numpy(), oracle.se3_inv(Y.numpy()), atol=1e-13)
+    assert np.allclose(RS.se3_mul(3, X, Y).numpy(), oracle.se3_mul(X.numpy(), Y.numpy()), atol=1e-13)
+    assert np.allclose(RS.se3_log(3, RS.se3_mul(3, Y, RS.se3_inv(3, Y))).numpy(), 0, atol=1e-8)          # test_inv
+    p = torch.randn(200, 4, generator=g, dtype=torch.float64)
+    assert np.allclose(RS.se3_act4(3, Y, p).numpy(), oracle.se3_act4(Y.numpy(), p.numpy()), atol=1e-13)
+    T = RS.se3_as_matrix(3, Y)
+    assert np.allclose((T @ p[..., None])[..., 0].numpy(), RS.se3_act4(3, Y, p).numpy(), atol=1e-12)      # test_act
+    assert np.allclose(RS.se3_act(3, Y, p[:, :3]).numpy(), (T[:, :3, :3] @ p[:, :3, None])[..., 0].numpy() + T[:, :3, 3].numpy(), atol=1e-12)
+    # test_adj (:30-41): X * Exp(a) * X^-1 == Exp(Ad_X a); adjT is the transpose of the same matrix
+    b = .3 * torch.randn(200, 6, generator=g, dtype=torch.float64)
+    lhs = RS.se3_mul(3, RS.se3_mul(3, X, RS.se3_exp(3, b)), RS.se3_inv(3, X))
+    assert np.allclose(RS.se3_log(3, lhs).numpy(), RS.se3_adj(3, X, b).numpy(), atol=1e-8)
+    c = torch.randn(200, 6, generator=g, dtype=torch.float64)
+    assert np.allclose((RS.se3_adjT(3, X, c) * b).sum(-1).numpy(), (c * RS.se3_adj(3, X, b)).sum(-1).numpy(), atol=1e-12)
+    # f32 runs the same branches
+    assert np.allclose(RS.se3_log(3, RS.se3_exp(3, a.float())).numpy(), a.numpy(), atol=2e-6)
+    # ---- scatter composites (torch_scatter 2.1.2 semantics), dim = 1 as at blocks.py:42-43
+    src = torch.randn(1, 300, 5, generator=g)
+    idx = torch.randint(0, 17, (300,), generator=g)
+    _, idx = torch.unique(idx, return_inverse=True)
+    sm, ss = RS.scatter_softmax(src, idx, dim=1), RS.scatter_sum(src, idx, dim=1)
+    for k in range(int(idx.max()) + 1):
+        m = idx == k
+        assert torch.allclose(sm[0, m], torch.softmax(src[0, m], 0), atol=1e-6)
+        assert torch.allclose(ss[0, k], src[0, m].sum(0), atol=1e-5)
+    h = RS.scatter_softmax(src.half(), idx, dim=1)
+    assert h.dtype == torch.float16 and torch.allclose(h.float(), sm, atol=2e-3)
