@@ -19,7 +19,8 @@ def stream(n, ht, wd, device, seed=1234):
     return make_stream(n, ht, wd, device, seed=seed)
 
 
-def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, overlap=True, buffer=256, **cfg_over):
+def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, overlap=True, buffer=256, ref_over=None, ours=True,
+               delta_scale=1.0, **cfg_over):
     """(ours, theirs, cfg): both trackers on default.yaml + overrides, the same random-init VONet weights (strict load on both sides),
     the initialisation probe accepted on both (random weights)"""
     from oracle import ref_pipeline as RP
@@ -34,10 +35,19 @@ def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, over
         cfg[k] = v
     torch.manual_seed(seed)
     net = VONet()
+    if delta_scale != 1.0:
+        # random-init weights make the flow head emit ~1 px of noise per edge, and a monocular tracker fed noise runs away in scale
+        # (extent x 2000 within 40 frames: tools/ref_parity.py scenario A); a smaller head keeps the SAME arithmetic in a bounded regime
+        with torch.no_grad():
+            net.update.d[1].weight.mul_(delta_scale)
+            net.update.d[1].bias.mul_(delta_scale)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}        # (DPVO casts the encoder towers to f16 in place)
-    ours = DPVO(cfg, net, ht=ht, wd=wd, device=dev, defer_keyframe=defer, overlap_encoders=overlap)
-    ours.motion_probe = lambda: 1.0e9
-    theirs = RP.make_tracker(RP.make_cfg(cfg), sd, ht, wd, accept_probe=True, feed_encoders=feed)
+    if ours:
+        ours = DPVO(cfg, net, ht=ht, wd=wd, device=dev, defer_keyframe=defer, overlap_encoders=overlap)
+        ours.motion_probe = lambda: 1.0e9
+    else:       # (reference against reference: the second tracker is another instance of the reference's class)
+        ours = RP.make_tracker(RP.make_cfg(cfg), sd, ht, wd, accept_probe=True, feed_encoders=feed)
+    theirs = RP.make_tracker(RP.make_cfg(cfg, **(ref_over or {})), sd, ht, wd, accept_probe=True, feed_encoders=feed)
     theirs._flows = []
     real_mm = theirs.motionmag
 
@@ -51,9 +61,11 @@ def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, over
 
 def compare(so, sr):
     """distances between two snapshots (oracle.ref_pipeline.snapshot) of the same frame"""
-    d = {"int_equal": all(so[k] == sr[k] for k in ("n", "m", "counter", "delta_keys"))}
-    for k in INT_KEYS:
-        d["int_equal"] = d["int_equal"] and so[k].shape == sr[k].shape and bool(np.array_equal(so[k], sr[k]))
+    bad = [k for k in ("n", "m", "counter", "delta_keys") if so[k] != sr[k]]
+    bad += [k for k in INT_KEYS if so[k].shape != sr[k].shape or not np.array_equal(so[k], sr[k])]
+    d = {"int_equal": not bad}
+    if bad:
+        d["int_mismatch"] = {k: ([int(np.size(so[k])), int(np.size(sr[k]))] if k in INT_KEYS else [so[k], sr[k]]) for k in bad}
     if not d["int_equal"] or so["n"] == 0:
         return d
     n = so["n"]
@@ -72,9 +84,23 @@ def compare(so, sr):
     return d
 
 
-def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, flush_each=True, log=None, stop_on_mismatch=True):
+def sync_from_reference(ours, theirs):
+    """teacher forcing: our tracker continues from the REFERENCE's float state (poses, patches incl. depths, hidden state).  The
+    integer state is never touched -- it has to be identical on its own."""
+    n = theirs.n
+    ours.pg.poses_[:n].copy_(theirs.pg.poses_[:n])
+    ours.pg.patches_[:n].copy_(theirs.pg.patches_[:n])
+    ours.pg.net.copy_(theirs.pg.net.float())
+
+
+def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, flush_each=True, log=None, stop_on_mismatch=True,
+                 teacher=False):
     """frame t: same seed -> our call (+ flush) -> [our encoder outputs handed to the reference] -> same seed -> reference call ->
-    compare.  Returns the list of per-frame distance records (each carries `t` and the two keyframe decisions)."""
+    compare.  Returns the list of per-frame distance records (each carries `t` and the two keyframe decisions).
+    teacher: after the comparison our tracker's float state is overwritten with the reference's (sync_from_reference), so that every
+    frame measures ONE frame's worth of divergence -- the random-weight tracker is a chaotic recurrence (the reference run twice
+    drifts apart as fast as the two implementations do: tools/ref_parity.py scenario R), which makes accumulated distances past
+    ~30 frames a statement about the dynamics, not about the implementation."""
     from oracle import ref_pipeline as RP
     recs = []
     n_img = frames.shape[0]
@@ -82,10 +108,13 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
         img = frames[t % n_img]
         n_o, n_r = ours.n, theirs.n
         torch.manual_seed(seed0 + t)
-        with torch.no_grad():
-            ours(float(t), img, intr, image_ready=False)
-            if flush_each:
-                ours.flush()
+        if not hasattr(ours, "flush"):              # (reference against reference)
+            RP.call(ours, float(t), img, intr)
+        else:
+            with torch.no_grad():
+                ours(float(t), img, intr, image_ready=False)
+                if flush_each:
+                    ours.flush()
         if feed:
             torch.cuda.synchronize()
             RP.feed(theirs, ours._fmap1_cl[(ours.n - 1) % ours.mem], ours._imap_full)
@@ -101,31 +130,44 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
         d["drop_ours"], d["drop_ref"] = (ours.n == n_o), (theirs.n == n_r)
         fl = theirs._flows[nf:]
         d["flow_ref"] = 0.5 * (fl[0] + fl[1]) if len(fl) == 2 else None
-        lk = ours.last_keyframe
+        lk = getattr(ours, "last_keyframe", None)
         if lk is not None and len(fl) == 2:
             s0, c0, s1, c1 = lk[1]
             d["flow_ours"] = 0.5 * ((s0 / c0 if c0 > 0 else float("nan")) + (s1 / c1 if c1 > 0 else float("nan")))
         else:
             d["flow_ours"] = None
+        if d["int_equal"] and hasattr(ours, "flush") and d["E"]:
+            dn = (ours.pg.net[0] - theirs.pg.net[0].float())
+            d["net_max"], d["net_rms"] = float(dn.abs().max()), float(dn.pow(2).mean().sqrt())
+            if hasattr(theirs.pg, "target") and theirs.pg.target.shape[1] == d["E"]:      # (set by the first update, dpvo.py:342-343)
+                d["target_max"] = float((ours.pg.target[0] - theirs.pg.target[0]).abs().max())
+                d["weight_max"] = float((ours.pg.weight[0] - theirs.pg.weight[0]).abs().max())
         recs.append(d)
         if log is not None:
             log(d)
         if stop_on_mismatch and not d["int_equal"]:
             break
+        if teacher and d["int_equal"]:
+            sync_from_reference(ours, theirs)
     return recs
 
 
 def summarise(recs):
     ok = [r for r in recs if r.get("int_equal") and "pose_max" in r]
     out = {"frames": len(recs), "int_equal_frames": sum(bool(r.get("int_equal")) for r in recs),
-           "first_int_mismatch": next((r["t"] for r in recs if not r.get("int_equal")), None)}
+           "first_int_mismatch": next(({"t": r["t"], **r.get("int_mismatch", {})} for r in recs if not r.get("int_equal")), None)}
     if ok:
         out.update(pose_max=max(r["pose_max"] for r in ok), trans_rms_max=max(r["trans_rms"] for r in ok),
                    trans_rms_last=ok[-1]["trans_rms"], extent_last=ok[-1]["extent"],
                    depth_rel_p50=max(r["depth_rel_p50"] for r in ok), depth_rel_p90=max(r["depth_rel_p90"] for r in ok),
                    colors_maxdiff=max(r["colors_maxdiff"] for r in ok), patch_xy_equal=all(r["patch_xy_equal"] for r in ok),
                    intrinsics_equal=all(r["intrinsics_equal"] for r in ok), finite=all(r["finite"] for r in ok),
-                   E_last=ok[-1]["E"], n_last=None)
+                   E_last=ok[-1]["E"], net_max=max((r.get("net_max", 0.0) for r in ok), default=None),
+                   net_rms=max((r.get("net_rms", 0.0) for r in ok), default=None),
+                   target_max=max((r.get("target_max", 0.0) for r in ok), default=None),
+                   weight_max=max((r.get("weight_max", 0.0) for r in ok), default=None),
+                   pose_max_first28=max((r["pose_max"] for r in ok if r["t"] < 28), default=None),
+                   pose_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}")] for r in ok[::4]])
     dec = [(r["t"], r["drop_ours"], r["drop_ref"], r["flow_ours"], r["flow_ref"]) for r in recs if r.get("flow_ref") is not None]
     out["decisions"] = len(dec)
     out["drops_ref"] = sum(1 for x in dec if x[2])

@@ -146,6 +146,90 @@ def test_device_keyframe_step_equals_the_host_path(dev):
     assert np.abs(pa - pb).max() < 1e-5
 
 
+def _run_unforced(dev, thresh, n_frames=44, M=16, ht=96, wd=128, seed=11, frame_call=True, **kw):
+    """a tracker whose keyframe test is NOT scripted (keyframe_override None, forced = -1): the decision comes from the flow test"""
+    import dpvo_amd.dpvo as dpvo_mod
+    fc_before = dpvo_mod._FRAME_CALL
+    dpvo_mod._FRAME_CALL = frame_call
+    try:
+        cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
+        cfg.PATCHES_PER_FRAME, cfg.BUFFER_SIZE, cfg.KEYFRAME_THRESH = M, 256, thresh
+        torch.manual_seed(seed)
+        slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev, **kw)
+        slam.motion_probe = lambda: 1e9
+        g = torch.Generator().manual_seed(seed)
+        tex = torch.rand(3, ht + 64, wd + 64, generator=g)
+        tex = torch.nn.functional.avg_pool2d(tex[None], 5, 1, 2)[0]
+        tex = (255 * (tex - tex.min()) / (tex.max() - tex.min())).to(torch.uint8)
+        intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
+        log = []
+        for t in range(n_frames):
+            img = tex[:, (2 * t) % 64:(2 * t) % 64 + ht, (3 * t) % 64:(3 * t) % 64 + wd].contiguous().to(dev)
+            torch.manual_seed(900 + t)
+            n0 = slam.n
+            slam(float(t), img, intr)
+            slam.flush()
+            if slam.is_initialized and t >= 8:
+                dec, (s0, c0, s1, c1) = slam.last_keyframe
+                assert bool(dec) == (slam.n == n0), t
+                log.append((dec, 0.5 * (s0 / c0 + s1 / c1) if c0 > 0 and c1 > 0 else float("nan")))
+        return slam, log
+    finally:
+        dpvo_mod._FRAME_CALL = fc_before
+
+
+def test_unforced_keyframe_decision_on_the_device(dev):
+    """the data-driven branch of track.hip:kf_decide (forced < 0: flow sums -> means -> threshold, dpvo.py:266-272) with a
+    threshold INSIDE the range of the measured flows, so that it both drops and keeps -- against the Python-paced path that takes
+    the same decision on the host from the same flow kernel.  Same decisions, same state, bit for bit; and the decision equals the
+    reference's rule applied to the recorded flow."""
+    _, probe = _run_unforced(dev, -1.0, frame_call=False)
+    flows = np.array([f for _, f in probe])
+    assert np.isfinite(flows).all() and not any(d for d, _ in probe)
+    thr = float(np.median(flows))
+    a, la = _run_unforced(dev, thr, frame_call=True, defer_keyframe=True, overlap_encoders=True)
+    b, lb = _run_unforced(dev, thr, frame_call=False)
+    torch.cuda.synchronize()
+    da, db = [d for d, _ in la], [d for d, _ in lb]
+    print(f"unforced keyframe test: threshold {thr:.4f}, device path dropped {sum(da)}/{len(da)}, host path {sum(db)}/{len(db)}")
+    assert 3 <= sum(da) <= len(da) - 3, "the threshold must exercise both branches"
+    assert da == db
+    for (d, f) in la:
+        assert bool(d) == (f < thr), (d, f, thr)                              # dpvo.py:272: m / 2 < KEYFRAME_THRESH
+    assert a.n == b.n and a.m == b.m
+    for k in ("ii", "jj", "kk", "ii_inac", "jj_inac", "kk_inac", "net", "target", "weight"):
+        assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)), k
+    assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
+
+
+def test_keyframe_step_decision_unit(dev):
+    """dpvo_keyframe_step's decision from synthetic flow sums, incl. the empty-direction case: mean of an empty tensor is NaN in the
+    reference (dpvo.py:264) and `NaN / 2 < thresh` is False -> keep"""
+    a, _ = _run_unforced(dev, 1.0, n_frames=16, frame_call=True)
+    fu = a._frame_update_buffers()
+    import ctypes
+    from dpvo_amd import _lib as L
+    for (s0, c0, s1, c1), expect in (((4.0, 8.0, 4.0, 8.0), 1),       # means 0.5 + 0.5 -> m/2 = 0.5 < 1 -> drop
+                                     ((40.0, 8.0, 4.0, 8.0), 0),      # 5 + 0.5 -> 2.75 -> keep
+                                     ((8.0, 8.0, 8.0, 8.0), 0),       # exactly the threshold: strict '<' -> keep
+                                     ((0.0, 0.0, 1.0, 8.0), 0),       # no edge i -> j: NaN -> keep
+                                     ((1.0, 8.0, 0.0, 0.0), 0)):
+        es = a.pg.edges
+        par = 0 if es.a is fu["sets"][0] else 1
+        args = fu["args"][par]
+        kf = L.KeyframeStep.from_buffer_copy(args.kf)
+        flow = torch.tensor([s0, c0, s1, c1, 0, 0, 0, 0] + [0.0] * 8, dtype=torch.float32, device=dev)
+        res = torch.zeros(16 + 2 * (es.cap // 1024 + 2), dtype=torch.float32, device=dev)
+        res[:16] = flow
+        kf.flow4, kf.result, kf.result_host, kf.host_words = res.data_ptr(), res.data_ptr() + 32, None, 8
+        kf.poses = a.pg.poses_.data_ptr()
+        kf.E, kf.n, kf.forced, kf.n_ring = 0, a.n, -1, 0               # decision only: no edges to move, no rings to shift
+        kf.inac_room = 0
+        L.check(L.lib().dpvo_keyframe_step(ctypes.byref(kf), L.stream()), "dpvo_keyframe_step")
+        torch.cuda.synchronize()
+        assert int(res.view(torch.int32)[8].item()) == expect, ((s0, c0, s1, c1), expect)
+
+
 def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
     """remove_factors with the compaction of `net` folded into the update operator's first kernel (EdgeStore.keep(defer_net=True),
     dpvo_update_forward_fused_rows) against compacting at once: same tracker state bit for bit, over kept and dropped keyframes
