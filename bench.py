@@ -200,18 +200,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     n_dev = torch.cuda.device_count()
-    backend = "nccl" if n_dev >= world else "gloo"        # fewer devices than ranks: ranks share them (smoke mode, see docstring)
+    from dpvo_amd import multiseq
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    # one device per rank over RCCL when the node has them, shared devices over gloo otherwise (smoke mode, see docstring); every rank
+    # pinned to its own slice of the host cores
+    backend, dev_index, cpus = multiseq.place_rank(local_rank, world, n_dev, allowed=allowed)
+    pinned = multiseq.pin_rank(cpus) if world > 1 and not os.environ.get("DPVO_BENCH_NO_PIN") else None
     dist = None
-    device = torch.device("cuda", local_rank % max(n_dev, 1))
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
+        dist = multiseq.init_distributed(backend, device)          # (raises if RCCL cannot be brought up: never a silent gloo run)
 
     os.environ.setdefault("DPVO_PROFILE_EVENTS", "1")      # the tracker creates its pool of timing events up front (warm-up), not in the timed region
     from dpvo_amd import altcorr
@@ -260,7 +259,6 @@ def main():
         if _SYNC_EVERY_FRAME:
             torch.cuda.synchronize(device)
 
-    from dpvo_amd import multiseq
     clock = multiseq.Clock(dist=dist, device=device)       # barrier + device sync on both sides of the timed region
     with torch.no_grad():
         for t in range(preroll + args.warmup):
@@ -352,6 +350,8 @@ def main():
             "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg,
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
                          for i, r in enumerate(res["per_rank"])],
+            "placement": {"backend": backend if world > 1 else None, "devices_visible": n_dev, "host_cores_allowed": len(allowed) if allowed else None,
+                          "rank0_pinned_to": pinned, "cores_per_rank": len(cpus)},
         }
         # the tracker state after the run: with random weights nothing guarantees that it stays sane, and a diverged state
         # (NaN poses, every edge projecting out of bounds) would make the correlation kernel skip its work

@@ -337,20 +337,12 @@ extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, co
   if (N1 <= 0 || N2 <= 0 || N1 > 0x7fffffff || N2 > 0x7fffffff) return DPVO_E_INVALID;
   // with an order hint the grid is padded to 8 slices of ceil(E/8) so that the XCD remap is a bijection onto [0,E)
   const int64_t grid = order ? ((E + 7) >> 3) << 3 : E;
-  static int occ = 0;
-  if (occ == 0) { const char* e = getenv("DPVO_CORR_OCC"); occ = e ? atoi(e) : 3; if (occ < 2 || occ > 5) occ = 3; }
-  if (occ == 2) { hipLaunchKernelGGL(corr_pyramid_kernel<2>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+  // three waves per SIMD (launch bound of the kernel): 2 / 3 measure the same, 4 and 5 are slower (263 -> 275 -> 332 us, round 2).
+  // Rounds 1-3 read DPVO_CORR_OCC from the environment once per process into a static; a library entry has no business doing
+  // either: one instantiation, no state.
+  hipLaunchKernelGGL(corr_pyramid_kernel<3>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
                      (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
-  else if (occ == 3) { hipLaunchKernelGGL(corr_pyramid_kernel<3>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
-                     (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
-  else if (occ == 4) { hipLaunchKernelGGL(corr_pyramid_kernel<4>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
-                     (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
-  else { hipLaunchKernelGGL(corr_pyramid_kernel<5>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
-                     (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2); }
+                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

@@ -50,8 +50,10 @@ _FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
 # DPVO_ENC_LEAD_US before the expected end of the update operator (= the running mean of the frame's duration minus DPVO_ENC_TAIL_US,
 # the BA / keyframe tail), so that the wait is pending for ~0.1 ms only.
 _ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '1')))
-_ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '-1'))     # -1: the whole side-stream batch (random draws, image
-#   normalisation, encoders) waits; k >= 0: only the encoder launches from number k on
+_ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '0'))      # -1: the whole side-stream batch (random draws, image
+#   normalisation, encoders) waits; k >= 0: only the encoder launches from number k on.  Round 4: 0 -- the three random draws and the
+#   image normalisation (~18 us of tiny kernels) run at once, only the convolutions are held: +0.5-2 % frames/sec and 50-90 us less
+#   host CPU per frame than -1 on one box (A/B/A/B, profiles/README.md r4), because the wait is issued inside the encoder call
 _ENC_TAIL_US = float(__import__('os').environ.get('DPVO_ENC_TAIL_US', '200'))
 _ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '120'))
 _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))

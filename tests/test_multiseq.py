@@ -81,3 +81,43 @@ def test_bench_self_spawns_two_real_trackers():
     secs = [r["seconds"] for r in rec["per_rank"]]
     assert abs(rec["value"] - 2 * 12 / max(secs)) / rec["value"] < 1e-2, rec     # whole-job frames/sec = N*K / max over ranks
     assert all(r["host_cpu_us_per_frame"] > 0 for r in rec["per_rank"]), rec
+
+
+def test_rank_placement_logic():
+    """bench.py's device / backend / host-core selection (multiseq.place_rank) for the shapes of node it can meet, with a faked device
+    count: 8 ranks on 8 devices over RCCL with disjoint core slices; more ranks than devices -> shared devices over gloo; a small host
+    (fewer cores than ranks) still gives every rank a core; nonsense raises."""
+    import pytest
+    got = [multiseq.place_rank(r, 8, 8, n_cpu=64) for r in range(8)]
+    assert [g[0] for g in got] == ["nccl"] * 8 and [g[1] for g in got] == list(range(8))
+    cores = [set(g[2]) for g in got]
+    assert all(len(c) == 8 for c in cores) and len(set().union(*cores)) == 64            # disjoint slices that cover the host
+    assert multiseq.place_rank(3, 8, 8, allowed=[2, 3, 5, 7, 11, 13, 17, 19])[2] == [7]   # an affinity mask handed down by a launcher
+    got = [multiseq.place_rank(r, 4, 1, n_cpu=8) for r in range(4)]
+    assert [g[0] for g in got] == ["gloo"] * 4 and [g[1] for g in got] == [0] * 4
+    got = [multiseq.place_rank(r, 8, 2, n_cpu=4) for r in range(8)]
+    assert [g[1] for g in got] == [0, 1] * 4 and all(len(g[2]) == 1 for g in got)         # 8 ranks on 4 cores: one each, wrapping
+    assert multiseq.place_rank(0, 1, 8)[0] == "nccl" and multiseq.place_rank(0, 2, 2)[1] == 0
+    with pytest.raises(RuntimeError):
+        multiseq.place_rank(0, 2, 0)
+    with pytest.raises(ValueError):
+        multiseq.place_rank(2, 2, 2)
+
+
+def _nccl_must_fail_loudly(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        multiseq.init_distributed("nccl", torch.device("cpu"))          # no GPU here: RCCL cannot come up
+        q.put("initialised")
+    except RuntimeError as e:
+        q.put(str(e))
+
+
+def test_nccl_init_failure_is_loud_not_a_gloo_fallback():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_must_fail_loudly, args=(0, 1, _free_port(), q))
+    p.start()
+    msg = q.get(timeout=120)
+    p.join(60)
+    assert "could not be initialised" in msg and "Not falling back to gloo" in msg, msg
