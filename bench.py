@@ -170,6 +170,38 @@ def ref_baseline(device, ht, wd, cfg, frames, intr, seed, warm=53, timed=20):
         return {"frames_per_sec": None, "error": repr(e)[:300]}
 
 
+def loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed, warm=70, timed=45):
+    """BASELINE config 5 (LOOP_CLOSURE=True) on the bench stream: see the call site"""
+    from dpvo_amd.dpvo import DPVO
+    from dpvo_amd.net import VONet
+    try:
+        c = cfg.clone()
+        c.LOOP_CLOSURE = True
+        c.BUFFER_SIZE = max(c.BUFFER_SIZE, warm + timed + 80)
+        torch.manual_seed(seed)
+        slam = DPVO(c, VONet(), ht=ht, wd=wd, device=device, defer_keyframe=True, overlap_encoders=True)
+        slam.motion_probe = lambda: 1.0e9
+        with torch.no_grad():
+            for t in range(warm):
+                slam(float(t), frames[t % n_img], intr, image_ready=False)
+            slam.flush(); torch.cuda.synchronize(device)
+            gb0, fast = int(slam.ran_global_ba.sum()), 0
+            t0 = time.perf_counter()
+            for t in range(warm, warm + timed):
+                pend = slam._fu_pending
+                slam(float(t), frames[t % n_img], intr, image_ready=False)
+                fast += int(slam._fu_pending is not None and slam._fu_pending is not pend)
+            slam.flush(); torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+        gb = int(slam.ran_global_ba.sum()) - gb0
+        return {"frames": timed, "frames_per_sec": round(timed / dt, 1), "ms_per_frame": round(1e3 * dt / timed, 3),
+                "frames_on_the_one_call_path": fast, "global_ba_runs": gb, "keyframes": int(slam.n),
+                "active_edges": int(slam.pg.ii.numel()), "inactive_edges": int(slam.pg.ii_inac.numel()),
+                "finite": bool(torch.isfinite(slam.pg.poses_[:slam.n]).all().item())}
+    except Exception as e:          # noqa: BLE001  (a side leg must never take the headline measurement down)
+        return {"frames_per_sec": None, "error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +329,13 @@ def main():
                     "ms_per_frame": round(1e3 * dt / n_timed, 4), "keyframes_dropped": n_timed - (slam.n - n0),
                     "edges_after": int(slam.pg.ii.numel())}
         slam.keyframe_override = None
+    # third leg (N = 1, default run only): BASELINE config 5 -- a second tracker with LOOP_CLOSURE=True on the same stream from its first
+    # frame: PatchGraph.edges_loop is evaluated whenever it is due, loop edges go in, update() runs the global BA (active + inactive
+    # edges, device Cholesky) while long-range edges are active, and every other frame takes the one-call path.  Reported beside the
+    # headline: frames/sec over the timed frames, how many of them ran a global BA / the one-call path, and the size of the last one.
+    lc_leg = None
+    if world == 1 and args.drop_every == 0 and args.config == "default" and not os.environ.get("DPVO_BENCH_NO_LC_LEG"):
+        lc_leg = loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed=1234 + seed_off)
     res = multiseq.gather_results(args.steps, local, extra=1e6 * (cpu1 - cpu0) / args.steps, dist=dist,
                                   device=device if backend == "nccl" else "cpu")
     elapsed = res["seconds"]                          # max over ranks
@@ -347,7 +386,7 @@ def main():
                                    f"steady state E={E_now} edges, random-init weights, one sequence per GPU",
                        "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "drop_every": args.drop_every, "parallelism": f"replicas x{world}" + ("" if backend == "nccl" or world == 1 else
                                                                 f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
-            "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg,
+            "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg, "with_loop_closure": lc_leg,
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
                          for i, r in enumerate(res["per_rank"])],
             "placement": {"backend": backend if world > 1 else None, "devices_visible": n_dev, "host_cores_allowed": len(allowed) if allowed else None,

@@ -9,12 +9,17 @@
 // (i,j) (patch slot = kk % M) plus one "self" block per source frame (the -w Jz Ji side, summed over all edges of the
 // patch).  Everything is indexed by the device-built graph plan (pairs sorted by (i,j), so the pairs of one source
 // frame are a contiguous run) -- no host tables.
-//   gba_scatter_kernel   edge records -> Ecol[pair][slot][6]                 (plain stores; atomics only fold duplicates)
+//   gba_scatter_kernel   edge records -> Ecol[pair][slot][6]: a block per pair, a thread per patch slot sums that slot's
+//                        edges in list order (duplicates of a (patch, frame) edge fold in a fixed order)
 //   gba_patch_kernel     per patch (CSR): C, u, Ei -> Q, u, Eself[frame][slot][6]
-//   gba_assemble_kernel  per pair: B blocks and v into the dense S / y       (float atomics, like the reference)
-//   gba_schur_kernel     per (source frame, block a, block b): S -= sum_slot Q ea eb^T, y -= sum_slot Q u ea; the sum
-//                        over the frame's M patch slots is reduced IN the wave, then 36 atomics per block pair
-//                        (the reference issues 36 atomics per block pair PER PATCH)
+//   gba_index_kernel     pairs by TARGET pose (tgt_off / tgt_list, ascending pair index) and the pair run of every source frame
+//   gba_row_kernel       one workgroup per free pose p builds block row p of S = B - E Q E^T and y[p] = v - E Q u: the B / v
+//                        terms of the pairs that touch p, then, for every source frame that sees p (ascending), the Schur
+//                        terms  sum_slot Q ea eb^T  against all of that frame's blocks.  Every entry of the row is updated by
+//                        ONE wave (column pose mod 4) in program order: no atomics, fixed summation order (the mirror blocks
+//                        (p,q) / (q,p) are formed from the same commutative products in the same order), so the whole call
+//                        is BIT-REPEATABLE (rounds 1-3 accumulated S with float
+//                        atomics like the reference, ba_cuda.cu:335-373 / block_e.cu:147-283: repeatable to rounding only)
 //   dpvo_gba_solve       S += I*(1e-4*S+1); blocked Cholesky + both substitutions on the device (chol.hip)
 //   gba_retr_kernel      dZ = Q (u - e^T dX), depth + pose retraction
 #include "ba_common.h"
@@ -23,14 +28,19 @@ namespace {
 using namespace ba;
 
 struct GbaWs {
-  size_t pairbuf, edgebuf, Q, u, Ecol, Eself, total;
+  size_t pairbuf, edgebuf, run_lo, tgt_off, tgt_cnt, tgt_list, Q, u, Ecol, Eself, total;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-inline void gba_layout(int64_t E, int64_t n_pairs, int64_t n_frames, int M, GbaWs* L) {
+inline void gba_layout(int64_t E, int64_t n_pairs, int64_t n_frames, int M, int64_t n_free, GbaWs* L) {
   const size_t n = (size_t)(E > 0 ? E : 1), g = (size_t)(n_pairs > 0 ? n_pairs : 1), f = (size_t)(n_frames > 0 ? n_frames : 1);
   size_t o = 0;
   L->pairbuf = o; o += al(g * kPairStride * 4);
   L->edgebuf = o; o += al(n * kEdgeStride * 4);
+  const size_t nf = (size_t)(n_free > 0 ? n_free : 1);
+  L->run_lo = o; o += al((f + 2) * 4);
+  L->tgt_off = o; o += al((nf + 2) * 4);
+  L->tgt_cnt = o; o += al((nf + 2) * 4);
+  L->tgt_list = o; o += al(g * 4);
   L->Q = o; o += al(f * M * 4);
   L->u = o; o += al(f * M * 4);
   L->Ecol = o; o += al(g * M * 6 * 4);
@@ -38,15 +48,38 @@ inline void gba_layout(int64_t E, int64_t n_pairs, int64_t n_frames, int M, GbaW
   L->total = o;
 }
 
-// Ecol[pu[e]][kk[e] % M][0..5] += Ej_e
-__global__ void gba_scatter_kernel(const int64_t* __restrict__ kk, const int32_t* __restrict__ pu,
-                                   const float* __restrict__ edgebuf, float* __restrict__ Ecol, int64_t E, int M) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
-    const int slot = (int)(kk[e] % M);
-    float* dst = Ecol + ((int64_t)pu[e] * M + slot) * 6;
-    const float* eb = edgebuf + e * kEdgeStride + 8;
+// Ecol[pair][kk[e] % M][0..5] = sum over the pair's edges e with that slot of Ej_e, in list order (perm_p is the stable sort by
+// (ii, jj): ascending edge number inside a pair).  One block per pair; the slots of a chunk of 128 edges go through LDS.
+__global__ __launch_bounds__(128) void gba_scatter_kernel(const int64_t* __restrict__ kk, const int32_t* __restrict__ perm_p,
+                                                          const int32_t* __restrict__ pair_off, const int32_t* __restrict__ n_pairs,
+                                                          const float* __restrict__ edgebuf, float* __restrict__ Ecol, int M) {
+  __shared__ int sl[128];
+  __shared__ int se[128];
+  const int ng = *n_pairs, t = threadIdx.x;
+  for (int g = blockIdx.x; g < ng; g += gridDim.x) {
+    const int p0 = pair_off[g], p1 = pair_off[g + 1];
+    for (int s0 = 0; s0 < M; s0 += 128) {
+      const int slot = s0 + t;
+      float acc[6] = {0, 0, 0, 0, 0, 0};
+      for (int c0 = p0; c0 < p1; c0 += 128) {
+        __syncthreads();
+        if (c0 + t < p1) { const int e = perm_p[c0 + t]; se[t] = e; sl[t] = (int)(kk[e] % M); } else sl[t] = -1;
+        __syncthreads();
+        const int nq = p1 - c0 < 128 ? p1 - c0 : 128;
+        if (slot < M)
+          for (int q = 0; q < nq; ++q)
+            if (sl[q] == slot) {
+              const float* eb = edgebuf + (int64_t)se[q] * kEdgeStride + 8;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) atomicAdd(dst + a, eb[a]);
+              for (int a = 0; a < 6; ++a) acc[a] += eb[a];
+            }
+      }
+      if (slot < M) {
+        float* dst = Ecol + ((int64_t)g * M + slot) * 6;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) dst[a] = acc[a];
+      }
+    }
   }
 }
 
@@ -75,97 +108,151 @@ __global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32
   }
 }
 
-// B and v from the pair Gram blocks (ba_cuda.cu:335-349,363-368); one wave per pair, lanes over the 36 entries
-__global__ __launch_bounds__(64) void gba_assemble_kernel(const int32_t* __restrict__ pair_ij,
-                                                          const int32_t* __restrict__ n_pairs,
-                                                          const float* __restrict__ pairbuf, int t0, int N,
-                                                          float* __restrict__ S, float* __restrict__ y) {
-  const int ng = *n_pairs;
-  const int lane = threadIdx.x;
-  const int64_t n6 = 6 * (int64_t)N;
-  for (int g = blockIdx.x; g < ng; g += gridDim.x) {
-    const int ix = pair_ij[2 * g] - t0, jx = pair_ij[2 * g + 1] - t0;
-    const bool fi = ix >= 0 && ix < N, fj = jx >= 0 && jx < N;
-    const float* pb = pairbuf + (int64_t)g * kPairStride;
-    if (lane < 36) {
-      const int a = lane / 6, b = lane - 6 * a;
-      if (fi) atomicAdd(&S[(6 * ix + a) * n6 + 6 * ix + b], pb[a * 16 + b]);
-      if (fj) atomicAdd(&S[(6 * jx + a) * n6 + 6 * jx + b], pb[(6 + a) * 16 + 6 + b]);
-      if (fi && fj) {
-        atomicAdd(&S[(6 * ix + a) * n6 + 6 * jx + b], -pb[a * 16 + 6 + b]);
-        atomicAdd(&S[(6 * jx + b) * n6 + 6 * ix + a], -pb[a * 16 + 6 + b]);
-      }
-    } else if (lane < 42) {
-      const int a = lane - 36;
-      if (fi) atomicAdd(&y[6 * ix + a], -pb[a * 16 + 12]);
-      if (fj) atomicAdd(&y[6 * jx + a], pb[(6 + a) * 16 + 12]);
-    }
-  }
-}
-
 __device__ __forceinline__ int lower_bound_i(const int32_t* pair_ij, int ng, int f) {
   int lo = 0, hi = ng;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (pair_ij[2 * mid] < f) lo = mid + 1; else hi = mid; }
   return lo;
 }
 
-// Schur complement.  grid.x = source frame (f0 + blockIdx.x), grid.y strides over block a; 4 waves stride over block b.
-// Block index b in [0, P]: b < P -> pair ga+b (pose slot = j of that pair), b == P -> the self block (pose slot = i).
-__global__ __launch_bounds__(256) void gba_schur_kernel(const int32_t* __restrict__ pair_ij,
-                                                        const int32_t* __restrict__ n_pairs,
-                                                        const float* __restrict__ Q, const float* __restrict__ U,
-                                                        const float* __restrict__ Ecol, const float* __restrict__ Eself,
-                                                        int M, int f0, int t0, int N, float* __restrict__ S,
-                                                        float* __restrict__ y) {
-  const int ng = *n_pairs;
-  const int fr = blockIdx.x, f = f0 + fr;
-  const int ga = lower_bound_i(pair_ij, ng, f), gb = lower_bound_i(pair_ij, ng, f + 1);
-  const int P = gb - ga;
-  if (P == 0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Index structures of the row kernel, one workgroup: run_lo[fr] = first pair of source frame f0 + fr (fr = 0 .. n_frames);
+// tgt_off / tgt_list = the pairs whose TARGET is free pose p, ascending pair index (= ascending source frame).
+__global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
+                                                         int f0, int n_frames, int t0, int N, int32_t* __restrict__ run_lo,
+                                                         int32_t* __restrict__ tgt_off, int32_t* __restrict__ tgt_cnt,
+                                                         int32_t* __restrict__ tgt_list) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int ng = *n_pairs, t = threadIdx.x;
+  for (int fr = t; fr <= n_frames; fr += 1024) run_lo[fr] = lower_bound_i(pair_ij, ng, f0 + fr);
+  for (int p = t; p < N; p += 1024) tgt_cnt[p] = 0;
+  __syncthreads();
+  for (int g = t; g < ng; g += 1024) {
+    const int jx = pair_ij[2 * g + 1] - t0;
+    if (jx >= 0 && jx < N) atomicAdd(&tgt_cnt[jx], 1);            // (integer counts: order-independent)
+  }
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {                     // exclusive scan, 1024 poses at a time
+    const int v = base + t < N ? tgt_cnt[base + t] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int x = t >= o ? part[t - o] : 0;
+      __syncthreads();
+      part[t] += x;
+      __syncthreads();
+    }
+    if (base + t < N) tgt_off[base + t] = carry + part[t] - v;
+    __syncthreads();
+    if (t == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (t == 0) tgt_off[N] = carry;
+  for (int p = t; p < N; p += 1024) tgt_cnt[p] = 0;
+  __syncthreads();
+  for (int g = t; g < ng; g += 1024) {
+    const int jx = pair_ij[2 * g + 1] - t0;
+    if (jx >= 0 && jx < N) tgt_list[tgt_off[jx] + atomicAdd(&tgt_cnt[jx], 1)] = g;
+  }
+  __syncthreads();
+  for (int p = t; p < N; p += 1024) {                              // (the claims above land in any order: sort every short list)
+    int32_t* L = tgt_list + tgt_off[p];
+    const int n = tgt_off[p + 1] - tgt_off[p];
+    for (int a = 1; a < n; ++a) {
+      const int v = L[a];
+      int b = a - 1;
+      while (b >= 0 && L[b] > v) { L[b + 1] = L[b]; --b; }
+      L[b + 1] = v;
+    }
+  }
+}
+
+// Block row p of S and y[p] (see the file header).  256 threads = 4 waves; wave w owns the column blocks whose pose q has
+// q % 4 == w, wave 0 also y.  `S` and `y` must be zero on entry.
+__global__ __launch_bounds__(256) void gba_row_kernel(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
+                                                      const int32_t* __restrict__ run_lo, const int32_t* __restrict__ tgt_off,
+                                                      const int32_t* __restrict__ tgt_list, const float* __restrict__ pairbuf,
+                                                      const float* __restrict__ Q, const float* __restrict__ U,
+                                                      const float* __restrict__ Ecol, const float* __restrict__ Eself, int M,
+                                                      int f0, int n_frames, int t0, int N, float* __restrict__ S,
+                                                      float* __restrict__ y) {
+  const int p = blockIdx.x, j = p + t0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n6 = 6 * (int64_t)N;
-  const float* Qf = Q + (int64_t)fr * M;
-  const float* Uf = U + (int64_t)fr * M;
-  auto blk_ptr = [&](int b) { return b < P ? Ecol + (int64_t)(ga + b) * M * 6 : Eself + (int64_t)fr * M * 6; };
-  auto blk_pose = [&](int b) { return (b < P ? pair_ij[2 * (ga + b) + 1] : f) - t0; };
-  for (int a = blockIdx.y; a <= P; a += gridDim.y) {
-    const int pa = blk_pose(a);
-    if (pa < 0 || pa >= N) continue;
-    const float* Ea = blk_ptr(a);
-    for (int b = a + wave; b <= P + 1; b += 4) {
-      // b == P + 1: the right-hand side  y[pa] -= sum_slot Q u ea
-      float acc[36];
+  const int r36 = lane / 6, c36 = lane - 6 * r36;                  // (lanes 0..35: entry (r36, c36) of a 6 x 6 block)
+  float* Srow = S + (int64_t)(6 * p) * n6;
+  const int tl0 = tgt_off[p], tl1 = tgt_off[p + 1];
+  const int frj = j - f0;                                          // pose p as a SOURCE frame (it owns patches iff 0 <= frj < n_frames)
+  const bool own = frj >= 0 && frj < n_frames;
+  const int ja = own ? run_lo[frj] : 0, jb = own ? run_lo[frj + 1] : 0;
+  // ---- B and v (ba_cuda.cu:335-349,363-368): pairs with source j, then pairs with target j, ascending pair index each
+  for (int g = ja; g < jb; ++g) {
+    const float* pb = pairbuf + (int64_t)g * kPairStride;
+    const int jx = pair_ij[2 * g + 1] - t0;
+    if (wave == (p & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[r36 * 16 + c36];
+    if (jx >= 0 && jx < N && wave == (jx & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * jx + c36] -= pb[r36 * 16 + 6 + c36];
+    if (wave == 0 && lane < 6) y[6 * p + lane] -= pb[lane * 16 + 12];
+  }
+  for (int q = tl0; q < tl1; ++q) {
+    const int g = tgt_list[q];
+    const float* pb = pairbuf + (int64_t)g * kPairStride;
+    const int ix = pair_ij[2 * g] - t0;
+    if (wave == (p & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[(6 + r36) * 16 + 6 + c36];
+    if (ix >= 0 && ix < N && wave == (ix & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * ix + c36] -= pb[c36 * 16 + 6 + r36];   // mirror of block (ix, p)
+    if (wave == 0 && lane < 6) y[6 * p + lane] += pb[(6 + lane) * 16 + 12];
+  }
+  // ---- Schur terms: every source frame f that has a block with pose p -- the sources of the target list, and j itself (its
+  //      self block; a pair (j, j) of self edges is in the target list too) -- in ascending f
+  int q = tl0;
+  bool self_done = !own;
+  while (q < tl1 || !self_done) {
+    int f, ga_;                                                    // the next frame and, if it comes from the list, its pair
+    const int gq = q < tl1 ? tgt_list[q] : -1;
+    const int fq = gq >= 0 ? pair_ij[2 * gq] : 0x7fffffff;
+    if (!self_done && j <= fq) { f = j; ga_ = (fq == j) ? gq : -1; self_done = true; if (fq == j) ++q; }
+    else { f = fq; ga_ = gq; ++q; }
+    const int fr = f - f0;
+    if (fr < 0 || fr >= n_frames) continue;
+    const int g0 = run_lo[fr], g1 = run_lo[fr + 1], P = g1 - g0;
+    const float* Qf = Q + (int64_t)fr * M;
+    const float* Uf = U + (int64_t)fr * M;
+    // the (at most two) blocks of f whose pose is p: its pair (f, j) if any, and the self block when f == j
+    for (int which = 0; which < 2; ++which) {
+      const float* Ea;
+      if (which == 0) { if (ga_ < 0) continue; Ea = Ecol + (int64_t)ga_ * M * 6; }
+      else { if (f != j) continue; Ea = Eself + (int64_t)fr * M * 6; }
+      for (int b = 0; b <= P; ++b) {
+        const int pb_ = (b < P ? pair_ij[2 * (g0 + b) + 1] : f) - t0;
+        if (pb_ < 0 || pb_ >= N || (pb_ & 3) != wave) continue;
+        const float* Eb = b < P ? Ecol + (int64_t)(g0 + b) * M * 6 : Eself + (int64_t)fr * M * 6;
+        float acc[36];
 #pragma unroll
-      for (int q = 0; q < 36; ++q) acc[q] = 0.f;
-      if (b <= P) {
-        const int pb_ = blk_pose(b);
-        if (pb_ < 0 || pb_ >= N) continue;
-        const float* Eb = blk_ptr(b);
-        for (int s = lane; s < M; s += 64) {
-          const float q = Qf[s];
+        for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+        for (int s_ = lane; s_ < M; s_ += 64) {
+          const float qv = Qf[s_];
           float ea[6], eb[6];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) { ea[r] = Ea[s * 6 + r]; eb[r] = Eb[s * 6 + r]; }
+          for (int r = 0; r < 6; ++r) { ea[r] = Ea[s_ * 6 + r]; eb[r] = Eb[s_ * 6 + r]; }
 #pragma unroll
           for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += q * ea[r] * eb[c];
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += qv * (ea[r] * eb[c]);      // (commutative inner product: S stays symmetric)
         }
 #pragma unroll
-        for (int q = 0; q < 36; ++q) acc[q] = wave_sum(acc[q]);
+        for (int k = 0; k < 36; ++k) acc[k] = wave_sum(acc[k]);
         if (lane < 36) {
-          const int r = lane / 6, c = lane - 6 * r;
           float v = 0.f;
 #pragma unroll
-          for (int q = 0; q < 36; ++q) v = (q == lane) ? acc[q] : v;
-          atomicAdd(&S[(6 * pa + r) * n6 + 6 * pb_ + c], -v);
-          if (b != a) atomicAdd(&S[(6 * pb_ + c) * n6 + 6 * pa + r], -v);
+          for (int k = 0; k < 36; ++k) v = (k == lane) ? acc[k] : v;
+          Srow[(int64_t)r36 * n6 + 6 * pb_ + c36] -= v;
         }
-      } else {
-        for (int s = lane; s < M; s += 64) {
-          const float qu = Qf[s] * Uf[s];
+      }
+      if (wave == 0) {                                             // right-hand side: y[p] -= sum_slot Q u ea
+        float acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int s_ = lane; s_ < M; s_ += 64) {
+          const float qu = Qf[s_] * Uf[s_];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) acc[r] += qu * Ea[s * 6 + r];
+          for (int r = 0; r < 6; ++r) acc[r] += qu * Ea[s_ * 6 + r];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
@@ -173,7 +260,7 @@ __global__ __launch_bounds__(256) void gba_schur_kernel(const int32_t* __restric
           float v = 0.f;
 #pragma unroll
           for (int r = 0; r < 6; ++r) v = (r == lane) ? acc[r] : v;
-          atomicAdd(&y[6 * pa + lane], -v);
+          y[6 * p + lane] -= v;
         }
       }
     }
@@ -230,10 +317,10 @@ __global__ __launch_bounds__(128) void gba_retr_kernel(float* __restrict__ poses
 
 }  // namespace
 
-extern "C" size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n_frames, int M) {
-  if (E < 0 || n_pairs < 0 || n_frames < 0 || M <= 0) return 0;
+extern "C" size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n_frames, int M, int64_t n_free) {
+  if (E < 0 || n_pairs < 0 || n_frames < 0 || M <= 0 || n_free < 0) return 0;
   GbaWs L;
-  gba_layout(E, n_pairs, n_frames, M, &L);
+  gba_layout(E, n_pairs, n_frames, M, n_free, &L);
   return L.total;
 }
 
@@ -247,7 +334,7 @@ extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, cons
   if (E <= 0 || P <= 0 || M <= 0 || t1 <= t0 || n_frames <= 0 || n_pairs_h <= 0 || n_patches_h <= 0) return DPVO_E_INVALID;
   if (!poses || !patches || !intrinsics || !target || !weight || !ii || !jj || !kk || !plan || !S || !y || !ws) return DPVO_E_INVALID;
   GbaWs L;
-  gba_layout(E, n_pairs_h, n_frames, M, &L);
+  gba_layout(E, n_pairs_h, n_frames, M, t1 - t0, &L);
   if (ws_bytes < L.total) return DPVO_E_WORKSPACE;
   dpvo_plan_layout_t PL;
   dpvo_plan_layout(E, &PL);
@@ -264,17 +351,21 @@ extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, cons
   const int32_t* n_pairs = plan + PL.counts + 1;
   hipError_t e = hipMemsetAsync(w + L.Q, 0, L.total - L.Q, st);     // Q, u, Ecol, Eself
   if (e != hipSuccess) return (int)e;
+  int32_t* run_lo = (int32_t*)(w + L.run_lo);
+  int32_t* tgt_off = (int32_t*)(w + L.tgt_off);
+  int32_t* tgt_cnt = (int32_t*)(w + L.tgt_cnt);
+  int32_t* tgt_list = (int32_t*)(w + L.tgt_list);
   const unsigned pair_grid = (unsigned)(n_pairs_h < 65535 ? n_pairs_h : 65535);
   hipLaunchKernelGGL(ba_pair_kernel, dim3(pair_grid), dim3(128), 0, st, poses, patches, intrinsics, target, weight, kk,
                      plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, n_pairs, pairbuf, edgebuf, P);
-  hipLaunchKernelGGL(gba_scatter_kernel, dim3((unsigned)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096)), dim3(256), 0,
-                     st, kk, plan + PL.pu, edgebuf, Ecol, E, M);
+  hipLaunchKernelGGL(gba_index_kernel, dim3(1), dim3(1024), 0, st, plan + PL.pair_ij, n_pairs, f0, n_frames, t0, N, run_lo,
+                     tgt_off, tgt_cnt, tgt_list);
+  hipLaunchKernelGGL(gba_scatter_kernel, dim3(pair_grid), dim3(128), 0, st, kk, plan + PL.perm_p, plan + PL.pair_off, n_pairs,
+                     edgebuf, Ecol, M);
   hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
                      plan + PL.patch_off, plan + PL.kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself);
-  hipLaunchKernelGGL(gba_assemble_kernel, dim3(pair_grid), dim3(64), 0, st, plan + PL.pair_ij, n_pairs, pairbuf, t0, N,
-                     S, y);
-  hipLaunchKernelGGL(gba_schur_kernel, dim3((unsigned)n_frames, 8), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, Q, U,
-                     Ecol, Eself, M, f0, t0, N, S, y);
+  hipLaunchKernelGGL(gba_row_kernel, dim3((unsigned)N), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
+                     pairbuf, Q, U, Ecol, Eself, M, f0, n_frames, t0, N, S, y);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
@@ -285,7 +376,7 @@ extern "C" int dpvo_gba_retract(float* poses, float* patches, const int32_t* pla
   if (E <= 0 || P <= 0 || M <= 0 || t1 <= t0 || n_frames <= 0 || n_pairs_h <= 0 || n_patches_h <= 0) return DPVO_E_INVALID;
   if (!poses || !patches || !plan || !dX || !ws) return DPVO_E_INVALID;
   GbaWs L;
-  gba_layout(E, n_pairs_h, n_frames, M, &L);
+  gba_layout(E, n_pairs_h, n_frames, M, t1 - t0, &L);
   if (ws_bytes < L.total) return DPVO_E_WORKSPACE;
   dpvo_plan_layout_t PL;
   dpvo_plan_layout(E, &PL);

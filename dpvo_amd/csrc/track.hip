@@ -21,7 +21,7 @@
 
 namespace {
 
-enum { RES_DECISION = 0, RES_KEEP = 1, RES_REM = 2, RES_E = 3, RES_OVERFLOW = 4 };
+enum { RES_DECISION = 0, RES_KEEP = 1, RES_REM = 2, RES_E = 3, RES_OVERFLOW = 4, RES_LONG_RANGE = 5 };
 
 struct Renum { int drop; int k; int M; };
 __device__ __forceinline__ void renumber(const Renum& R, int64_t& i, int64_t& j, int64_t& k) {
@@ -57,7 +57,10 @@ __device__ __forceinline__ int kf_class(const dpvo_keyframe_step_t& a, int d, in
   renumber(R, i, j, k);
   const int n_after = a.n - (d ? 1 : 0);
   bool rem = (k / a.M) < n_after - a.removal_window;         // ix[kk] < n - REMOVAL_WINDOW (dpvo.py:305): index_ rows hold their frame number
-  if (a.loop_closure && rem) rem = !(((j - i) > 30) && (j > (n_after - a.optimization_window)));      // dpvo.py:307-308
+  if (a.loop_closure && rem) {
+    rem = !(((j - i) > 30) && (j > (n_after - a.optimization_window)));      // dpvo.py:307-308
+    if (!rem) return 3;       // kept ONLY because it serves loop closure: a long-range edge (source frame < n - REMOVAL_WINDOW).  While
+  }                           // such edges are active the next update() runs the global BA (dpvo.py:348): the host needs their count
   return rem ? 2 : 1;
 }
 // the host's copy of the result, written straight into its pinned buffer by one thread (a 32- or 64-byte hipMemcpyAsync is another
@@ -74,18 +77,18 @@ __device__ __forceinline__ void kf_host_copy(const dpvo_keyframe_step_t& a) {
 }
 constexpr int KF_CHUNK = 1024;
 __global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts) {
-  __shared__ int wsum[2][16];
+  __shared__ int wsum[3][16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int d = kf_decide(a);
   const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
   const int cls = e < a.E ? kf_class(a, d, e) : 0;
-  const unsigned long long bk = __ballot(cls == 1), br = __ballot(cls == 2);
-  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); }
+  const unsigned long long bk = __ballot(cls == 1 || cls == 3), br = __ballot(cls == 2), bl = __ballot(cls == 3);
+  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); wsum[2][wv] = __popcll(bl); }
   __syncthreads();
   if (tid == 0) {
-    int tk = 0, tr = 0;
-    for (int w = 0; w < 16; ++w) { tk += wsum[0][w]; tr += wsum[1][w]; }
-    counts[2 * blockIdx.x] = tk; counts[2 * blockIdx.x + 1] = tr;
+    int tk = 0, tr = 0, tl = 0;
+    for (int w = 0; w < 16; ++w) { tk += wsum[0][w]; tr += wsum[1][w]; tl += wsum[2][w]; }
+    counts[3 * blockIdx.x] = tk; counts[3 * blockIdx.x + 1] = tr; counts[3 * blockIdx.x + 2] = tl;
     if (blockIdx.x == 0 && a.delta_pose) {
       // dP = SE3(poses[k]) * SE3(poses[k-1]).inv() (dpvo.py:276), with lietorch's store / load between the two ops
       const int k = a.n - a.keyframe_index;
@@ -99,16 +102,17 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_
 }
 __global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe_step_t a, const int32_t* __restrict__ counts) {
   __shared__ int wsum[2][16];
-  __shared__ int base[2], total[2];
+  __shared__ int base[3], total[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int d = kf_decide(a);
-  if (tid < 2) {                                  // exclusive prefix over the chunks before this one (<= a few dozen), and the total
+  if (tid < 3) {                                  // exclusive prefix over the chunks before this one (<= a few dozen), and the total
     int pre = 0, tot = 0;
-    for (int b = 0; b < (int)gridDim.x; ++b) { const int c = counts[2 * b + tid]; if (b < (int)blockIdx.x) pre += c; tot += c; }
+    for (int b = 0; b < (int)gridDim.x; ++b) { const int c = counts[3 * b + tid]; if (b < (int)blockIdx.x) pre += c; tot += c; }
     base[tid] = pre; total[tid] = tot;
   }
   const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
-  const int cls = e < a.E ? kf_class(a, d, e) : 0;
+  int cls = e < a.E ? kf_class(a, d, e) : 0;
+  if (cls == 3) cls = 1;                          // (a long-range edge is a kept edge)
   const unsigned long long bk = __ballot(cls == 1), br = __ballot(cls == 2);
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int pk = __popcll(bk & below), pr = __popcll(br & below);
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe
     int nrem = total[1], ovf = 0;
     if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
     a.result[RES_DECISION] = d; a.result[RES_KEEP] = total[0]; a.result[RES_REM] = nrem; a.result[RES_E] = (int32_t)a.E;
-    a.result[RES_OVERFLOW] = ovf; a.result[5] = a.result[6] = a.result[7] = 0;
+    a.result[RES_OVERFLOW] = ovf; a.result[RES_LONG_RANGE] = total[2]; a.result[6] = a.result[7] = 0;
     // (the host's copy is written by the gather kernel that follows -- kf_host_copy -- unless there is none to launch)
     if (a.result_host && a.E == 0 && a.n_ring == 0) kf_host_copy(a);
   }
@@ -204,7 +208,7 @@ extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
   for (int r = 0; r < a->n_ring; ++r)
     if (!a->ring[r].base || a->ring[r].slot_bytes <= 0 || a->ring[r].ring < 0) return DPVO_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  // the per-chunk counts live behind the 8 result words: `result` has room for 8 + 2 * ceil(E / 1024) ints
+  // the per-chunk counts live behind the 8 result words: `result` has room for 8 + 3 * ceil(E / 1024) ints
   int32_t* counts = a->result + 8;
   const unsigned chunks = (unsigned)(a->E > 0 ? cdiv64(a->E, KF_CHUNK) : 1);
   hipLaunchKernelGGL(kf_count_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, counts);
@@ -231,7 +235,10 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   const dpvo_keyframe_step_t& K = a->kf;
   const int64_t E = K.E;
   const int n = K.n, M = K.M;
-  if (E <= 0 || n < 2 || M <= 0 || a->P <= 0 || K.loop_closure) return DPVO_E_INVALID;
+  // (K.loop_closure: the removal keeps long-range edges per dpvo.py:307-308 and reports their count; the CALLER must not use this
+  //  entry while such edges are active -- update() then owes a global BA over active + inactive edges, dpvo.py:348 -- nor in a frame
+  //  that appends loop-closure edges: the window plan below assumes sources within REMOVAL_WINDOW and targets within PATCH_LIFETIME)
+  if (E <= 0 || n < 2 || M <= 0 || a->P <= 0) return DPVO_E_INVALID;
   if (!a->poses || !a->patches || !a->intrinsics || !a->points || !a->ix || !a->gmap || !a->fmap1 || !a->fmap2 || !a->imap ||
       !a->coords || !a->corr || !a->delta || !a->plan || !a->ws_plan || !a->ws_update || !a->ws_ba || !a->net)
     return DPVO_E_INVALID;

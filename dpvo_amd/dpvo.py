@@ -91,6 +91,8 @@ class DPVO:
         # dpvo.py:266-270 (True = drop keyframe n - KEYFRAME_INDEX); the test kernel and its read-back still run.  For workloads
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
+        self._lr_active = 0         # long-range (loop-closure) edges in the active list: > 0 => update() owes a global BA (dpvo.py:348)
+        self._loop_try = None       # this frame's PatchGraph.edges_loop() result when it was evaluated ahead of the frame call
         self.last_keyframe = None   # (decision, (sum_ij, count_ij, sum_ji, count_ji)) of the last resolved keyframe test
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:     # "cuda" -> "cuda:<current>": tensors carry an index, and
@@ -315,7 +317,9 @@ class DPVO:
         """generic append (loop-closure edges): ii = patch ids, jj = target frames (dpvo.py:215-221)"""
         self.pg.edges.append(self.ix[ii], jj, ii)
         self._plan = None
-        self._plan_exact = True          # edges from outside the tracker's own bookkeeping: no window / bound assumptions
+        # edges from outside the tracker's own bookkeeping (loop closure): no window / bound assumptions while they are active; the
+        # keyframe step reports when the last of them has left the active list (_lr_active back to 0)
+        self._lr_active += int(ii.numel())
 
     def append_frame_factors(self):
         """append_factors(*edges_forw) + append_factors(*edges_back) (dpvo.py:458-459) as one kernel"""
@@ -470,6 +474,10 @@ class DPVO:
             to_remove, staged = self._removal_mask(es.host()), None
 
         self.remove_factors(to_remove, store=True, staged=staged)
+        if self.cfg.LOOP_CLOSURE:
+            # what the device-side step reports in its result word [5]: the edges the rule of dpvo.py:307-308 kept alive.  With the
+            # next frame counted (n + 1) they satisfy ii < n - REMOVAL_WINDOW - 1 of dpvo.py:348
+            self._lr_active = int(np.count_nonzero(es.host()["ii"] < self.n - self.cfg.REMOVAL_WINDOW))
         if _CHECK_MIRROR:       # tests: the host mirror must track the device arrays exactly
             h = es.host()
             for k in ("ii", "jj", "kk"):
@@ -486,7 +494,9 @@ class DPVO:
     def _frame_call_ok(self, n=None):
         from . import net as net_mod
         n = self.n if n is None else n
-        return (_FRAME_CALL and self.is_initialized and not self.cfg.LOOP_CLOSURE and self._hip_enc is not None and self.P == 3
+        # LOOP_CLOSURE (BASELINE config 5): the one-call path serves every frame whose update() takes the LOCAL BA branch of
+        # dpvo.py:351-354 -- no long-range edge active (reported by the previous keyframe step) and none appended for this frame
+        return (_FRAME_CALL and self.is_initialized and self._lr_active == 0 and self._hip_enc is not None and self.P == 3
                 and self._gmap_cl.dtype == torch.float16 and net_mod.FUSED_DEFAULT and not net_mod.PM_DEFAULT
                 and n - self.cfg.KEYFRAME_INDEX >= 1 and self.cfg.OPTIMIZATION_WINDOW <= 20)
 
@@ -516,7 +526,7 @@ class DPVO:
               # timing events for bench.py's roofline legs (HIP events around the correlation kernel / the update operator
               # inside the call): created once, re-recorded in place -- creating events per frame costs the host ~20 us
               "evpool": [torch.cuda.Event(enable_timing=True) for _ in range(512)] if prof_on else None,
-              "result": torch.zeros(16 + 2 * (cap // 1024 + 2), dtype=f32, device=dev),
+              "result": torch.zeros(16 + 3 * (cap // 1024 + 2), dtype=f32, device=dev),
               "host": [torch.zeros(16, dtype=f32).pin_memory() for _ in range(2)],
               "dpose": torch.zeros(2, 7, dtype=f32, device=dev),
               "ev": [torch.cuda.Event() for _ in range(2)], "wait_ema": 0.0,
@@ -546,7 +556,7 @@ class DPVO:
             for r, (t, ring) in enumerate(rings):
                 kf.ring[r].base, kf.ring[r].slot_bytes, kf.ring[r].ring = dp(t), t.stride(0) * t.element_size(), ring
             kf.n_ring, kf.M, kf.D = len(rings), self.M, es.D
-            kf.keyframe_index, kf.removal_window, kf.loop_closure = cfg.KEYFRAME_INDEX, cfg.REMOVAL_WINDOW, 0
+            kf.keyframe_index, kf.removal_window, kf.loop_closure = cfg.KEYFRAME_INDEX, cfg.REMOVAL_WINDOW, int(bool(cfg.LOOP_CLOSURE))
             kf.optimization_window, kf.keyframe_thresh = cfg.OPTIMIZATION_WINDOW, cfg.KEYFRAME_THRESH
             a.poses, a.patches, a.intrinsics, a.points, a.ix = (dp(self.pg.poses_), dp(self.pg.patches_), dp(self.pg.intrinsics_),
                                                                 dp(self.pg.points_), dp(self.pg.index_))
@@ -673,6 +683,7 @@ class DPVO:
         decision, n_keep, n_rem, e_in, overflow = int(hi[8]), int(hi[9]), int(hi[10]), int(hi[11]), int(hi[12])
         # what the device decided on: the flow test's sums and counts for (i -> j) and (j -> i) (dpvo.py:266-270), for diagnostics
         self.last_keyframe = (decision, tuple(fu["host_f"][flip][0:4].tolist()))
+        self._lr_active = int(hi[13])
         if e_in != E or overflow:
             raise L.DPVOHipError(f"dpvo_keyframe_step: inconsistent result {hi[8:13].tolist()} for E = {E}")
         if fu["host_f"][flip][7] != 0 and not getattr(self, "_plan_exact", False):
@@ -726,7 +737,7 @@ class DPVO:
         the side stream behind that event only (the caller runs plan_sync() before the first reader on the main stream)."""
         if self._plan is None or self._plan.E != self.pg.ii.numel():
             ub_p = ub_g = window = None
-            if not self.cfg.LOOP_CLOSURE and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
+            if self._lr_active == 0 and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
                 # every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
                 # PATCH_LIFETIME frames of the source: bounds on #patches / #frame pairs, no device read-back needed
                 nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
@@ -949,7 +960,15 @@ class DPVO:
             n = self.n
             # steady state: patch gathers + state stores, motion model, depth median, pyramid level 1 and the new frame's
             # edges as ONE C-ABI call (dpvo_frame_state); otherwise the same entries one by one
-            composite = (self.is_initialized and not self.cfg.LOOP_CLOSURE and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR'
+            # LOOP_CLOSURE: PatchGraph.edges_loop() is due every GLOBAL_OPT_FREQ frames -- and on EVERY frame while it finds nothing
+            # (dpvo.py:449-455: last_global_ba only moves when edges were found).  It reads poses / patches of frames the new frame
+            # does not touch, so it is evaluated here, ahead of the frame call (one host round trip); loop edges found => this frame
+            # takes the call-by-call path (they go in front of the frame's own edges, and update() then runs the global BA)
+            self._loop_try = None
+            if self.cfg.LOOP_CLOSURE and self.is_initialized and (n + 1) - self.last_global_ba >= self.cfg.GLOBAL_OPT_FREQ:
+                self._loop_try = self.pg.edges_loop(n=n + 1)
+            loop_found = self._loop_try is not None and self._loop_try[0].numel() > 0
+            composite = (self.is_initialized and not loop_found and self._lr_active == 0 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR'
                          and n > 1 and 3 * self.M * self.P * self.P <= 4096)
             fac = None
             if n > 1 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
@@ -1097,7 +1116,8 @@ class DPVO:
         if self.cfg.LOOP_CLOSURE:
             if self.n - self.last_global_ba >= self.cfg.GLOBAL_OPT_FREQ:
                 """ Add loop closure factors """
-                lii, ljj = self.pg.edges_loop()
+                lii, ljj = self._loop_try if self._loop_try is not None else self.pg.edges_loop()
+                self._loop_try = None
                 if lii.numel() > 0:
                     self.last_global_ba = self.n
                     self.append_factors(lii, ljj)

@@ -46,7 +46,7 @@ def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0,
         f0 = kmin // M
         n_frames = kmax // M - f0 + 1
     lm = float(lmbda) if not torch.is_tensor(lmbda) else float(lmbda.reshape(-1)[0].item())
-    nbytes = L.lib().dpvo_gba_workspace_bytes(L.i64(E), L.i64(plan.n_pairs_host), L.i64(n_frames), L.i32(M))
+    nbytes = L.lib().dpvo_gba_workspace_bytes(L.i64(E), L.i64(plan.n_pairs_host), L.i64(n_frames), L.i32(M), L.i64(N))
     ws = workspace.get(nbytes, poses.device, "gba")
     n6 = 6 * N
     dev = poses.device

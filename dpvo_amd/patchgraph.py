@@ -376,17 +376,19 @@ class PatchGraph:
     target_inac = property(lambda self: self.edges_inac.view("target")[None])
     weight_inac = property(lambda self: self.edges_inac.view("weight")[None])
 
-    def edges_loop(self):
-        """Adding edges from old patches to new frames (patchgraph.py:56-82)"""
+    def edges_loop(self, n=None):
+        """Adding edges from old patches to new frames (patchgraph.py:56-82).  n: the frame count to evaluate for (default self.n;
+        the tracker asks for n + 1 just before it counts a new frame: none of the candidates involves that frame)"""
+        n = self.n if n is None else n
         lc_range = self.cfg.MAX_EDGE_AGE
-        l = self.n - self.cfg.REMOVAL_WINDOW  # l is the upper bound for "old" patches
+        l = n - self.cfg.REMOVAL_WINDOW  # l is the upper bound for "old" patches
         dev = self.poses_.device
         if l <= 0:
             return torch.empty(2, 0, dtype=torch.long, device=dev)
 
         # create candidate edges
         jj, kk = flatmeshgrid(
-            torch.arange(self.n - self.cfg.GLOBAL_OPT_FREQ, self.n - self.cfg.KEYFRAME_INDEX, device=dev),
+            torch.arange(n - self.cfg.GLOBAL_OPT_FREQ, n - self.cfg.KEYFRAME_INDEX, device=dev),
             torch.arange(max(l - lc_range, 0) * self.M, l * self.M, device=dev), indexing='ij')
         ii = self.ix[kk]
 

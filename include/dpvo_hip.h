@@ -357,10 +357,12 @@ int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const fl
  *   3. the edges whose source frame kk / M < n' - removal_window leave to the inactive store (remove_factors(..., store=True),
  *      :305-310; with loop_closure != 0 the long-range edges of :307-308 stay), the others are compacted in order into the
  *      spare arrays (*_b).
- * result (device, 8 x int32 followed by 2 * ceil(E / 1024) ints of scratch; the words are also written to result_host if not
+ * result (device, 8 x int32 followed by 3 * ceil(E / 1024) ints of scratch; the words are also written to result_host if not
  * NULL -- pinned host memory, see host_words):
  *   [0] decision, [1] edges kept, [2] edges moved to the inactive store, [3] E, [4] 1 if the inactive room was too small
- *   (nothing written beyond it).  The caller swaps its array sets and updates its counters when it reads the result --
+ *   (nothing written beyond it), [5] how many of the kept edges are long-range ones that stayed only because of the loop-closure
+ *   rule of dpvo.py:307-308 (0 unless loop_closure != 0): while that count is non-zero the next update() owes the global bundle
+ *   adjustment of dpvo.py:348 and the caller must take the call-by-call path.  The caller swaps its array sets and updates its counters when it reads the result --
  *   one frame later, if it likes: nothing on the device waits for the host. */
 typedef struct { void* base; int64_t slot_bytes; int64_t ring; } dpvo_ring_t;   /* ring = 0: slot i lives at i, else at i % ring */
 typedef struct {
@@ -383,13 +385,14 @@ typedef struct {
 } dpvo_keyframe_step_t;
 int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream);
 
-/* dpvo_frame_update: DPVO.update() + DPVO.keyframe() of one steady-state frame (dpvo.py:328-360,266-310; no loop closure)
- * as ONE call: graph plan (window build, ranged fallback), reproject, two-level correlation, update operator (seven
+/* dpvo_frame_update: DPVO.update() + DPVO.keyframe() of one steady-state frame (dpvo.py:328-360,266-310) as ONE call -- with
+ * LOOP_CLOSURE too (kf.loop_closure = 1) in every frame that neither appends loop-closure edges nor has long-range edges active
+ * (result word [5] of the previous step == 0): the local-BA branch of dpvo.py:351-354 is the one this entry runs -- graph plan (window build, ranged fallback), reproject, two-level correlation, update operator (seven
  * launches), two local BA iterations, point cloud, flow test, dpvo_keyframe_step, result copy.  Every pointer is a caller
  * buffer (capacity buffers + workspaces sized with the *_workspace_bytes functions for E); ev[0..3] (hipEvent_t or NULL) are
  * recorded before / after the correlation kernel and before / after the update operator (roofline measurement).
  * result_dev: 16 words -- [0..3] flow sums, [4..7] plan counters (float), [8..15] the dpvo_keyframe_step result -- followed by
- * that step's 2 * ceil(E / 1024) ints of scratch.  fs (may be NULL): a dpvo_frame_state to issue first (the new frame's patch
+ * that step's 3 * ceil(E / 1024) ints of scratch.  fs (may be NULL): a dpvo_frame_state to issue first (the new frame's patch
  * gathers, state stores and edges: everything between the encoders and the plan), with ev_fs (hipEvent_t or NULL) recorded
  * right behind it. */
 typedef struct {
@@ -448,7 +451,7 @@ int dpvo_pool4_nhwc(const void* in, void* out, int h, int w, int C, void* stream
  * f0 / n_frames: first source frame that owns a patch in kk and the number of frames up to the last one
  * (patch p belongs to frame p / M); M = patches per frame (PPF); plan from dpvo_plan_build(ii,jj,kk);
  * the same `ws` (dpvo_gba_workspace_bytes) must be passed to both calls of one iteration. */
-size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n_frames, int M);
+size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n_frames, int M, int64_t n_free);   /* n_free = t1 - t0 */
 int dpvo_gba_linearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
                        const float* weight, float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk,
                        const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E, int P, int M, int f0,

@@ -219,7 +219,7 @@ def test_keyframe_step_decision_unit(dev):
         args = fu["args"][par]
         kf = L.KeyframeStep.from_buffer_copy(args.kf)
         flow = torch.tensor([s0, c0, s1, c1, 0, 0, 0, 0] + [0.0] * 8, dtype=torch.float32, device=dev)
-        res = torch.zeros(16 + 2 * (es.cap // 1024 + 2), dtype=torch.float32, device=dev)
+        res = torch.zeros(16 + 3 * (es.cap // 1024 + 2), dtype=torch.float32, device=dev)
         res[:16] = flow
         kf.flow4, kf.result, kf.result_host, kf.host_words = res.data_ptr(), res.data_ptr() + 32, None, 8
         kf.poses = a.pg.poses_.data_ptr()
@@ -228,6 +228,56 @@ def test_keyframe_step_decision_unit(dev):
         L.check(L.lib().dpvo_keyframe_step(ctypes.byref(kf), L.stream()), "dpvo_keyframe_step")
         torch.cuda.synchronize()
         assert int(res.view(torch.int32)[8].item()) == expect, ((s0, c0, s1, c1), expect)
+
+
+def _run_loop_closure(dev, frame_call, n_frames=60, M=16, ht=96, wd=128, seed=13, **kw):
+    """LOOP_CLOSURE=True (BASELINE config 5) on a stream that revisits its start, so that PatchGraph.edges_loop finds edges and
+    update() runs global BAs; no scripted decision except the initialisation probe"""
+    import dpvo_amd.dpvo as dpvo_mod
+    fc_before = dpvo_mod._FRAME_CALL
+    dpvo_mod._FRAME_CALL = frame_call
+    try:
+        cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
+        cfg.PATCHES_PER_FRAME, cfg.BUFFER_SIZE, cfg.KEYFRAME_THRESH, cfg.LOOP_CLOSURE = M, 256, -1.0, True
+        torch.manual_seed(seed)
+        slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=dev, **kw)
+        slam.motion_probe = lambda: 1e9
+        g = torch.Generator().manual_seed(seed)
+        tex = torch.rand(3, ht + 64, wd + 64, generator=g)
+        tex = torch.nn.functional.avg_pool2d(tex[None], 5, 1, 2)[0]
+        tex = (255 * (tex - tex.min()) / (tex.max() - tex.min())).to(torch.uint8)
+        intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
+        fast = slow = 0
+        for t in range(n_frames):
+            img = tex[:, (2 * t) % 64:(2 * t) % 64 + ht, (3 * t) % 64:(3 * t) % 64 + wd].contiguous().to(dev)
+            torch.manual_seed(700 + t)
+            pend = slam._fu_pending
+            slam(float(t), img, intr)
+            fast += int(slam._fu_pending is not None and slam._fu_pending is not pend)
+            slam.flush()
+        return slam, fast
+    finally:
+        dpvo_mod._FRAME_CALL = fc_before
+
+
+def test_loop_closure_on_the_one_call_path(dev):
+    """BASELINE config 5: with LOOP_CLOSURE=True the one-call frame path serves every frame that takes update()'s local-BA branch
+    (no long-range edge active, none appended), the call-by-call path the others (loop edges appended in front of the frame's own,
+    global BA over active + inactive edges).  Against the all-call-by-call run: the same state bit for bit -- which also needs the
+    global BA to be bit-repeatable (gba_row_kernel, round 4)."""
+    a, fast = _run_loop_closure(dev, True, defer_keyframe=True, overlap_encoders=True)
+    b, none = _run_loop_closure(dev, False)
+    torch.cuda.synchronize()
+    gb = int(a.ran_global_ba.sum())
+    print(f"loop closure: {fast} of 60 frames on the one-call path, {gb} global BA runs, {a.pg.ii_inac.numel()} inactive edges")
+    assert none == 0 and fast >= 15, "both paths must have been exercised"
+    assert gb >= 2 and gb == int(b.ran_global_ba.sum()) and np.array_equal(a.ran_global_ba, b.ran_global_ba)
+    assert a.n == b.n and a.m == b.m and a.last_global_ba == b.last_global_ba
+    for k in ("ii", "jj", "kk", "ii_inac", "jj_inac", "kk_inac", "net", "target", "weight", "target_inac", "weight_inac"):
+        assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)), k
+    assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
+    pa, _ = a.terminate(); pb, _ = b.terminate()
+    assert np.array_equal(pa, pb)
 
 
 def test_deferred_state_compaction_is_bit_identical(dev, monkeypatch):
