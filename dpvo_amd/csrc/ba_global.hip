@@ -167,9 +167,17 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
   }
 }
 
-// Block row p of S and y[p] (see the file header).  256 threads = 4 waves; wave w owns the column blocks whose pose q has
-// q % 4 == w, wave 0 also y.  `S` and `y` must be zero on entry.
-__global__ __launch_bounds__(256) void gba_row_kernel(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
+// Block row p of S and y[p] (see the file header).  grid (N, split), 1024 threads = 16 waves: the 16 * split waves of a row
+// each own the column blocks whose pose q has q % (16 * split) == their number; wave 0 of the first workgroup also owns y.
+// split = gridDim.y is chosen by the launcher: 4 for N <= 128, 2 for N <= 400, else 1 -- more chains per row shorten a short
+// call (N = 49: 0.44 -> 0.21 ms) but every wave scans every block of every source frame, which is what a long call pays for
+// (N = 799: 1.9 ms with 4 or 16 waves per row, 2.4 with 64).
+// (A row is one dependent chain per wave -- ~28 source frames x its share of their ~28 blocks, each a round trip for the block
+// operands and one for the read-modify-write: with 4 waves per row the kernel took 0.45-1.9 ms, with 16 0.3-1.9; measured
+// alternative: the frame's blocks staged in LDS + the row in an LDS strip, 16 waves: slower (two barriers and a 64 KB copy per
+// source frame); the atomics version this replaces: 0.28 ms.)  `S` and `y` must be zero on entry.
+constexpr int kRowWaves = 16;
+__global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
                                                       const int32_t* __restrict__ run_lo, const int32_t* __restrict__ tgt_off,
                                                       const int32_t* __restrict__ tgt_list, const float* __restrict__ pairbuf,
                                                       const float* __restrict__ Q, const float* __restrict__ U,
@@ -177,7 +185,8 @@ __global__ __launch_bounds__(256) void gba_row_kernel(const int32_t* __restrict_
                                                       int f0, int n_frames, int t0, int N, float* __restrict__ S,
                                                       float* __restrict__ y) {
   const int p = blockIdx.x, j = p + t0;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) + kRowWaves * (int)blockIdx.y);
+  const int kRowCls = kRowWaves * (int)gridDim.y;
   const int64_t n6 = 6 * (int64_t)N;
   const int r36 = lane / 6, c36 = lane - 6 * r36;                  // (lanes 0..35: entry (r36, c36) of a 6 x 6 block)
   float* Srow = S + (int64_t)(6 * p) * n6;
@@ -189,16 +198,16 @@ __global__ __launch_bounds__(256) void gba_row_kernel(const int32_t* __restrict_
   for (int g = ja; g < jb; ++g) {
     const float* pb = pairbuf + (int64_t)g * kPairStride;
     const int jx = pair_ij[2 * g + 1] - t0;
-    if (wave == (p & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[r36 * 16 + c36];
-    if (jx >= 0 && jx < N && wave == (jx & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * jx + c36] -= pb[r36 * 16 + 6 + c36];
+    if (wave == (p % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[r36 * 16 + c36];
+    if (jx >= 0 && jx < N && wave == (jx % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * jx + c36] -= pb[r36 * 16 + 6 + c36];
     if (wave == 0 && lane < 6) y[6 * p + lane] -= pb[lane * 16 + 12];
   }
   for (int q = tl0; q < tl1; ++q) {
     const int g = tgt_list[q];
     const float* pb = pairbuf + (int64_t)g * kPairStride;
     const int ix = pair_ij[2 * g] - t0;
-    if (wave == (p & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[(6 + r36) * 16 + 6 + c36];
-    if (ix >= 0 && ix < N && wave == (ix & 3) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * ix + c36] -= pb[c36 * 16 + 6 + r36];   // mirror of block (ix, p)
+    if (wave == (p % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[(6 + r36) * 16 + 6 + c36];
+    if (ix >= 0 && ix < N && wave == (ix % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * ix + c36] -= pb[c36 * 16 + 6 + r36];   // mirror of block (ix, p)
     if (wave == 0 && lane < 6) y[6 * p + lane] += pb[(6 + lane) * 16 + 12];
   }
   // ---- Schur terms: every source frame f that has a block with pose p -- the sources of the target list, and j itself (its
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) void gba_row_kernel(const int32_t* __restrict_
       else { if (f != j) continue; Ea = Eself + (int64_t)fr * M * 6; }
       for (int b = 0; b <= P; ++b) {
         const int pb_ = (b < P ? pair_ij[2 * (g0 + b) + 1] : f) - t0;
-        if (pb_ < 0 || pb_ >= N || (pb_ & 3) != wave) continue;
+        if (pb_ < 0 || pb_ >= N || (pb_ % kRowCls) != wave) continue;
         const float* Eb = b < P ? Ecol + (int64_t)(g0 + b) * M * 6 : Eself + (int64_t)fr * M * 6;
         float acc[36];
 #pragma unroll
@@ -364,7 +373,7 @@ extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, cons
                      edgebuf, Ecol, M);
   hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
                      plan + PL.patch_off, plan + PL.kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself);
-  hipLaunchKernelGGL(gba_row_kernel, dim3((unsigned)N), dim3(256), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
+  hipLaunchKernelGGL(gba_row_kernel, dim3((unsigned)N, N <= 128 ? 4u : (N <= 400 ? 2u : 1u)), dim3(64 * kRowWaves), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
                      pairbuf, Q, U, Ecol, Eself, M, f0, n_frames, t0, N, S, y);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
