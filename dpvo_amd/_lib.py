@@ -29,7 +29,7 @@ SYMBOLS = [
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract", "dpvo_gba_solve_workspace_bytes", "dpvo_gba_solve",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
-    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state", "dpvo_keyframe_step", "dpvo_frame_update", "dpvo_debug_stamp",
+    "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state", "dpvo_frame_state_part", "dpvo_keyframe_step", "dpvo_frame_update", "dpvo_debug_stamp",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_encoders_forward_hold", "dpvo_pool4_nhwc",
 ]
 
@@ -77,7 +77,9 @@ class KeyframeStep(ctypes.Structure):
 
 class FrameUpdate(ctypes.Structure):
     """dpvo_frame_update_t"""
-    _fields_ = ([("kf", KeyframeStep), ("fs", ctypes.c_void_p), ("ev_fs", ctypes.c_void_p), ("ev_update_done", ctypes.c_void_p),
+    _fields_ = ([("kf", KeyframeStep), ("fs", ctypes.c_void_p), ("ev_fs", ctypes.c_void_p), ("ev_enc", ctypes.c_void_p),
+                 ("fmap_spec", ctypes.c_void_p), ("ev_record", ctypes.c_void_p),
+                 ("ev_update_done", ctypes.c_void_p),
                  ("fs_auto", ctypes.c_int32),
                  ("index_map", ctypes.c_void_p), ("net", ctypes.c_void_p), ("net_rows", ctypes.c_void_p), ("n_kept", ctypes.c_int64)] +
                 [(k, ctypes.c_void_p) for k in ("poses", "patches", "intrinsics", "points", "ix", "gmap", "fmap1", "fmap2",

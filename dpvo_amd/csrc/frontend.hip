@@ -502,6 +502,47 @@ extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void
   return DPVO_OK;
 }
 
+// part 0: everything (dpvo_frame_state).  part 1: what does NOT read the encoders' outputs -- coordinate / depth patches, colours,
+// intrinsics, index rows, motion model, depth median, the new edges; part 2: what does -- the gmap / imap gathers and pyramid
+// level 1.  dpvo_frame_update issues part 1, the plan and the reprojection BEFORE it makes its stream wait for the side stream's
+// encoders, and part 2 behind that wait: ~45 us of small launches that no longer sit between "encoders done" and the correlation.
+extern "C" int dpvo_frame_state_part(dpvo_frame_state_t* p, int part, void* stream) {
+  if (!p || part < 0 || part > 2) return DPVO_E_INVALID;
+  if (part == 0) return dpvo_frame_state(p, stream);
+  dpvo_frame_state_t q = *p;
+  if (part == 1) { q.gmap_slot = q.imap_slot = q.fmap2_slot = nullptr; }
+  else { q.patches_slot = nullptr; q.colors_slot = nullptr; q.intrinsics_slot = nullptr; q.index_row = nullptr; q.index_map = nullptr;
+         q.poses = nullptr; q.patches_all = nullptr; q.ii = nullptr; }
+  const int M = q.M;
+  if (M <= 0 || q.P != 3 || q.h <= 0 || q.w <= 0 || (q.h % 4) || (q.w % 4) || (q.CF % 8) || q.CI <= 0 || !(q.coords || (q.xs && q.ys)))
+    return DPVO_E_INVALID;
+  if (part == 2 && (!q.fmap || !q.imap || !q.gmap_slot || !q.imap_slot || !q.fmap2_slot)) return DPVO_E_INVALID;
+  if (part == 1 && (!q.img_u8 || !q.patches_slot || !q.colors_slot || !q.poses || !q.patches_all || !q.ii || !q.jj || !q.kk || !q.ix ||
+                    q.mm_n < 2 || q.md_n < 3 || 3 * M * 9 > 4096 || q.E0 < 0 || q.ap_n < 1 || q.ap_r < 0 || q.D <= 0 || (q.D % 4)))
+    return DPVO_E_INVALID;
+  FrameStateArgs S;
+  S.fp = {(const _Float16*)q.fmap, (const _Float16*)q.imap, (const uint8_t*)q.img_u8, q.coords, q.xs, q.ys, q.depth,
+          q.intrinsics, q.res, (_Float16*)q.gmap_slot, (_Float16*)q.imap_slot, q.patches_slot, (uint8_t*)q.colors_slot,
+          q.intrinsics_slot, q.index_row, q.index_map, nullptr, M, q.h, q.w, q.H, q.W, q.CF, q.CI, q.frame_next, q.m_next, 1};
+  S.poses = q.poses; S.mm_n = q.mm_n; S.mm_scale = q.mm_scale;
+  S.patches_all = q.patches_all; S.md_n = q.md_n; S.P = q.P;
+  S.fmap2_slot = (_Float16*)q.fmap2_slot;
+  S.ii = q.ii; S.jj = q.jj; S.kk = q.kk; S.net = q.net; S.ix = q.ix; S.E0 = q.E0; S.ap_n = q.ap_n; S.ap_r = q.ap_r; S.D = q.D;
+  S.n_med = 0; S.n_pool = 0; S.n_app = 0;
+  if (part == 1) {
+    const int n = q.ap_n, r = q.ap_r, jlo = n - r > 0 ? n - r : 0;
+    const int64_t total = (int64_t)M * ((n - 1 > 0 ? n - 1 : 0) - jlo) + (int64_t)M * (n - jlo);
+    p->n_new = total;
+    S.n_med = (3 * M * 9 + 31) / 32;
+    S.n_app = total > 0 ? (int)grid_for(total * (q.D / 4), 2048) : 0;
+  } else {
+    S.n_pool = (int)(((int64_t)(q.h / 4) * (q.w / 4) * (q.CF / 8) + 255) / 256);
+  }
+  hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(M + 1 + S.n_med + S.n_pool + S.n_app)), dim3(256), 0, (hipStream_t)stream, S);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
 extern "C" int dpvo_frame_state(dpvo_frame_state_t* p, void* stream) {
   if (!p) return DPVO_E_INVALID;
   const bool fused = p->poses && p->patches_all && p->fmap2_slot && p->ii && p->jj && p->kk && p->ix && p->fmap && p->imap &&

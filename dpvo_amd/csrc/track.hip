@@ -34,13 +34,13 @@ __device__ __forceinline__ void renumber(const Renum& R, int64_t& i, int64_t& j,
 // ---- 1. decision + stable partition, two small launches: (a) every 1024-edge chunk counts its kept / inactive edges,
 //         (b) every chunk adds up the counts of the chunks before it and writes its indices in order.  (One workgroup walking
 //         all ~5 x 10^4 index triples took 95 us; this takes ~2 x 5.)
-__device__ __forceinline__ int kf_decide(const dpvo_keyframe_step_t& a) {
+__device__ __forceinline__ int kf_decide(const dpvo_keyframe_step_t& a, const float* flow4) {
   int d;
   if (a.forced >= 0) d = a.forced ? 1 : 0;
   else {
     // m = motionmag(i, j) + motionmag(j, i); drop iff m / 2 < KEYFRAME_THRESH (dpvo.py:266-271).  A direction without
     // edges gives mean = NaN in the reference (mean of an empty tensor) and the comparison is false.
-    const float s0 = a.flow4[0], n0 = a.flow4[1], s1 = a.flow4[2], n1 = a.flow4[3];
+    const float s0 = flow4[0], n0 = flow4[1], s1 = flow4[2], n1 = flow4[3];
     const float nan = __builtin_nanf("");
     const float m = (n0 > 0.f ? s0 / n0 : nan) + (n1 > 0.f ? s1 / n1 : nan);
     d = (m / 2.f < a.keyframe_thresh) ? 1 : 0;
@@ -76,10 +76,22 @@ __device__ __forceinline__ void kf_host_copy(const dpvo_keyframe_step_t& a) {
   //  host reads the record only after synchronising with an event recorded behind this kernel, which orders the writes.)
 }
 constexpr int KF_CHUNK = 1024;
-__global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts) {
+// F.poses != NULL: the flow test itself (DPVO.motionmag for (k - 1, k + 1) and back, dpvo.py:257-269) runs HERE, in every chunk's
+// workgroup redundantly (one scan of the ~500 pair records + ~190 edge flows: less than the launch it saves), block 0 leaves the
+// sums in a.flow4 for kf_select, the record and the host.  Same code, same reduction tree as dpvo_motionmag: same bits in every block.
+__global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts, const MotionPlanArgs F) {
   __shared__ int wsum[3][16];
+  __shared__ float fl4[8];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int d = kf_decide(a);
+  const float* flow4 = a.flow4;
+  if (F.poses) {
+    motionmag_plan_body(F.poses, F.patches, F.intr, F.kk, F.perm_p, F.pair_off, F.pair_ij, F.n_pairs, F.P, F.qi, F.qj, F.beta, fl4,
+                        blockIdx.x == 0 ? F.status : nullptr);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < 4) F.out[tid] = fl4[tid];
+    flow4 = fl4;
+  }
+  const int d = kf_decide(a, flow4);
   const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
   const int cls = e < a.E ? kf_class(a, d, e) : 0;
   const unsigned long long bk = __ballot(cls == 1 || cls == 3), br = __ballot(cls == 2), bl = __ballot(cls == 3);
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe
   __shared__ int wsum[2][16];
   __shared__ int base[3], total[3];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int d = kf_decide(a);
+  const int d = kf_decide(a, a.flow4);
   if (tid < 3) {                                  // exclusive prefix over the chunks before this one (<= a few dozen), and the total
     int pre = 0, tot = 0;
     for (int b = 0; b < (int)gridDim.x; ++b) { const int c = counts[3 * b + tid]; if (b < (int)blockIdx.x) pre += c; tot += c; }
@@ -127,15 +139,16 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe
     if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
     a.result[RES_DECISION] = d; a.result[RES_KEEP] = total[0]; a.result[RES_REM] = nrem; a.result[RES_E] = (int32_t)a.E;
     a.result[RES_OVERFLOW] = ovf; a.result[RES_LONG_RANGE] = total[2]; a.result[6] = a.result[7] = 0;
-    // (the host's copy is written by the gather kernel that follows -- kf_host_copy -- unless there is none to launch)
-    if (a.result_host && a.E == 0 && a.n_ring == 0) kf_host_copy(a);
+    // the host's copy: from here on the record is final (the gather that follows only executes it).  Round 3 wrote it from the
+    // gather kernel to keep the 16 PCIe writes off this kernel's critical path; round 4 lets the HOST start on the next frame one
+    // point-cloud + gather (~36 us) earlier instead, behind an event recorded right after this kernel
+    if (a.result_host) kf_host_copy(a);
   }
 }
 
 // ---- 2. the two gathers (kept -> spare set, incl. the 1.5 KB hidden-state rows; inactive -> tail of the inactive store)
 __device__ __forceinline__ void kf_shift_body(const dpvo_keyframe_step_t& a, int blk, int blocks_per_ring);
 __global__ __launch_bounds__(256) void kf_gather_kernel(const dpvo_keyframe_step_t a, int nblk_keep, int nblk_gather, int blocks_per_ring) {
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255 && a.result_host) kf_host_copy(a);
   if ((int)blockIdx.x >= nblk_gather) { kf_shift_body(a, (int)blockIdx.x - nblk_gather, blocks_per_ring); return; }
   const Renum R = {a.result[RES_DECISION], a.n - a.keyframe_index, a.M};
   const bool keep_job = (int)blockIdx.x < nblk_keep;
@@ -197,6 +210,10 @@ inline unsigned blocks_for(int64_t n, int64_t cap) {
 
 }  // namespace
 
+namespace {
+void kf_decide_launch(const dpvo_keyframe_step_t* a, const MotionPlanArgs& F, hipStream_t st);
+void kf_apply_launch(const dpvo_keyframe_step_t* a, hipStream_t st);
+}
 extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
   if (!a || a->E < 0 || a->E >= (1ll << 31) || a->M <= 0 || a->D <= 0 || (a->D % 4) || a->n_ring < 0 || a->n_ring > 8) return DPVO_E_INVALID;
   if (a->result_host && a->host_words != 8 && a->host_words != 16) return DPVO_E_INVALID;
@@ -207,12 +224,23 @@ extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
   if ((a->net == nullptr) != (a->net_b == nullptr)) return DPVO_E_INVALID;
   for (int r = 0; r < a->n_ring; ++r)
     if (!a->ring[r].base || a->ring[r].slot_bytes <= 0 || a->ring[r].ring < 0) return DPVO_E_INVALID;
-  hipStream_t st = (hipStream_t)stream;
+  kf_decide_launch(a, MotionPlanArgs{}, (hipStream_t)stream);
+  kf_apply_launch(a, (hipStream_t)stream);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+namespace {
+// decision, counts, index lists, result record (device + host copy).  F.poses != NULL: the flow test runs inside the count kernel.
+void kf_decide_launch(const dpvo_keyframe_step_t* a, const MotionPlanArgs& F, hipStream_t st) {
   // the per-chunk counts live behind the 8 result words: `result` has room for 8 + 3 * ceil(E / 1024) ints
   int32_t* counts = a->result + 8;
   const unsigned chunks = (unsigned)(a->E > 0 ? cdiv64(a->E, KF_CHUNK) : 1);
-  hipLaunchKernelGGL(kf_count_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, counts);
+  hipLaunchKernelGGL(kf_count_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, counts, F);
   hipLaunchKernelGGL(kf_select_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, (const int32_t*)counts);
+}
+// the two gathers (kept edges -> spare set, removed edges -> inactive store) and the ring shifts of a dropped keyframe
+void kf_apply_launch(const dpvo_keyframe_step_t* a, hipStream_t st) {
   {
     // the two gathers and the ring shifts are independent of each other: one launch (the shift blocks leave at once unless
     // the keyframe was dropped)
@@ -226,9 +254,8 @@ extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
     if (gk + gr + bpr * (unsigned)a->n_ring > 0)
       hipLaunchKernelGGL(kf_gather_kernel, dim3(gk + gr + bpr * (unsigned)a->n_ring), dim3(256), 0, st, *a, (int)gk, (int)(gk + gr), (int)bpr);
   }
-  DPVO_LAUNCH_CHECK();
-  return DPVO_OK;
 }
+}  // namespace
 
 extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (!a || !a->upd || !a->result_dev) return DPVO_E_INVALID;
@@ -268,8 +295,13 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
       F->frame_next = f + 1; F->m_next = a->m;            // index_[f + 1] = f + 1, index_map_[f + 1] = m (after the increment)
       F->M = M; F->P = a->P; F->h = a->H0; F->w = a->W0;
     }
-    STEP(dpvo_frame_state(a->fs, stream));
-    if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
+    // ev_enc (the side stream's "encoders done"): only the feature gathers and the pyramid's level 1 need the encoders' outputs,
+    // so the state stores, the new edges, the plan and the reprojection go first and the stream waits just in front of part 2
+    if (a->ev_enc) STEP(dpvo_frame_state_part(a->fs, 1, stream));
+    else {
+      STEP(dpvo_frame_state(a->fs, stream));
+      if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
+    }
   }
   // ---- graph plan: every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
   //      PATCH_LIFETIME frames of it (dpvo.py:305,362-375): counting-sort build over that window, bounds on the group counts
@@ -284,6 +316,16 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (rc) return rc;
   // ---- reproject -> correlation -> update operator (dpvo.py:331-343)
   STEP(dpvo_reproject(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->coords, E, a->P, 1, stream));
+  if (a->fs && a->ev_enc) {
+    if (hipStreamWaitEvent(st, (hipEvent_t)a->ev_enc, 0) != hipSuccess) return DPVO_E_INVALID;
+    // the encoders wrote the frame's feature map where the host EXPECTED its ring slot to be; a keyframe dropped in between moved
+    // the slot down by one (dpvo.py:289-299 shifts the ring, the new frame lands at n - 1)
+    if (a->fmap_spec && a->fmap_spec != a->fs->fmap &&
+        hipMemcpyAsync(const_cast<void*>(a->fs->fmap), a->fmap_spec, (size_t)K.ring[6].slot_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return DPVO_E_INVALID;
+    STEP(dpvo_frame_state_part(a->fs, 2, stream));
+    if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
+  }
   if (a->ev[0] && hipEventRecord((hipEvent_t)a->ev[0], st) != hipSuccess) return DPVO_E_INVALID;
   STEP(dpvo_corr_pyramid_forward(a->gmap, a->fmap1, a->fmap2, a->coords, K.kk, K.jj, nullptr, a->corr, 896, E, 128, a->P,
                                  (int64_t)a->pmem * M, a->mem, a->H0, a->W0, a->H1, a->W1, 3, stream));
@@ -303,15 +345,28 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
                a->iterations, nullptr, a->ws_ba, a->ws_ba_bytes, stream));
   // ---- point cloud, and the keyframe's flow test between frames k - 1 and k + 1 (dpvo.py:266-269), in one launch; then everything
   //      else of the keyframe step on the device
+  // Order (round 4): flow test + decision + index lists + RESULT RECORD first, the event the host waits for right behind them,
+  // then the point cloud and the gathers / ring shifts that execute the decision -- the host reads the record and enqueues the
+  // next frame while those two kernels (~36 us) still run, which is what used to be a bubble of the same length.  (The point cloud
+  // has to precede the ring shifts: it indexes the frames as update() left them, dpvo.py:358-360.)
   const int k = n - K.keyframe_index;
-  STEP(dpvo_point_cloud_motionmag(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, K.kk, a->plan, E, a->P, k - 1, k + 1,
-                                  a->mm_beta, a->result_dev, a->result_dev + 4, stream));
   dpvo_keyframe_step_t kf = K;
   kf.flow4 = a->result_dev;
   kf.result = reinterpret_cast<int32_t*>(a->result_dev + 8);
   kf.poses = a->poses;
   kf.host_words = 16;               // the host's copy carries the flow sums and the plan counters in front of the 8 result words
-  STEP(dpvo_keyframe_step(&kf, stream));
+  if ((kf.result_host && kf.host_words != 16) || !kf.keep_idx || !kf.rem_idx) return DPVO_E_INVALID;
+  {
+    dpvo_plan_layout_t PLy;
+    dpvo_plan_layout(E, &PLy);
+    const MotionPlanArgs F = {a->poses, a->patches, a->intrinsics, K.kk, a->plan + PLy.perm_p, a->plan + PLy.pair_off, a->plan + PLy.pair_ij,
+                              a->plan + PLy.counts + 1, a->P, k - 1, k + 1, a->mm_beta, a->result_dev, a->result_dev + 4};
+    kf_decide_launch(&kf, F, st);
+  }
+  if (a->ev_record && hipEventRecord((hipEvent_t)a->ev_record, st) != hipSuccess) return DPVO_E_INVALID;
+  STEP(dpvo_point_cloud(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, a->P, stream));
+  kf_apply_launch(&kf, st);
+  DPVO_LAUNCH_CHECK();
 #undef STEP
   return DPVO_OK;
 }

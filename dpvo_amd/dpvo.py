@@ -46,20 +46,19 @@ _FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
 # DPVO_ENC_AFTER_UPDATE=1: the side stream holds the next frame's encoders back until the current frame's update operator is
 # through, so that they run beside the small BA / keyframe kernels instead of beside the correlation / update kernels
 # The hold is a hipStreamWaitEvent, and while such a wait is pending a thread of the HIP runtime burns CPU (0.7 ms per frame when
-# the encoders are enqueued right behind the frame call).  The host therefore enqueues the side stream's work LATE: it sleeps until
-# DPVO_ENC_LEAD_US before the expected end of the update operator (= the running mean of the frame's duration minus DPVO_ENC_TAIL_US,
-# the BA / keyframe tail), so that the wait is pending for ~0.1 ms only.
+# the encoders are enqueued right behind the frame call).  The host therefore issues the wait LATE (DPVO._pace_hold: a feedback
+# on whether the event had already completed when the host got there); DPVO_ENC_LEAD_US < 0 switches the pacing off.
 _ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '1')))
 _ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '0'))      # -1: the whole side-stream batch (random draws, image
 #   normalisation, encoders) waits; k >= 0: only the encoder launches from number k on.  Round 4: 0 -- the three random draws and the
 #   image normalisation (~18 us of tiny kernels) run at once, only the convolutions are held: +0.5-2 % frames/sec and 50-90 us less
 #   host CPU per frame than -1 on one box (A/B/A/B, profiles/README.md r4), because the wait is issued inside the encoder call
-_ENC_TAIL_US = float(__import__('os').environ.get('DPVO_ENC_TAIL_US', '200'))
-_ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '120'))
+_ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '0'))
 _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
 _HOST_TRACE = [] if __import__('os').environ.get('DPVO_HOST_TRACE') else None      # (dev aid: host time stamps around the frame call)
 _PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
+_EARLY_RECORD = bool(int(__import__('os').environ.get('DPVO_EARLY_RECORD', '1')))      # 0: wait for the end of the whole frame call (round 3)
 _MAX_SLEEP_S = 2.0e-3      # no single pacing sleep is longer than this, whatever the running mean says
 _MAX_FRAME_S = 4.0e-3      # a wait longer than this is not a frame's GPU time (first frames, a paused caller): clamped in the mean
 
@@ -92,6 +91,8 @@ class DPVO:
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
         self._lr_active = 0         # long-range (loop-closure) edges in the active list: > 0 => update() owes a global BA (dpvo.py:348)
+        self._enc_done_ev = None    # the side stream's "encoders done" events (two, alternating)
+        self._fs_join = None        # (encoders-done event handle, speculative feature-map slot) handed to the next frame call
         self._loop_try = None       # this frame's PatchGraph.edges_loop() result when it was evaluated ahead of the frame call
         self.last_keyframe = None   # (decision, (sum_ij, count_ij, sum_ji, count_ji)) of the last resolved keyframe test
         self.device = torch.device(device)
@@ -529,7 +530,7 @@ class DPVO:
               "result": torch.zeros(16 + 3 * (cap // 1024 + 2), dtype=f32, device=dev),
               "host": [torch.zeros(16, dtype=f32).pin_memory() for _ in range(2)],
               "dpose": torch.zeros(2, 7, dtype=f32, device=dev),
-              "ev": [torch.cuda.Event() for _ in range(2)], "wait_ema": 0.0,
+              "ev": [torch.cuda.Event() for _ in range(2)], "wake": 0.0, "side": 0.0,
               "args": [L.FrameUpdate(), L.FrameUpdate()]}
         fu["host_i"] = [h.view(torch.int32).numpy() for h in fu["host"]]       # (views of the same pinned memory)
         fu["host_f"] = [h.numpy() for h in fu["host"]]
@@ -634,6 +635,10 @@ class DPVO:
             elif a.ev[2 * i] or a.ev[2 * i + 1]:
                 a.ev[2 * i] = a.ev[2 * i + 1] = None
         a.m = self.m
+        a.ev_enc = a.fmap_spec = None
+        if fs is not None and self._fs_join is not None:
+            a.ev_enc, a.fmap_spec = self._fs_join
+            self._fs_join = None
         if fs is not None:
             # ev_fs ("the frame state has read the encoder outputs"): what the NEXT frame's side-stream batch waits for before it
             # overwrites them -- unless that batch is held behind this call's update operator anyway (one marker less in the stream)
@@ -650,14 +655,40 @@ class DPVO:
                 a.ev_update_done, self._hold_event = self._upd_done.cuda_event, self._upd_done
         self._stamp(3)
         if _HOST_TRACE is not None: _HOST_TRACE.append(("call", __import__("time").perf_counter()))
+        # the event the host waits for is recorded INSIDE the call, as soon as the keyframe step's result record is final -- the
+        # point cloud and the gathers that execute the decision (~36 us) then run while the host reads the record and enqueues the
+        # next frame (round 3 recorded it here, behind the whole call: that stretch was an idle bubble of the same length)
+        ev = fu["ev"][par]
+        if not ev.cuda_event:
+            ev.record()                 # (creates the handle)
+        a.ev_record = ev.cuda_event if _EARLY_RECORD else None
         L.check(L.lib().dpvo_frame_update(ctypes.byref(a), L.stream()), "dpvo_frame_update")
+        if not _EARLY_RECORD:
+            ev.record()
         if _HOST_TRACE is not None: _HOST_TRACE.append(("ret", __import__("time").perf_counter()))
         self._stamp(4)
         es.net_pending = None           # (gathered by the operator's first kernel, rewritten compact by its last one)
-        ev = fu["ev"][par]
-        ev.record()
         self._plan = None
         self._fu_pending = (ev, fu["host"][par], par, n, E, __import__("time").perf_counter())
+
+    def _pace_hold(self, hold_ev):
+        """The wait of the side stream for `hold_ev` (behind the update operator of the frame in flight) costs a HIP runtime thread
+        its CPU time for as long as it is PENDING (0.7 ms per frame when issued right behind the frame call), so the host issues
+        it late: fu["side"] seconds after that call was enqueued.  Steered by what the host finds when it gets there -- the event
+        already complete: the encoders could have started earlier, issue 60 us sooner next time; still pending: 15 us later, but
+        never closer than 200 us to the expected result record -- instead of by a running mean of the frame duration, which the
+        delay it causes feeds back into."""
+        if _ENC_LEAD_US < 0 or self._fu is None or self._fu_pending is None:
+            return
+        import time
+        fu = self._fu
+        rest = min(self._fu_pending[5] + fu["side"] - time.perf_counter(), _MAX_SLEEP_S)
+        if rest > 6e-5 and not hold_ev.query():
+            time.sleep(rest - 3e-5)
+        if hold_ev.query():
+            fu["side"] = max(0.0, fu["side"] - 6e-5)
+        else:
+            fu["side"] = max(0.0, min(fu["side"] + 1.5e-5, fu["wake"] - 2e-4))
 
     def _frame_update_finish(self, ev, host, flip, n, E, t_enq):
         """the host side of the keyframe step whose device side dpvo_keyframe_step has already executed (dpvo.py:266-310)"""
@@ -666,18 +697,25 @@ class DPVO:
         # the start would burn a host core per tracker for nothing.
         import time
         fu = self._fu
-        # (the running mean only ever holds GPU-bound durations: a sample is taken when the host actually had to wait, and is
-        #  clamped -- a caller that pauses between frames must not teach the tracker to sleep through its next frames)
-        waited = not ev.query()
-        if _BLOCKING_SYNC and waited:
-            rest = min(fu["wait_ema"] - (time.perf_counter() - t_enq), _MAX_SLEEP_S)
-            if rest > 2.5e-4:
-                time.sleep(rest - 2.0e-4)
-        ev.synchronize()
+        # Pacing without a running mean of frame durations (rounds 2-3 used one; it fed back on itself: a late wake-up or a late encoder
+        # batch lengthens the very duration it is derived from).  fu["wake"] = how long after the call was enqueued this wait wakes
+        # up, steered by what it finds: the record already there -> wake 80 us earlier next time; otherwise half of the time it then
+        # spends in the event wait beyond a 100 us margin is added.  Nothing is learnt from a frame the caller arrived late for, and
+        # no single sleep exceeds _MAX_SLEEP_S (a paused caller must not teach the tracker to sleep through frames).
+        if _BLOCKING_SYNC and not ev.query():
+            rest = min(fu["wake"] - (time.perf_counter() - t_enq), _MAX_SLEEP_S)
+            if rest > 6e-5:
+                time.sleep(rest - 3e-5)
+            t_wake = time.perf_counter()
+            late = ev.query()
+            ev.synchronize()
+            if late:
+                fu["wake"] = max(0.0, fu["wake"] - 8e-5)
+            else:
+                fu["wake"] = min(max(0.0, fu["wake"] + 0.5 * (time.perf_counter() - t_wake - 1e-4)), _MAX_FRAME_S)
+        else:
+            ev.synchronize()
         if _HOST_TRACE is not None: _HOST_TRACE.append(("sync", time.perf_counter()))
-        if waited:
-            sample = min(time.perf_counter() - t_enq, _MAX_FRAME_S)
-            fu["wait_ema"] = 0.8 * fu["wait_ema"] + 0.2 * sample if fu["wait_ema"] else sample
         # (numpy views of the pinned record: this stretch of host code runs while the GPU has nothing to do)
         hi = fu["host_i"][flip]
         decision, n_keep, n_rem, e_in, overflow = int(hi[8]), int(hi[9]), int(hi[10]), int(hi[11]), int(hi[12])
@@ -870,13 +908,8 @@ class DPVO:
             hold_ev = None
             if _ENC_AFTER_UPDATE and getattr(self, "_hold_event", None) is not None and self._fu_pending is not None:
                 hold_ev = self._hold_event
-                ema_ = self._fu["wait_ema"]
-                if ema_ > 0 and _ENC_LEAD_US >= 0 and not hold_ev.query():      # (already through: nothing to wait out)
-                    import time
-                    rest_ = min(self._fu_pending[5] + ema_ - 1e-6 * (_ENC_TAIL_US + _ENC_LEAD_US) - time.perf_counter(), _MAX_SLEEP_S)
-                    if rest_ > 6e-5:
-                        time.sleep(rest_ - 5e-5)
                 if _ENC_HOLD_AT < 0:
+                    self._pace_hold(hold_ev)
                     side.wait_event(hold_ev)
                     hold_ev = None
             # the caller's stream may still be producing / uploading the image (torch.from_numpy(img).cuda() from pageable
@@ -912,23 +945,31 @@ class DPVO:
                 if self._imap_full is None:
                     self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
                 if side is not None and hold_ev is not None:
+                    self._pace_hold(hold_ev)
                     self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full, hold_event=hold_ev, hold_at=_ENC_HOLD_AT)
                 else:
                     self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
                 self._stamp(2)
                 if side is not None:
-                    enc_done = torch.cuda.Event()
+                    if self._enc_done_ev is None:
+                        self._enc_done_ev = [torch.cuda.Event(), torch.cuda.Event()]      # (two, alternating: one may still be awaited)
+                    enc_done = self._enc_done_ev[self.counter & 1]
                     enc_done.record(side)
+        join = None
         if hip_enc:
             n_spec = self.n
             self.flush()                        # the previous frame's keyframe decision, now that the GPU has the encoders to chew on
-            if side is not None:
-                # (after the host has waited, when the encoders are through: issued earlier, the wait would be PENDING for the
-                #  encoders' whole run and a cross-stream wait that is pending costs a runtime thread its CPU time, 0.3 ms per frame)
-                main_stream.wait_event(enc_done)
+            slot_spec = slot
             if self.n != n_spec:                # that keyframe was dropped: the new frame lives one slot lower
-                self._fmap1_cl[self.n % self.mem].copy_(slot)
                 slot = self._fmap1_cl[self.n % self.mem]
+
+            def join():
+                """order the main stream behind the side stream's encoders (and move the feature map if its slot changed).  The
+                one-call frame path does both inside dpvo_frame_update, behind the plan and the reprojection, instead"""
+                if side is not None:
+                    main_stream.wait_event(enc_done)
+                if slot is not slot_spec:
+                    slot.copy_(slot_spec)
             maps = (slot, self._imap_full)
         self.flush()
 
@@ -1007,12 +1048,20 @@ class DPVO:
                 # (the one-call frame path issues it itself, in front of the plan: no Python between the two)
                 fs_deferred = fs if fast_call else None
                 if fs_deferred is None:
+                    join()
                     L.check(L.lib().dpvo_frame_state(ctypes.byref(fs), L.stream()), "dpvo_frame_state")
                     assert fs.n_new == total
+                else:
+                    # the frame call waits for the encoders itself, behind its plan and reprojection (dpvo_frame_update_t.ev_enc)
+                    self._fs_join = (enc_done.cuda_event if side is not None else None,
+                                     slot_spec.data_ptr() if slot is not slot_spec else None)
+                    if side is None and slot is not slot_spec:
+                        join()
                 es.appended_frame(n + 1, self.M, self.cfg.PATCH_LIFETIME, total)
                 self._plan = None
                 appended = True
             else:
+                join()
                 L.check(L.lib().dpvo_frame_patches(
                     L.ptr(maps[0]), L.ptr(maps[1]), L.ptr(image_u8), L.ptr(cdev), L.ptr(xs), L.ptr(ys), L.ptr(depth),
                     L.ptr(intr_dev), L.f32(self.RES), L.row_ptr(self._gmap_cl, n % self.pmem),
@@ -1043,6 +1092,8 @@ class DPVO:
                 elif not self._fp_done.cuda_event:
                     self._fp_done.record()              # (creates the handle; re-recorded behind dpvo_frame_state inside the call)
         else:
+            if join is not None:
+                join()
             fmap, gmap, imap, patches, _, coords = \
                 self.network.patchify(img32 if img32 is not None else img16,
                                       patches_per_image=self.cfg.PATCHES_PER_FRAME,

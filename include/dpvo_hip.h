@@ -294,6 +294,9 @@ typedef struct {
   int32_t M, h, w, H, W, CF, CI, P, mm_n, md_n, ap_n, ap_r, D;
 } dpvo_frame_state_t;
 int dpvo_frame_state(dpvo_frame_state_t* p, void* stream);
+/* part 0: the same; part 1: only what does not read fmap / imap (coordinate + depth patches, colours, intrinsics, index rows, motion
+ * model, depth median, the new edges); part 2: only what does (gmap / imap gathers, pyramid level 1). */
+int dpvo_frame_state_part(dpvo_frame_state_t* p, int part, void* stream);
 
 
 /* Update.forward (dpvo/net.py:74-92) as SEVEN launches of row-tile-resident MFMA kernels (dpvo_amd/csrc/update_fused.hip): a workgroup keeps
@@ -388,7 +391,8 @@ int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream);
 /* dpvo_frame_update: DPVO.update() + DPVO.keyframe() of one steady-state frame (dpvo.py:328-360,266-310) as ONE call -- with
  * LOOP_CLOSURE too (kf.loop_closure = 1) in every frame that neither appends loop-closure edges nor has long-range edges active
  * (result word [5] of the previous step == 0): the local-BA branch of dpvo.py:351-354 is the one this entry runs -- graph plan (window build, ranged fallback), reproject, two-level correlation, update operator (seven
- * launches), two local BA iterations, point cloud, flow test, dpvo_keyframe_step, result copy.  Every pointer is a caller
+ * launches), two local BA iterations, flow test + keyframe decision + result record (ev_record), point cloud, the keyframe step's
+ * gathers / ring shifts.  Every pointer is a caller
  * buffer (capacity buffers + workspaces sized with the *_workspace_bytes functions for E); ev[0..3] (hipEvent_t or NULL) are
  * recorded before / after the correlation kernel and before / after the update operator (roofline measurement).
  * result_dev: 16 words -- [0..3] flow sums, [4..7] plan counters (float), [8..15] the dpvo_keyframe_step result -- followed by
@@ -398,6 +402,15 @@ int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream);
 typedef struct {
   dpvo_keyframe_step_t kf;          /* edge arrays, rings, decision parameters; kf.flow4 / kf.result are set by the call */
   dpvo_frame_state_t* fs; void* ev_fs;
+  void* ev_enc; const void* fmap_spec;
+                                    /* ev_enc: hipEvent_t or NULL.  Not NULL (needs fs): an event of ANOTHER stream behind the producer of
+                                       fs->fmap / fs->imap (the encoders); the call then issues the part of the frame state that does not read
+                                       them, the plan and the reprojection first, waits for the event, and only then gathers gmap / imap and
+                                       pools pyramid level 1.  fmap_spec: where the encoders wrote the feature map if that is not the frame's
+                                       ring slot (a keyframe dropped since they were enqueued): copied into the slot behind the wait */
+  void* ev_record;                  /* hipEvent_t or NULL: recorded as soon as the keyframe step's RESULT RECORD is final (behind its
+                                       select kernel; the point cloud and the gathers that execute the decision follow): what the host
+                                       waits for before it reads result_host and enqueues the next frame */
   void* ev_update_done;             /* hipEvent_t or NULL: recorded behind the update operator (the caller's side stream may hold the
                                        next frame's encoders back until the two chip-filling kernels are through) */
   int32_t fs_auto;                  /* != 0: the call fills the fields of *fs that depend on the frame number (ring slots, index rows,
