@@ -390,7 +390,7 @@ def main():
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
                          for i, r in enumerate(res["per_rank"])],
             "placement": {"backend": backend if world > 1 else None, "devices_visible": n_dev, "host_cores_allowed": len(allowed) if allowed else None,
-                          "rank0_pinned_to": pinned, "cores_per_rank": len(cpus)},
+                          "rank0_pinned_to": (f"{pinned[0]}-{pinned[-1]} ({len(pinned)} cores)" if pinned else None), "cores_per_rank": len(cpus)},
         }
         # the tracker state after the run: with random weights nothing guarantees that it stays sane, and a diverged state
         # (NaN poses, every edge projecting out of bounds) would make the correlation kernel skip its work

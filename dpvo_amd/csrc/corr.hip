@@ -120,18 +120,29 @@ __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fma
     __syncthreads();
     CORR_T(2 + 2 * level);
     const int np = bw * bh;
-#pragma unroll 4
-    for (int s = 0; s < 7; ++s) {
-      const int q = lane + 64 * s;
-      if (q < CORR_NOUT) {
-        const int bx = q / 63, rem = q - bx * 63, ay = rem / 9, p = rem - ay * 9;
-        const float ddx = meta_f[p], ddy = meta_f[16 + p];
-        const float* rp = raw + p * np + (meta_i[16 + p] + ay) * bw + meta_i[p] + bx;
-        float o = (1.f - ddx) * (1.f - ddy) * rp[0];
-        o += ddx * (1.f - ddy) * rp[1];
-        o += (1.f - ddx) * ddy * rp[bw];
-        o += ddx * ddy * rp[bw + 1];
-        orow[2 * q + level] = (_Float16)o;
+    // Blend (correlation_kernel.cu:221-230): lane = (patch pixel p = lane % 9, window column bx = lane / 9) walks the 7 window
+    // rows ay of its column.  Its four weights are computed once, every raw row is read once (the lower pair of row ay is the
+    // upper pair of row ay + 1), no index arithmetic is left inside the loop -- rounds 1-3 gave every lane 7 arbitrary outputs
+    // (q = lane + 64 s: two integer divisions, six LDS look-ups and the weight products PER OUTPUT): ~280 of the kernel's 815
+    // VALU instructions per edge and level, in a kernel that tools/corr_variants.sh shows to be bound by exactly those (with every
+    // window load served cache-hot it still takes 187 of its 270 us).  Same products, same order of additions: same bits.
+    if (lane < 63) {
+      const int p = lane % 9, bx = lane / 9;
+      const float ddx = meta_f[p], ddy = meta_f[16 + p];
+      const float w00 = (1.f - ddx) * (1.f - ddy), w01 = ddx * (1.f - ddy), w10 = (1.f - ddx) * ddy, w11 = ddx * ddy;
+      const float* rp = raw + p * np + meta_i[16 + p] * bw + meta_i[p] + bx;
+      _Float16* op = orow + 2 * (bx * 63 + p) + level;          // q = (bx * 7 + ay) * 9 + p
+      float a0 = rp[0], a1 = rp[1];
+#pragma unroll
+      for (int ay = 0; ay < 7; ++ay) {
+        rp += bw;
+        const float b0 = rp[0], b1 = rp[1];
+        float o = w00 * a0;
+        o += w01 * a1;
+        o += w10 * b0;
+        o += w11 * b1;
+        op[18 * ay] = (_Float16)o;
+        a0 = b0; a1 = b1;
       }
     }
     __syncthreads();
@@ -210,9 +221,23 @@ __global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel(
     { float s0 = cx + (float)a[0][0]; asm volatile("" :: "v"(s0)); }        // (stamp 1 = indices, coordinates and templates have landed)
 #endif
     CORR_T(1);
+    // CORR_VARIANT (measurement builds only, tools/corr_variants.sh; results are wrong on purpose): 1 = level 0 only, 2 = level 1
+    // only, 4 = level 1 reads one fixed cache-hot window (what a level-1 tile shared through LDS could save at best), 5 = both do
+#if !defined(CORR_VARIANT) || CORR_VARIANT != 2
+  #if defined(CORR_VARIANT) && CORR_VARIANT == 5
+    corr_level(a, fmap0, H0, W0, 20.f + (cx - floorf(cx)), 20.f + (cy - floorf(cy)), raw, meta_i, meta_f, lane, orow, 0);
+  #else
     corr_level(a, fmap0 + (int64_t)v * H0 * W0 * CORR_C, H0, W0, cx, cy, raw, meta_i, meta_f, lane, orow, 0);
+  #endif
+#endif
     CORR_T(3);
+#if !defined(CORR_VARIANT) || CORR_VARIANT != 1
+  #if defined(CORR_VARIANT) && (CORR_VARIANT == 4 || CORR_VARIANT == 5)
+    corr_level(a, fmap1, H1, W1, 10.f + (cx * 0.25f - floorf(cx * 0.25f)), 10.f + (cy * 0.25f - floorf(cy * 0.25f)), raw, meta_i, meta_f, lane, orow, 1);
+  #else
     corr_level(a, fmap1 + (int64_t)v * H1 * W1 * CORR_C, H1, W1, cx * 0.25f, cy * 0.25f, raw, meta_i, meta_f, lane, orow, 1);
+  #endif
+#endif
     CORR_T(5);
     // coalesced row store: 441 packed (level0, level1) words
     const uint32_t* src = reinterpret_cast<const uint32_t*>(orow);
