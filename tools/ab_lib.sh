@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../dpvo_amd/csrc"
 sfx=${2:-ab}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $1 -c update_fused.hip -o /tmp/uf_$sfx.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libdpvo_hip_$sfx.so corr.o geom.o graph.o /tmp/uf_$sfx.o ba.o ba_global.o frontend.o encoder.o track.o capi.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libdpvo_hip_$sfx.so corr.o geom.o graph.o /tmp/uf_$sfx.o ba.o ba_global.o chol.o frontend.o encoder.o track.o capi.o
 echo built ../libdpvo_hip_$sfx.so with "$1"
