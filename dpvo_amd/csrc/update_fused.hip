@@ -631,8 +631,12 @@ extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, c
 
 
 #define FU_RT 3
+#ifndef FU_DW
 #define FU_DW 6
+#endif
+#ifndef FU_DW7
 #define FU_DW7 6
+#endif
 #ifndef FU_DW1
 #define FU_DW1 6
 #endif

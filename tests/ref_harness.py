@@ -167,6 +167,7 @@ def summarise(recs):
                    target_max=max((r.get("target_max", 0.0) for r in ok), default=None),
                    weight_max=max((r.get("weight_max", 0.0) for r in ok), default=None),
                    pose_max_first28=max((r["pose_max"] for r in ok if r["t"] < 28), default=None),
+                   pose_max_first24=max((r["pose_max"] for r in ok if r["t"] < 24), default=None),
                    pose_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}")] for r in ok[::4]])
     dec = [(r["t"], r["drop_ours"], r["drop_ref"], r["flow_ours"], r["flow_ref"]) for r in recs if r.get("flow_ref") is not None]
     out["decisions"] = len(dec)
