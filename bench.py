@@ -37,6 +37,7 @@ The JSON line also carries
                   same steady state (E = 45 312): frames/sec over 20 frames, rank 0 at N = 1 only; null when oracle/_ref is absent.
                   A reported baseline (the only same-node comparator north_star's ">= reference frames/sec" has), never `value`;
   box          -- the shader clock this box sustains under a full-chip / quarter-chip MFMA load (tools/probes/clock_probe.hip);
+  frame_period_ms -- device-side frame period (correlation start to correlation start) over the timed frames: median, p90, max;
   state        -- whether the tracker state after the run is sane (finite poses, fraction of edges that project in
                   bounds): with random weights nothing guarantees that, and a diverged state would make the correlation
                   kernel skip its work; such a run carries an "error" field.
@@ -342,6 +343,14 @@ def main():
 
     corr_ms = [s.elapsed_time(e) for s, e, _ in prof]
     corr_edges = [n for _, _, n in prof]
+    # frame-to-frame period on the device (start of one frame's correlation kernel to the next one's): with 20-60 timed frames one
+    # hiccup moves `value` by several per cent -- the median says what the steady state is, the max what the hiccup was
+    period = None
+    if len(prof) > 2:
+        raw = [prof[i][0].elapsed_time(prof[i + 1][0]) for i in range(len(prof) - 1)]
+        per = sorted(raw)
+        period = {"median": round(per[len(per) // 2], 4), "p90": round(per[int(0.9 * (len(per) - 1))], 4), "max": round(per[-1], 4),
+                  "max_at_frame": raw.index(per[-1]) + 1, "frames_per_sec_at_median": round(1e3 / per[len(per) // 2], 1)}
     roof = None
     if corr_ms:
         avg_ms = sum(corr_ms) / len(corr_ms)
@@ -386,6 +395,7 @@ def main():
                                    f"steady state E={E_now} edges, random-init weights, one sequence per GPU",
                        "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "drop_every": args.drop_every, "parallelism": f"replicas x{world}" + ("" if backend == "nccl" or world == 1 else
                                                                 f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
+            "frame_period_ms": period,
             "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg, "with_loop_closure": lc_leg,
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
                          for i, r in enumerate(res["per_rank"])],

@@ -361,7 +361,11 @@ class PatchGraph:
         ### edge information: preallocated stores, exposed under the reference's attribute names ###
         self.edges = EdgeStore(DIM, dev, with_state=True, mirror=True)
         ### inactive edge information (i.e., no longer updated, but useful for BA) ###
-        self.edges_inac = EdgeStore(DIM, dev, with_state=False, cap=1 << 17)
+        # sized for the whole buffer up front when that is affordable (every keyframe eventually retires its ~2 * PATCH_LIFETIME * M
+        # edges here, remove_factors(store=True): 40 B per edge, 0.4 GB for the default 4096-frame buffer on a 288 GB device): growing
+        # it by doubling allocates -- a device-wide sync -- in the middle of a tracked frame (a 0.3 ms hiccup once per doubling)
+        per_frame = 2 * int(getattr(self.cfg, "PATCH_LIFETIME", 13)) * self.M
+        self.edges_inac = EdgeStore(DIM, dev, with_state=False, cap=max(1 << 17, min(self.N * per_frame, 1 << 24)))
 
     # active edges (views of the store; assignment copies into it, in-place ops on the views work as in the reference)
     ii = property(lambda self: self.edges.view("ii"), lambda self, v: self.edges.assign("ii", v))
