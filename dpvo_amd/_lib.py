@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPVO_HIP_LIB") or os.path.join(_HERE, "libdpvo_hip.so")      # (override: development builds)
 
 F16, F32 = 0, 1
-ABI_VERSION = 4         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
+ABI_VERSION = 5         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
 
 # every symbol include/dpvo_hip.h declares (tests/test_capi.py checks the .so exports all of them)
 SYMBOLS = [
@@ -80,6 +80,7 @@ class FrameUpdate(ctypes.Structure):
     _fields_ = ([("kf", KeyframeStep), ("fs", ctypes.c_void_p), ("ev_fs", ctypes.c_void_p), ("ev_enc", ctypes.c_void_p),
                  ("fmap_spec", ctypes.c_void_p), ("ev_record", ctypes.c_void_p),
                  ("ev_update_done", ctypes.c_void_p),
+                 ("plan_stream", ctypes.c_void_p), ("ev_plan_fork", ctypes.c_void_p), ("ev_plan_done", ctypes.c_void_p),
                  ("fs_auto", ctypes.c_int32),
                  ("index_map", ctypes.c_void_p), ("net", ctypes.c_void_p), ("net_rows", ctypes.c_void_p), ("n_kept", ctypes.c_int64)] +
                 [(k, ctypes.c_void_p) for k in ("poses", "patches", "intrinsics", "points", "ix", "gmap", "fmap1", "fmap2",

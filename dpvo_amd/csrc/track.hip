@@ -310,9 +310,21 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   const int64_t ub_p = nf * M, ub_g = nf * (2 * PL + 2);
   const int64_t np_ub = ub_p < E ? ub_p : E, ng_ub = ub_g < E ? ub_g : E;
   const int64_t flo = n - (RW + PL + 3) > 0 ? n - (RW + PL + 3) : 0;
-  rc = dpvo_plan_build_window(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M, stream);
+  // Nothing in front of the update operator's second kernel reads the plan, so with a second stream at hand its five launches
+  // (~36 us of dependent-launch latency, 45 workgroups each) run beside the reprojection, part 2 of the frame state and the start
+  // of the correlation kernel instead of in front of them
+  const bool plan_aside = a->plan_stream && a->ev_plan_fork && a->ev_plan_done;
+  if ((a->plan_stream || a->ev_plan_fork || a->ev_plan_done) && !plan_aside) return DPVO_E_INVALID;
+  void* pst = stream;
+  if (plan_aside) {
+    pst = a->plan_stream;
+    if (hipEventRecord((hipEvent_t)a->ev_plan_fork, st) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)pst, (hipEvent_t)a->ev_plan_fork, 0) != hipSuccess) return DPVO_E_INVALID;
+  }
+  rc = dpvo_plan_build_window(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M, pst);
   if (rc == DPVO_E_UNSUPPORTED)
-    rc = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, stream);
+    rc = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, pst);
+  if (plan_aside && hipEventRecord((hipEvent_t)a->ev_plan_done, (hipStream_t)pst) != hipSuccess) return DPVO_E_INVALID;
   if (rc) return rc;
   // ---- reproject -> correlation -> update operator (dpvo.py:331-343)
   STEP(dpvo_reproject(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->coords, E, a->P, 1, stream));
@@ -331,6 +343,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
                                  (int64_t)a->pmem * M, a->mem, a->H0, a->W0, a->H1, a->W1, 3, stream));
   if (a->ev[1] && hipEventRecord((hipEvent_t)a->ev[1], st) != hipSuccess) return DPVO_E_INVALID;
   if (a->ev[2] && a->ev[2] != a->ev[1] && hipEventRecord((hipEvent_t)a->ev[2], st) != hipSuccess) return DPVO_E_INVALID;   // (one record serves both)
+  if (plan_aside && hipStreamWaitEvent(st, (hipEvent_t)a->ev_plan_done, 0) != hipSuccess) return DPVO_E_INVALID;
   float* net = a->net;
   float* target = const_cast<float*>(K.target);
   float* weight = const_cast<float*>(K.weight);

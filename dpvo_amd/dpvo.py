@@ -58,6 +58,7 @@ _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
 _HOST_TRACE = [] if __import__('os').environ.get('DPVO_HOST_TRACE') else None      # (dev aid: host time stamps around the frame call)
 _PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
+_PLAN_ASIDE = bool(int(__import__('os').environ.get('DPVO_PLAN_ASIDE', '1')))          # 0: the graph plan in front of the reprojection, on the compute stream (rounds 1-3)
 _EARLY_RECORD = bool(int(__import__('os').environ.get('DPVO_EARLY_RECORD', '1')))      # 0: wait for the end of the whole frame call (round 3)
 _MAX_SLEEP_S = 2.0e-3      # no single pacing sleep is longer than this, whatever the running mean says
 _MAX_FRAME_S = 4.0e-3      # a wait longer than this is not a frame's GPU time (first frames, a paused caller): clamped in the mean
@@ -653,6 +654,17 @@ class DPVO:
                 a.ev_update_done, self._hold_event = None, fu["ev_upd_end"]
             else:
                 a.ev_update_done, self._hold_event = self._upd_done.cuda_event, self._upd_done
+        # the plan's five launches go to the side stream (behind whatever the encoders have queued there) when there is one: only
+        # the update operator's second kernel needs them (dpvo_frame_update_t.plan_stream)
+        if _PLAN_ASIDE and self._enc_stream is not None:
+            evs = fu.get("ev_plan")
+            if evs is None:
+                evs = fu["ev_plan"] = [torch.cuda.Event(), torch.cuda.Event()]
+                for e_ in evs:
+                    e_.record()         # (creates the handles)
+            a.plan_stream, a.ev_plan_fork, a.ev_plan_done = self._enc_stream.cuda_stream, evs[0].cuda_event, evs[1].cuda_event
+        else:
+            a.plan_stream = a.ev_plan_fork = a.ev_plan_done = None
         self._stamp(3)
         if _HOST_TRACE is not None: _HOST_TRACE.append(("call", __import__("time").perf_counter()))
         # the event the host waits for is recorded INSIDE the call, as soon as the keyframe step's result record is final -- the

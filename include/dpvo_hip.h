@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version: bumped on ANY change of a signature, a struct layout or the exported set (round 3 changed all three without a
  * bump: ADVICE r3).  The Python binding refuses a library whose version differs from the one it was written against. */
-#define DPVO_ABI_VERSION 4
+#define DPVO_ABI_VERSION 5
 int dpvo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -413,6 +413,13 @@ typedef struct {
                                        waits for before it reads result_host and enqueues the next frame */
   void* ev_update_done;             /* hipEvent_t or NULL: recorded behind the update operator (the caller's side stream may hold the
                                        next frame's encoders back until the two chip-filling kernels are through) */
+  void *plan_stream, *ev_plan_fork, *ev_plan_done;
+                                    /* all three set (a second hipStream_t of the caller and two hipEvent_t) or all NULL.  Set: the graph
+                                       plan -- five launches that only the update operator's SECOND kernel, the BA and the flow test read
+                                       -- is issued on plan_stream behind ev_plan_fork (recorded on `stream` behind the new frame's edges)
+                                       and joined through ev_plan_done in front of the update operator: reprojection and correlation
+                                       do not wait for it.  plan_stream may be the stream the encoders run on: the plan goes behind
+                                       whatever that stream already holds */
   int32_t fs_auto;                  /* != 0: the call fills the fields of *fs that depend on the frame number (ring slots, index rows,
                                        edge arrays and counts) from kf.ring[] (order: colours, poses, patches, intrinsics, imap, gmap,
                                        fmap1, fmap2), index_map and the counters; the caller sets the per-frame inputs only */
