@@ -22,7 +22,7 @@ SYMBOLS = [
     "dpvo_corr_forward", "dpvo_corr_pyramid_forward", "dpvo_patchify_forward", "dpvo_patchify_bilinear",
     "dpvo_reproject", "dpvo_flow_mag", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud", "dpvo_point_cloud_motionmag",
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
-    "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window",
+    "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window", "dpvo_plan_build_window_flow",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
     "dpvo_softagg",
     "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_default_tiling",
@@ -95,7 +95,7 @@ class FrameUpdate(ctypes.Structure):
 class PlanLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int64) for n in
                 ("perm_k", "ku", "kx", "patch_off", "ix", "jx", "perm_p", "pu", "pair_off", "pair_ij", "counts",
-                 "total_ints")]
+                 "total_ints", "flow")]
 
 
 _lib = None

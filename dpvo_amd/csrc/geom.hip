@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void motionmag_kernel(const float* __restrict
                                                          const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
                                                          int64_t E, int P, int64_t qi, int64_t qj, float beta,
                                                          float* __restrict__ out) {
-  __shared__ float red[4][1024];
+  __shared__ float red[4][16];
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int64_t e = threadIdx.x; e < E; e += 1024) {
     const int64_t i = ii[e], j = jj[e];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void motionmag_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void motionmag_plan_kernel(MotionPlanArgs A) {
-  motionmag_plan_body(A.poses, A.patches, A.intr, A.kk, A.perm_p, A.pair_off, A.pair_ij, A.n_pairs, A.P, A.qi, A.qj, A.beta, A.out, A.status);
+  motionmag_plan_body(A.poses, A.patches, A.intr, A.kk, A.perm_p, A.pair_off, A.pair_ij, A.n_pairs, A.P, A.qi, A.qj, A.beta, A.out, A.status, A.flow);
 }
 
 // pops.point_cloud centre pixel, dpvo.py:358-360.
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void point_cloud_motionmag_kernel(const float*
                                                                     const float* __restrict__ intr, const int64_t* __restrict__ ix,
                                                                     float* __restrict__ points, int64_t m, int P, MotionPlanArgs A) {
   if (blockIdx.x == gridDim.x - 1)
-    motionmag_plan_body(A.poses, A.patches, A.intr, A.kk, A.perm_p, A.pair_off, A.pair_ij, A.n_pairs, A.P, A.qi, A.qj, A.beta, A.out, A.status);
+    motionmag_plan_body(A.poses, A.patches, A.intr, A.kk, A.perm_p, A.pair_off, A.pair_ij, A.n_pairs, A.P, A.qi, A.qj, A.beta, A.out, A.status, A.flow);
   else
     point_cloud_body(poses, patches, intr, ix, points, m, P, blockIdx.x, gridDim.x - 1);
 }
@@ -294,7 +294,7 @@ extern "C" int dpvo_motionmag_status(const float* poses, const float* patches, c
     dpvo_plan_layout_t PL;
     dpvo_plan_layout(E, &PL);
     const MotionPlanArgs A = {poses, patches, intrinsics, kk, plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, plan + PL.counts + 1,
-                              P, (int)i, (int)j, beta, out4, status4};
+                              P, (int)i, (int)j, beta, out4, status4, plan + PL.flow};
     hipLaunchKernelGGL(motionmag_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
   } else
   hipLaunchKernelGGL(motionmag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, poses, patches, intrinsics, ii, jj,
@@ -310,7 +310,7 @@ extern "C" int dpvo_point_cloud_motionmag(const float* poses, const float* patch
   dpvo_plan_layout_t PL;
   dpvo_plan_layout(E, &PL);
   const MotionPlanArgs A = {poses, patches, intrinsics, kk, plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, plan + PL.counts + 1,
-                            P, (int)i, (int)j, beta, out4, status4};
+                            P, (int)i, (int)j, beta, out4, status4, plan + PL.flow};
   hipLaunchKernelGGL(point_cloud_motionmag_kernel, dim3(grid_for(m) + 1), dim3(256), 0, (hipStream_t)stream, poses, patches,
                      intrinsics, ix, points, m, P, A);
   DPVO_LAUNCH_CHECK();

@@ -19,7 +19,8 @@ constexpr int kKeyShift = 24;   // generic path: jj (frame index) < 2^24; BUFFER
 template <typename K>
 __global__ void make_keys_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
                                  const int64_t* __restrict__ kk, K* __restrict__ keysA, K* __restrict__ keysB,
-                                 int32_t* __restrict__ vals, int64_t E, int shift) {
+                                 int32_t* __restrict__ vals, int64_t E, int shift, int32_t* __restrict__ flow) {
+  if (flow && blockIdx.x == 0 && threadIdx.x < 4) flow[threadIdx.x] = threadIdx.x < 2 ? -1 : 0;      // (no flow-test list from this builder)
   const K lomask = ((K)1 << shift) - 1;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
     const K lo = (K)jj[e] & lomask;
@@ -130,6 +131,7 @@ struct WinArgs {
   int32_t *perm_k, *perm_p, *flag;      // flag: ids outside the window were seen (lives next to tot, copied to counts[3])
   int32_t* gid;                         // [kWinBins]: number of non-empty bins before a bin = its group index
   int32_t *ku, *kx, *patch_off, *ix, *jx, *pu, *pair_off, *pair_ij, *counts;
+  int32_t* flow; int qi, qj;            // flow-test list of the pair (qi, qj) / (qj, qi): dpvo_plan_layout_t.flow
 };
 
 __device__ __forceinline__ void win_bins(const WinArgs& W, int64_t e, int& ba, int& bb, bool& bad) {
@@ -140,9 +142,10 @@ __device__ __forceinline__ void win_bins(const WinArgs& W, int64_t e, int& ba, i
   bb = ic * W.nfw + jc;
 }
 
-__global__ __launch_bounds__(1024) void win_zero_kernel(int32_t* __restrict__ p, int n) {
+__global__ __launch_bounds__(1024) void win_zero_kernel(int32_t* __restrict__ p, int n, int32_t* __restrict__ flow, int qi, int qj) {
   const int i = blockIdx.x * 1024 + threadIdx.x;
   if (i < n) p[i] = 0;
+  if (i < 4) flow[i] = i == 0 ? qi : (i == 1 ? qj : 0);
 }
 
 __global__ __launch_bounds__(1024) void win_hist_kernel(WinArgs W) {
@@ -273,10 +276,21 @@ __global__ __launch_bounds__(1024) void win_scatter_kernel(WinArgs W) {
     // frame-pair group structures: the bins are in (i, j) order already
     const int g = W.gid[kWinA + bb];
     W.pu[e] = g;
-    if (pb == W.binstart[kWinA + bb]) {
+    const int bs = W.binstart[kWinA + bb];
+    const int32_t fi = (int32_t)W.ii[e], fj = (int32_t)W.jj[e];
+    if (pb == bs) {
       W.pair_off[g] = pb;
-      W.pair_ij[2 * g] = (int32_t)W.ii[e];
-      W.pair_ij[2 * g + 1] = (int32_t)W.jj[e];
+      W.pair_ij[2 * g] = fi;
+      W.pair_ij[2 * g + 1] = fj;
+    }
+    // the flow test's pair: its edges in edge order (the scatter is stable), and how many there are
+    if (W.qi >= 0) {
+      const int dirn = (fi == W.qi && fj == W.qj) ? 0 : ((fi == W.qj && fj == W.qi) ? 1 : -1);
+      if (dirn >= 0) {
+        const int r = pb - bs;
+        if (r < DPVO_PLAN_FLOW_CAP) W.flow[4 + dirn * DPVO_PLAN_FLOW_CAP + r] = (int32_t)W.kk[e];
+        if (r == 0) W.flow[2 + dirn] = W.binstart[kWinA + bb + 1] - bs;
+      }
     }
   }
 }
@@ -351,7 +365,7 @@ int build_plan(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t 
   K* keys_out = (K*)(w + L.keys_out);
   int32_t* vals_in = (int32_t*)(w + L.vals_in);
   hipLaunchKernelGGL(make_keys_kernel<K>, dim3(grid_for(E)), dim3(256), 0, st, ii, jj, kk, (which & 1) ? keys_a : (K*)nullptr,
-                     (which & 2) ? keys_b : (K*)nullptr, vals_in, E, shift);
+                     (which & 2) ? keys_b : (K*)nullptr, vals_in, E, shift, plan + P.flow);
   if (which & 1) {      // sort by (kk, jj, edge)
     size_t tb = L.temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_a, keys_out, vals_in, plan + P.perm_k, (size_t)E, 0,
@@ -390,6 +404,8 @@ extern "C" int dpvo_plan_layout(int64_t E, dpvo_plan_layout_t* L) {
   L->pair_off = o; o += n + 1;
   L->pair_ij = o; o += 2 * n;
   L->counts = o; o += 4;
+  o = (o + 3) & ~(int64_t)3;
+  L->flow = o; o += DPVO_PLAN_FLOW_INTS;
   L->total_ints = o;
   return DPVO_OK;
 }
@@ -408,6 +424,7 @@ extern "C" int dpvo_plan_build_ranged(const int64_t* ii, const int64_t* jj, cons
   dpvo_plan_layout(E, &P);
   if (E == 0) {
     hipError_t e = hipMemsetAsync(plan + P.counts, 0, 4 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(plan + P.flow, 0xff, 4 * sizeof(int32_t), st);       // (qi = qj = -1: no flow-test list)
     return e == hipSuccess ? DPVO_OK : (int)e;
   }
   if (!ii || !jj || !kk || !ws) return DPVO_E_INVALID;
@@ -436,6 +453,12 @@ extern "C" int dpvo_plan_build_ranged(const int64_t* ii, const int64_t* jj, cons
 extern "C" int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
                                       void* ws, size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
                                       int64_t n_patches_win, void* stream) {
+  return dpvo_plan_build_window_flow(ii, jj, kk, E, plan, ws, ws_bytes, frame_lo, n_frames_win, patch_lo, n_patches_win, -1, -1, stream);
+}
+
+extern "C" int dpvo_plan_build_window_flow(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+                                           void* ws, size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
+                                           int64_t n_patches_win, int64_t qi, int64_t qj, void* stream) {
   if (E < 0 || !plan || frame_lo < 0 || patch_lo < 0 || n_frames_win <= 0 || n_patches_win <= 0) return DPVO_E_INVALID;
   if (n_frames_win * n_frames_win > kWinB || n_patches_win > kWinA || E >= (1 << 24)) return DPVO_E_UNSUPPORTED;
   const int shift = bits_for(frame_lo + n_frames_win);
@@ -445,6 +468,7 @@ extern "C" int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, cons
   dpvo_plan_layout(E, &P);
   if (E == 0) {
     hipError_t e = hipMemsetAsync(plan + P.counts, 0, 4 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(plan + P.flow, 0xff, 4 * sizeof(int32_t), st);       // (qi = qj = -1: no flow-test list)
     return e == hipSuccess ? DPVO_OK : (int)e;
   }
   if (!ii || !jj || !kk || !ws) return DPVO_E_INVALID;
@@ -463,7 +487,10 @@ extern "C" int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, cons
   W.flag = W.tot + kWinBins;
   W.gid = W.flag + 1;
   // totals + flag = 0 (one small launch: hipMemsetAsync turns this 24 KB region into three fill kernels, 13 us of the frame start)
-  hipLaunchKernelGGL(win_zero_kernel, dim3((kWinBins + 1 + 1023) / 1024), dim3(1024), 0, st, W.tot, kWinBins + 1);
+  W.flow = plan + P.flow;
+  const bool with_flow = qi >= 0 && qj >= 0 && qi != qj && qi < (1ll << 30) && qj < (1ll << 30);
+  W.qi = with_flow ? (int)qi : -1; W.qj = with_flow ? (int)qj : -1;
+  hipLaunchKernelGGL(win_zero_kernel, dim3((kWinBins + 1 + 1023) / 1024), dim3(1024), 0, st, W.tot, kWinBins + 1, W.flow, W.qi, W.qj);
   W.tmp_key = (uint32_t*)(w + L.keys_a); W.tmp_e = (int32_t*)(w + L.vals_in);
   W.perm_k = plan + P.perm_k; W.perm_p = plan + P.perm_p;
   W.ku = plan + P.ku; W.kx = plan + P.kx; W.patch_off = plan + P.patch_off; W.ix = plan + P.ix; W.jx = plan + P.jx;
@@ -509,7 +536,7 @@ extern "C" int dpvo_neighbors(const int64_t* kk, const int64_t* jj, int64_t* ix,
   uint64_t* keys_out = (uint64_t*)(w + L.keys_out);
   int32_t* vals_in = (int32_t*)(w + L.vals_in);
   hipLaunchKernelGGL(make_keys_kernel<uint64_t>, dim3(grid_for(E)), dim3(256), 0, st, (const int64_t*)nullptr, jj, kk, keys_a,
-                     (uint64_t*)nullptr, vals_in, E, kKeyShift);
+                     (uint64_t*)nullptr, vals_in, E, kKeyShift, (int32_t*)nullptr);
   size_t tb = L.temp_bytes;
   hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_a, keys_out, vals_in, perm, (size_t)E, 0, 64, st);
   if (e != hipSuccess) return (int)e;

@@ -58,50 +58,79 @@ __device__ __forceinline__ void se3_act4(Pose X, const float* p, float* o) {   /
 // ---- flow test of DPVO.keyframe (dpvo.py:257-270), shared by geom.hip (dpvo_motionmag*) and track.hip (the keyframe step computes it itself)
 // pops.flow_mag (projective_ops.py:120-130) for one edge: mean over the PxP pixels of
 // beta*|x(Gij) - x(Gii)| + (1-beta)*|x(t-only) - x(Gii)|, and the number of valid pixels (Z > 0.2).
-__device__ __forceinline__ void edge_flow(const float* __restrict__ poses, const float* __restrict__ patches,
-                                          const float* __restrict__ intr, int64_t i, int64_t j, int64_t k, float beta,
-                                          int P, float* flow, float* nvalid) {
-  const int PP = P * P;
+// the three transforms of one frame pair and its intrinsics (loaded once per pair, not per edge)
+struct FlowPair { Pose Gii, Gij, Gt; float Ki[4], Kj[4]; };
+__device__ __forceinline__ FlowPair flow_pair(const float* __restrict__ poses, const float* __restrict__ intr, int64_t i, int64_t j) {
+  FlowPair F;
   const Pose Gi = load_pose(poses + 7 * i), Gj = load_pose(poses + 7 * j);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { F.Ki[a] = intr[4 * i + a]; F.Kj[a] = intr[4 * j + a]; }
   const Pose Gi_inv = se3_inv(Gi);
-  const Pose Gij = se3_mul(Gj, Gi_inv);
-  const Pose Gii = se3_mul(Gi, Gi_inv);
-  Pose Gt; Gt.t = Gij.t; Gt.q = {0.f, 0.f, 0.f, 1.f};          // tonly (:62-63)
-  const float* Ki = intr + 4 * i; const float* Kj = intr + 4 * j;
+  F.Gij = se3_mul(Gj, Gi_inv);
+  F.Gii = se3_mul(Gi, Gi_inv);
+  F.Gt.t = F.Gij.t; F.Gt.q = {0.f, 0.f, 0.f, 1.f};        // tonly (:62-63)
+  return F;
+}
+__device__ __forceinline__ void flow_pixel(const FlowPair& F, float x, float y, float dd, float beta, float& fsum, float& vsum) {
+  const float* Ki = F.Ki; const float* Kj = F.Kj;
+  const float X0[4] = {(x - Ki[2]) / Ki[0], (y - Ki[3]) / Ki[1], 1.0f, dd};
+  float A0[4], A1[4], A2[4];
+  se3_act4(F.Gii, X0, A0); se3_act4(F.Gij, X0, A1); se3_act4(F.Gt, X0, A2);
+  const float d0 = 1.0f / fmaxf(A0[2], 0.1f), d1 = 1.0f / fmaxf(A1[2], 0.1f), d2 = 1.0f / fmaxf(A2[2], 0.1f);
+  const float c0x = Ki[0] * (d0 * A0[0]) + Ki[2], c0y = Ki[1] * (d0 * A0[1]) + Ki[3];
+  const float c1x = Kj[0] * (d1 * A1[0]) + Kj[2], c1y = Kj[1] * (d1 * A1[1]) + Kj[3];
+  const float c2x = Kj[0] * (d2 * A2[0]) + Kj[2], c2y = Kj[1] * (d2 * A2[1]) + Kj[3];
+  const float f1 = sqrtf((c1x - c0x) * (c1x - c0x) + (c1y - c0y) * (c1y - c0y));
+  const float f2 = sqrtf((c2x - c0x) * (c2x - c0x) + (c2y - c0y) * (c2y - c0y));
+  fsum += beta * f1 + (1.0f - beta) * f2;
+  vsum += (A1[2] > 0.2f) ? 1.0f : 0.0f;
+}
+// one edge of a pair: P == 3 (every configuration of the reference) has its 27 patch values fetched up front -- as a loop over
+// a run-time P x P the nine pixels were nine dependent global round trips, 9 of the flow test's 17 us
+__device__ __forceinline__ void edge_flow_pair(const FlowPair& F, const float* __restrict__ patches, int64_t k, float beta, int P,
+                                               float* flow, float* nvalid) {
+  const int PP = P * P;
   const float* pk = patches + k * 3 * PP;
   float fsum = 0.f, vsum = 0.f;
-  for (int a = 0; a < PP; ++a) {
-    const float X0[4] = {(pk[a] - Ki[2]) / Ki[0], (pk[PP + a] - Ki[3]) / Ki[1], 1.0f, pk[2 * PP + a]};
-    float A0[4], A1[4], A2[4];
-    se3_act4(Gii, X0, A0); se3_act4(Gij, X0, A1); se3_act4(Gt, X0, A2);
-    const float d0 = 1.0f / fmaxf(A0[2], 0.1f), d1 = 1.0f / fmaxf(A1[2], 0.1f), d2 = 1.0f / fmaxf(A2[2], 0.1f);
-    const float c0x = Ki[0] * (d0 * A0[0]) + Ki[2], c0y = Ki[1] * (d0 * A0[1]) + Ki[3];
-    const float c1x = Kj[0] * (d1 * A1[0]) + Kj[2], c1y = Kj[1] * (d1 * A1[1]) + Kj[3];
-    const float c2x = Kj[0] * (d2 * A2[0]) + Kj[2], c2y = Kj[1] * (d2 * A2[1]) + Kj[3];
-    const float f1 = sqrtf((c1x - c0x) * (c1x - c0x) + (c1y - c0y) * (c1y - c0y));
-    const float f2 = sqrtf((c2x - c0x) * (c2x - c0x) + (c2y - c0y) * (c2y - c0y));
-    fsum += beta * f1 + (1.0f - beta) * f2;
-    vsum += (A1[2] > 0.2f) ? 1.0f : 0.0f;
+  if (P == 3) {
+    float v[27];
+#pragma unroll
+    for (int a = 0; a < 27; ++a) v[a] = pk[a];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) flow_pixel(F, v[a], v[9 + a], v[18 + a], beta, fsum, vsum);
+  } else {
+    for (int a = 0; a < PP; ++a) flow_pixel(F, pk[a], pk[PP + a], pk[2 * PP + a], beta, fsum, vsum);
   }
   *flow = fsum / (float)PP;
   *nvalid = vsum;
+}
+__device__ __forceinline__ void edge_flow(const float* __restrict__ poses, const float* __restrict__ patches,
+                                          const float* __restrict__ intr, int64_t i, int64_t j, int64_t k, float beta,
+                                          int P, float* flow, float* nvalid) {
+  const FlowPair F = flow_pair(poses, intr, i, j);
+  edge_flow_pair(F, patches, k, beta, P, flow, nvalid);
 }
 
 
 // DPVO.motionmag(i,j) + motionmag(j,i) (dpvo.py:257-264,269) in one launch: sums and counts of the per-edge
 // pixel-mean flow (pops.flow_mag(...).mean() averages over edges x pixels; every edge has PxP pixels) over the
-// edges (i->j) and (j->i).  out = {sum_ij, n_ij, sum_ji, n_ji}.  Fixed-order tree reductions (deterministic).
-__device__ __forceinline__ void block_reduce4(float (&s)[4], float (*red)[1024], float* out) {
+// edges (i->j) and (j->i).  out = {sum_ij, n_ij, sum_ji, n_ji}.  Fixed order (deterministic, and the same for every block size
+// as long as a thread holds the same edges): butterfly inside a wave, then the waves in order.
+__device__ __forceinline__ void block_reduce4(float (&s)[4], float (*red)[16], float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) red[a][threadIdx.x] = s[a];
-  __syncthreads();
-  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o)
+  for (int a = 0; a < 4; ++a) {
+    float v = s[a];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + o];
-    __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[a][wave] = v;
   }
-  if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x][0];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int w = 0; w < nw; ++w) v += red[threadIdx.x][w];
+    out[threadIdx.x] = v;
+  }
 }
 
 
@@ -111,7 +140,9 @@ struct MotionPlanArgs {
   const float *poses, *patches, *intr; const int64_t* kk;
   const int32_t *perm_p, *pair_off, *pair_ij, *n_pairs;
   int P, qi, qj; float beta; float *out, *status;
+  const int32_t* flow;      // dpvo_plan_layout_t.flow of the same plan, or NULL
 };
+constexpr int kFlowPx = 256;       // pixel-parallel flow test: at most this many edges per direction (else one thread per edge)
 __device__ __forceinline__ void motionmag_plan_body(const float* __restrict__ poses, const float* __restrict__ patches,
                                                     const float* __restrict__ intr, const int64_t* __restrict__ kk,
                                                     const int32_t* __restrict__ perm_p,
@@ -119,32 +150,106 @@ __device__ __forceinline__ void motionmag_plan_body(const float* __restrict__ po
                                                     const int32_t* __restrict__ pair_ij,
                                                     const int32_t* __restrict__ n_pairs, int P, int qi, int qj,
                                                     float beta, float* __restrict__ out,
-                                                    float* __restrict__ status) {
-  __shared__ float red[4][1024];
+                                                    float* __restrict__ status, const int32_t* __restrict__ flow = nullptr) {
+  __shared__ float red[4][16];
   __shared__ int found[2];
-  const int ng = *n_pairs;
-  // the plan's counters [n_patches, n_pairs, 0, ids-outside-the-window flag] ride along with the frame's only read-back
-  if (status && threadIdx.x < 4) status[threadIdx.x] = (float)n_pairs[(int)threadIdx.x - 1];
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  // both pairs located by ONE parallel scan of the pair list (a binary search is ~9 dependent global round trips per
-  // pair: 12 of this kernel's 21 us); pairs are unique, so at most one thread writes each slot
-  if (threadIdx.x < 2) found[threadIdx.x] = -1;
-  __syncthreads();
-  for (int g = threadIdx.x; g < ng; g += blockDim.x) {
-    const int pi = pair_ij[2 * g], pj = pair_ij[2 * g + 1];
-    if (pi == qi && pj == qj) found[0] = g;
-    if (pi == qj && pj == qi) found[1] = g;
-  }
-  __syncthreads();
+  __shared__ int klist[2][kFlowPx];                     // patch ids of the pair's edges, both directions, in edge order
+  __shared__ FlowPair fpair[2];
+  __shared__ float pxl[2][kFlowPx * 9];                 // per-pixel flow terms
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // ---- 1. the two edge lists.  The plan may carry them (dpvo_plan_build_window_flow): header, patch ids and the plan's counters
+  //         travel together -- one round trip instead of the four dependent ones of the walk (pair list -> offsets -> edge -> patch id)
+  int hq[4] = {-1, -1, 0, 0}, kf = 0, kb = 0;
+  if (flow) {
 #pragma unroll
-  for (int dir = 0; dir < 2; ++dir) {
-    const int a = dir ? qj : qi, b = dir ? qi : qj;
-    const int g = found[dir];
-    if (g >= 0) {
-      for (int p = pair_off[g] + threadIdx.x; p < pair_off[g + 1]; p += blockDim.x) {
-        float f, v;
-        edge_flow(poses, patches, intr, a, b, kk[perm_p[p]], beta, P, &f, &v);
-        s[2 * dir] += f; s[2 * dir + 1] += 1.f;
+    for (int a = 0; a < 4; ++a) hq[a] = flow[a];
+    if (tid < DPVO_PLAN_FLOW_CAP && tid < kFlowPx) { kf = flow[4 + tid]; kb = flow[4 + DPVO_PLAN_FLOW_CAP + tid]; }
+  }
+  const int ng = *n_pairs;
+  const int outside = n_pairs[2];                       // ids outside the window the plan was sized for: its bins are not to be trusted
+  // the plan's counters [n_patches, n_pairs, 0, ids-outside-the-window flag] ride along with the frame's only read-back
+  if (status && tid < 4) status[tid] = (float)n_pairs[tid - 1];
+  int n0, n1, p0[2] = {0, 0};
+  const bool listed = flow && qi >= 0 && hq[0] == qi && hq[1] == qj && !outside && hq[2] >= 0 && hq[3] >= 0 &&
+                      hq[2] <= DPVO_PLAN_FLOW_CAP && hq[3] <= DPVO_PLAN_FLOW_CAP && hq[2] <= kFlowPx && hq[3] <= kFlowPx;
+  if (listed) {
+    n0 = hq[2]; n1 = hq[3];
+    if (tid < kFlowPx) { klist[0][tid] = kf; klist[1][tid] = kb; }
+  } else {
+    // both pairs located by ONE parallel scan of the pair list (a binary search is ~9 dependent global round trips per
+    // pair); pairs are unique, so at most one thread writes each slot
+    if (tid < 2) found[tid] = -1;
+    __syncthreads();
+    for (int g = tid; g < ng; g += nt) {
+      const int pi = pair_ij[2 * g], pj = pair_ij[2 * g + 1];
+      if (pi == qi && pj == qj) found[0] = g;
+      if (pi == qj && pj == qi) found[1] = g;
+    }
+    __syncthreads();
+    int cnt[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int g = found[d];
+      cnt[d] = 0;
+      if (g >= 0) { p0[d] = pair_off[g]; cnt[d] = pair_off[g + 1] - p0[d]; }
+    }
+    n0 = cnt[0]; n1 = cnt[1];
+    if (n0 <= kFlowPx && n1 <= kFlowPx) {
+      if (tid < n0) klist[0][tid] = (int)kk[perm_p[p0[0] + tid]];
+      if (tid < n1) klist[1][tid] = (int)kk[perm_p[p0[1] + tid]];
+    }
+  }
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (P == 3 && n0 <= kFlowPx && n1 <= kFlowPx && n0 <= nt && n1 <= nt) {
+    // ---- 2. one work item per (edge, pixel): a thread per EDGE ran ~3 500 dependent VALU instructions (IEEE divisions, square
+    //         roots, three SE3 actions per pixel) on one wave per SIMD -- 10 of the flow test's 14 us.  The pair's transforms are
+    //         built once (threads 0 and 64: two waves) and shared through LDS; a pair that has edges has valid frame ids.
+    __syncthreads();                                   // (the lists)
+    const int items = 9 * (n0 + n1);
+    float px[8][3];                                    // (256-thread callers: up to 18 x 256 items -> a few per thread, fetched up front)
+    int cnt = 0;
+    for (int w = tid; w < items && cnt < 8; w += nt, ++cnt) {
+      const int d = w >= 9 * n0, l = w - (d ? 9 * n0 : 0), e = l / 9, a = l - 9 * e;
+      const float* pk = patches + (int64_t)klist[d][e] * 27;
+      px[cnt][0] = pk[a]; px[cnt][1] = pk[9 + a]; px[cnt][2] = pk[18 + a];
+    }
+    if (tid == 0 && n0 > 0) fpair[0] = flow_pair(poses, intr, qi, qj);
+    if (tid == 64 % nt && n1 > 0) fpair[1] = flow_pair(poses, intr, qj, qi);
+    __syncthreads();
+    cnt = 0;
+    for (int w = tid; w < items; w += nt, ++cnt) {
+      const int d = w >= 9 * n0, l = w - (d ? 9 * n0 : 0);
+      float x, y, dd;
+      if (cnt < 8) { x = px[cnt][0]; y = px[cnt][1]; dd = px[cnt][2]; }
+      else { const int e = l / 9, a = l - 9 * e; const float* pk = patches + (int64_t)klist[d][e] * 27; x = pk[a]; y = pk[9 + a]; dd = pk[18 + a]; }
+      float f = 0.f, v = 0.f;
+      flow_pixel(fpair[d], x, y, dd, beta, f, v);
+      pxl[d][l] = f;
+    }
+    __syncthreads();
+    // per-edge pixel sums in pixel order, thread t = edge t of either direction (the order the per-edge loop had)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      if (tid < (d ? n1 : n0)) {
+        float fs = 0.f;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) fs += pxl[d][9 * tid + a];
+        s[2 * d] += fs / 9.0f; s[2 * d + 1] += 1.f;
+      }
+  } else {
+    // ---- 2'. general patch size / very wide pairs: one thread per edge
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int nd = d ? n1 : n0;
+      if (tid < nd) {
+        const FlowPair FP = flow_pair(poses, intr, d ? qj : qi, d ? qi : qj);
+        for (int t = tid; t < nd; t += nt) {
+          const int64_t k = (listed || (n0 <= kFlowPx && n1 <= kFlowPx)) ? (int64_t)klist[d][t] : kk[perm_p[p0[d] + t]];
+          float f, v;
+          edge_flow_pair(FP, patches, k, beta, P, &f, &v);
+          s[2 * d] += f; s[2 * d + 1] += 1.f;
+        }
       }
     }
   }

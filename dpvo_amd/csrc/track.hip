@@ -31,9 +31,8 @@ __device__ __forceinline__ void renumber(const Renum& R, int64_t& i, int64_t& j,
   }
 }
 
-// ---- 1. decision + stable partition, two small launches: (a) every 1024-edge chunk counts its kept / inactive edges,
-//         (b) every chunk adds up the counts of the chunks before it and writes its indices in order.  (One workgroup walking
-//         all ~5 x 10^4 index triples took 95 us; this takes ~2 x 5.)
+// ---- 1. decision + stable partition in one launch of 1024-edge chunks (kf_decide_kernel below).  (One workgroup walking all
+//         ~5 x 10^4 index triples took 95 us; a count launch + a select launch 41 us.)
 __device__ __forceinline__ int kf_decide(const dpvo_keyframe_step_t& a, const float* flow4) {
   int d;
   if (a.forced >= 0) d = a.forced ? 1 : 0;
@@ -63,88 +62,141 @@ __device__ __forceinline__ int kf_class(const dpvo_keyframe_step_t& a, int d, in
   }                           // such edges are active the next update() runs the global BA (dpvo.py:348): the host needs their count
   return rem ? 2 : 1;
 }
-// the host's copy of the result, written straight into its pinned buffer by one thread (a 32- or 64-byte hipMemcpyAsync is another
-// ~5 us launch in the frame's tail); `host_words` = 16: the 8 words in front of `result` (flow sums + plan counters) go along.
-// Issued by one thread of the gather kernel: inside the select kernel the 16 PCIe writes and their system-scope fence sat on the
-// frame's critical path (select 17 us, of which ~10 were this), here they travel while the gather runs; the host waits for the
-// stream's event, i.e. for the end of that kernel, anyway.
-__device__ __forceinline__ void kf_host_copy(const dpvo_keyframe_step_t& a) {
-  volatile int32_t* h = (volatile int32_t*)a.result_host;
-  const int32_t* src = a.result - (a.host_words == 16 ? 8 : 0);
-  for (int i = 0; i < a.host_words; ++i) h[i] = src[i];
-  // (no __threadfence_system(): it parks the wave until the PCIe writes are acknowledged, ~8 us at the very end of the frame.  The
-  //  host reads the record only after synchronising with an event recorded behind this kernel, which orders the writes.)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+#ifdef KF_TRACE
+// instrumentation build (tools/kf_trace.sh): thread 0 of the first and the last chunk stamps the 100 MHz wall clock at every phase
+__device__ unsigned long long kf_trace_buf[2][16];
+#define KFT(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) kf_trace_buf[blockIdx.x == 0 ? 0 : 1][i] = wall_clock64(); } while (0)
+#else
+#define KFT(i) do {} while (0)
+#endif
 constexpr int KF_CHUNK = 1024;
+constexpr int KF_HDR = 4;         // scratch behind the 8 result words: [0] generation, [1] workgroups done, then per chunk {kept, removed, long-range, flag}
+// ONE launch (rounds 2-3: a count kernel and a select kernel, 21 + 20 us): every 1024-edge chunk classifies its edges, publishes its
+// three counts with a flag (= the call's generation number, so nothing has to be cleared between calls) and reads the counts of the
+// chunks BEFORE it (look-back: a workgroup only ever waits for lower-numbered ones, which were dispatched before it), writes its
+// indices in order; the last chunk holds the totals and writes the result record.  The last workgroup to finish bumps the generation.
 // F.poses != NULL: the flow test itself (DPVO.motionmag for (k - 1, k + 1) and back, dpvo.py:257-269) runs HERE, in every chunk's
 // workgroup redundantly (one scan of the ~500 pair records + ~190 edge flows: less than the launch it saves), block 0 leaves the
-// sums in a.flow4 for kf_select, the record and the host.  Same code, same reduction tree as dpvo_motionmag: same bits in every block.
-__global__ __launch_bounds__(KF_CHUNK) void kf_count_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ counts, const MotionPlanArgs F) {
+// sums in F.out for the record and the host.  Same code, same reduction tree as dpvo_motionmag: same bits in every block.
+__global__ __launch_bounds__(KF_CHUNK) void kf_decide_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ sc, const MotionPlanArgs F) {
   __shared__ int wsum[3][16];
+  __shared__ int pre[3];
   __shared__ float fl4[8];
+  __shared__ __attribute__((aligned(16))) int rec[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int blk = blockIdx.x, last = (int)gridDim.x - 1;
+  KFT(0);
+  const int gen = __hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   const float* flow4 = a.flow4;
+  if (tid < 3) pre[tid] = 0;
+  float statv = 0.f;                              // (the plan counters of the host record: fetched here, used at the very end)
   if (F.poses) {
+    if (blk == last && tid >= 4 && tid < 8) statv = (float)F.n_pairs[tid - 5];
     motionmag_plan_body(F.poses, F.patches, F.intr, F.kk, F.perm_p, F.pair_off, F.pair_ij, F.n_pairs, F.P, F.qi, F.qj, F.beta, fl4,
-                        blockIdx.x == 0 ? F.status : nullptr);
+                        blk == 0 ? F.status : nullptr, F.flow);
     __syncthreads();
-    if (blockIdx.x == 0 && tid < 4) F.out[tid] = fl4[tid];
+    if (blk == 0 && tid < 4) { F.out[tid] = fl4[tid]; __threadfence(); }     // (the last chunk's host copy reads them)
     flow4 = fl4;
   }
+  KFT(1);
   const int d = kf_decide(a, flow4);
-  const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
-  const int cls = e < a.E ? kf_class(a, d, e) : 0;
-  const unsigned long long bk = __ballot(cls == 1 || cls == 3), br = __ballot(cls == 2), bl = __ballot(cls == 3);
-  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); wsum[2][wv] = __popcll(bl); }
-  __syncthreads();
-  if (tid == 0) {
-    int tk = 0, tr = 0, tl = 0;
-    for (int w = 0; w < 16; ++w) { tk += wsum[0][w]; tr += wsum[1][w]; tl += wsum[2][w]; }
-    counts[3 * blockIdx.x] = tk; counts[3 * blockIdx.x + 1] = tr; counts[3 * blockIdx.x + 2] = tl;
-    if (blockIdx.x == 0 && a.delta_pose) {
-      // dP = SE3(poses[k]) * SE3(poses[k-1]).inv() (dpvo.py:276), with lietorch's store / load between the two ops
-      const int k = a.n - a.keyframe_index;
-      if (k >= 1 && k < a.n) {
-        float tmp[7];
-        store_pose(tmp, se3_inv(load_pose(a.poses + 7 * (int64_t)(k - 1))));
-        store_pose(a.delta_pose, se3_mul(load_pose(a.poses + 7 * (int64_t)k), load_pose(tmp)));
-      }
-    }
-  }
-}
-__global__ __launch_bounds__(KF_CHUNK) void kf_select_kernel(const dpvo_keyframe_step_t a, const int32_t* __restrict__ counts) {
-  __shared__ int wsum[2][16];
-  __shared__ int base[3], total[3];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int d = kf_decide(a, a.flow4);
-  if (tid < 3) {                                  // exclusive prefix over the chunks before this one (<= a few dozen), and the total
-    int pre = 0, tot = 0;
-    for (int b = 0; b < (int)gridDim.x; ++b) { const int c = counts[3 * b + tid]; if (b < (int)blockIdx.x) pre += c; tot += c; }
-    base[tid] = pre; total[tid] = tot;
-  }
-  const int64_t e = (int64_t)blockIdx.x * KF_CHUNK + tid;
+  const int64_t e = (int64_t)blk * KF_CHUNK + tid;
   int cls = e < a.E ? kf_class(a, d, e) : 0;
+  const unsigned long long bl = __ballot(cls == 3);
   if (cls == 3) cls = 1;                          // (a long-range edge is a kept edge)
   const unsigned long long bk = __ballot(cls == 1), br = __ballot(cls == 2);
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int pk = __popcll(bk & below), pr = __popcll(br & below);
-  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); }
+  if (lane == 0) { wsum[0][wv] = __popcll(bk); wsum[1][wv] = __popcll(br); wsum[2][wv] = __popcll(bl); }
   __syncthreads();
-  int ok = base[0], orr = base[1];
+  KFT(2);
+  int32_t* mine = sc + KF_HDR + 4 * blk;
+  int tk = 0, tr = 0, tl = 0;
+  if (tid == 0) {
+    for (int w = 0; w < 16; ++w) { tk += wsum[0][w]; tr += wsum[1][w]; tl += wsum[2][w]; }
+    mine[0] = tk; mine[1] = tr; mine[2] = tl;
+    __hip_atomic_store(&mine[3], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blk == 0 && tid == 64 && a.delta_pose) {    // (not thread 0: every other chunk waits for this chunk's counts)
+    // dP = SE3(poses[k]) * SE3(poses[k-1]).inv() (dpvo.py:276), with lietorch's store / load between the two ops
+    const int k = a.n - a.keyframe_index;
+    if (k >= 1 && k < a.n) {
+      float tmp[7];
+      store_pose(tmp, se3_inv(load_pose(a.poses + 7 * (int64_t)(k - 1))));
+      store_pose(a.delta_pose, se3_mul(load_pose(a.poses + 7 * (int64_t)k), load_pose(tmp)));
+    }
+  }
+  KFT(3);
+  // look-back: thread t collects chunk t, t + 1024, ... (< blk)
+  {
+    int ak = 0, ar = 0, al = 0;
+    for (int b = tid; b < blk; b += KF_CHUNK) {
+      const int32_t* o = sc + KF_HDR + 4 * b;
+      while (__hip_atomic_load(&o[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(1);
+      ak += __hip_atomic_load(&o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ar += __hip_atomic_load(&o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      al += __hip_atomic_load(&o[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wv * 64 < blk) {                          // (waves without a chunk to collect have nothing to add)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { ak += __shfl_xor(ak, o); ar += __shfl_xor(ar, o); al += __shfl_xor(al, o); }
+      if (lane == 0) { atomicAdd(&pre[0], ak); atomicAdd(&pre[1], ar); atomicAdd(&pre[2], al); }
+    }
+  }
+  KFT(4);
+  __syncthreads();
+  KFT(5);
+  int ok = pre[0], orr = pre[1];
   for (int w = 0; w < wv; ++w) { ok += wsum[0][w]; orr += wsum[1][w]; }
   if (cls == 1) { a.keep_idx[ok + pk] = (int32_t)e; if (a.keep_rows) a.keep_rows[ok + pk] = e; }
   if (cls == 2 && orr + pr < a.inac_room) a.rem_idx[orr + pr] = (int32_t)e;
-  if (blockIdx.x == 0 && tid == 0) {
-    int nrem = total[1], ovf = 0;
-    if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
-    a.result[RES_DECISION] = d; a.result[RES_KEEP] = total[0]; a.result[RES_REM] = nrem; a.result[RES_E] = (int32_t)a.E;
-    a.result[RES_OVERFLOW] = ovf; a.result[RES_LONG_RANGE] = total[2]; a.result[6] = a.result[7] = 0;
-    // the host's copy: from here on the record is final (the gather that follows only executes it).  Round 3 wrote it from the
-    // gather kernel to keep the 16 PCIe writes off this kernel's critical path; round 4 lets the HOST start on the next frame one
-    // point-cloud + gather (~36 us) earlier instead, behind an event recorded right after this kernel
-    if (a.result_host) kf_host_copy(a);
+  KFT(6);
+  if (blk == last && wv == 0) {
+    // the record: 8 result words; the host's copy (pinned memory) takes the 8 words in front of them along when host_words = 16
+    // (flow sums + plan counters: block 0 writes them to device memory, this chunk has the same values at hand).  One 16-byte
+    // store per lane -- as 16 volatile 4-byte stores from one thread the copy took 11 us of the frame's tail.  From here on the
+    // record is final (the gather that follows only executes it); the HOST starts on the next frame behind an event recorded
+    // right after this kernel, one point cloud + gather earlier than the end of the call.
+    if (tid == 0) {
+      int nrem = pre[1] + tr, ovf = 0;
+      if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
+      rec[8 + RES_DECISION] = d; rec[8 + RES_KEEP] = pre[0] + tk; rec[8 + RES_REM] = nrem; rec[8 + RES_E] = (int32_t)a.E;
+      rec[8 + RES_OVERFLOW] = ovf; rec[8 + RES_LONG_RANGE] = pre[2] + tl; rec[8 + 6] = rec[8 + 7] = 0;
+    }
+    if (tid < 8 && a.result_host && a.host_words == 16) {
+      if (F.poses) rec[tid] = tid < 4 ? __float_as_int(fl4[tid]) : __float_as_int(statv);
+      else rec[tid] = (a.result - 8)[tid];
+    }
+    wave_lds_fence();
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    if (tid >= 2 && tid < 4) reinterpret_cast<i4v*>(a.result)[tid - 2] = reinterpret_cast<const i4v*>(rec)[tid];
+    if (a.result_host) {
+      const int first = a.host_words == 16 ? 0 : 2;
+      if (tid >= first && tid < 4) reinterpret_cast<i4v*>(a.result_host)[tid - first] = reinterpret_cast<const i4v*>(rec)[tid];
+    }
   }
+  if (tid == 0) {
+    KFT(7);
+    const int done = __hip_atomic_fetch_add(&sc[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == last) {                           // everybody has read the generation and every flag: next call, next number
+      __hip_atomic_store(&sc[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sc[0], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  KFT(8);
 }
+#ifdef KF_TRACE
+}  // namespace
+extern "C" int dpvo_debug_kf_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(kf_trace_buf), sizeof(kf_trace_buf)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 // ---- 2. the two gathers (kept -> spare set, incl. the 1.5 KB hidden-state rows; inactive -> tail of the inactive store)
 __device__ __forceinline__ void kf_shift_body(const dpvo_keyframe_step_t& a, int blk, int blocks_per_ring);
@@ -217,6 +269,7 @@ void kf_apply_launch(const dpvo_keyframe_step_t* a, hipStream_t st);
 extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
   if (!a || a->E < 0 || a->E >= (1ll << 31) || a->M <= 0 || a->D <= 0 || (a->D % 4) || a->n_ring < 0 || a->n_ring > 8) return DPVO_E_INVALID;
   if (a->result_host && a->host_words != 8 && a->host_words != 16) return DPVO_E_INVALID;
+  if (((uintptr_t)a->result & 15) || ((uintptr_t)a->result_host & 15)) return DPVO_E_INVALID;      // (the record is stored 16 bytes at a time)
   if (!a->result || !a->keep_idx || !a->rem_idx || (a->forced < 0 && !a->flow4) || !a->poses) return DPVO_E_INVALID;
   if (a->E > 0 && (!a->ii || !a->jj || !a->kk || !a->target || !a->weight || !a->ii_b || !a->jj_b || !a->kk_b || !a->target_b ||
                    !a->weight_b || !a->ii_inac || !a->jj_inac || !a->kk_inac || !a->target_inac || !a->weight_inac))
@@ -233,11 +286,10 @@ extern "C" int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream) {
 namespace {
 // decision, counts, index lists, result record (device + host copy).  F.poses != NULL: the flow test runs inside the count kernel.
 void kf_decide_launch(const dpvo_keyframe_step_t* a, const MotionPlanArgs& F, hipStream_t st) {
-  // the per-chunk counts live behind the 8 result words: `result` has room for 8 + 3 * ceil(E / 1024) ints
-  int32_t* counts = a->result + 8;
+  // the look-back scratch lives behind the 8 result words: `result` has room for 8 + 4 + 4 * ceil(E / 1024) ints, zeroed ONCE by the caller
+  int32_t* sc = a->result + 8;
   const unsigned chunks = (unsigned)(a->E > 0 ? cdiv64(a->E, KF_CHUNK) : 1);
-  hipLaunchKernelGGL(kf_count_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, counts, F);
-  hipLaunchKernelGGL(kf_select_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, (const int32_t*)counts);
+  hipLaunchKernelGGL(kf_decide_kernel, dim3(chunks), dim3(KF_CHUNK), 0, st, *a, sc, F);
 }
 // the two gathers (kept edges -> spare set, removed edges -> inactive store) and the ring shifts of a dropped keyframe
 void kf_apply_launch(const dpvo_keyframe_step_t* a, hipStream_t st) {
@@ -321,7 +373,9 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
     if (hipEventRecord((hipEvent_t)a->ev_plan_fork, st) != hipSuccess ||
         hipStreamWaitEvent((hipStream_t)pst, (hipEvent_t)a->ev_plan_fork, 0) != hipSuccess) return DPVO_E_INVALID;
   }
-  rc = dpvo_plan_build_window(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M, pst);
+  // (with the flow test's frame pair (k - 1, k + 1), k = n - KEYFRAME_INDEX, extracted on the way: dpvo_plan_layout_t.flow)
+  rc = dpvo_plan_build_window_flow(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M,
+                                   n - K.keyframe_index - 1, n - K.keyframe_index + 1, pst);
   if (rc == DPVO_E_UNSUPPORTED)
     rc = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, pst);
   if (plan_aside && hipEventRecord((hipEvent_t)a->ev_plan_done, (hipStream_t)pst) != hipSuccess) return DPVO_E_INVALID;
@@ -373,7 +427,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
     dpvo_plan_layout_t PLy;
     dpvo_plan_layout(E, &PLy);
     const MotionPlanArgs F = {a->poses, a->patches, a->intrinsics, K.kk, a->plan + PLy.perm_p, a->plan + PLy.pair_off, a->plan + PLy.pair_ij,
-                              a->plan + PLy.counts + 1, a->P, k - 1, k + 1, a->mm_beta, a->result_dev, a->result_dev + 4};
+                              a->plan + PLy.counts + 1, a->P, k - 1, k + 1, a->mm_beta, a->result_dev, a->result_dev + 4, a->plan + PLy.flow};
     kf_decide_launch(&kf, F, st);
   }
   if (a->ev_record && hipEventRecord((hipEvent_t)a->ev_record, st) != hipSuccess) return DPVO_E_INVALID;

@@ -528,7 +528,7 @@ class DPVO:
               # timing events for bench.py's roofline legs (HIP events around the correlation kernel / the update operator
               # inside the call): created once, re-recorded in place -- creating events per frame costs the host ~20 us
               "evpool": [torch.cuda.Event(enable_timing=True) for _ in range(512)] if prof_on else None,
-              "result": torch.zeros(16 + 3 * (cap // 1024 + 2), dtype=f32, device=dev),
+              "result": torch.zeros(16 + 4 + 4 * (cap // 1024 + 2), dtype=f32, device=dev),      # (zeroed once: the look-back scratch counts its own generations)
               "host": [torch.zeros(16, dtype=f32).pin_memory() for _ in range(2)],
               "dpose": torch.zeros(2, 7, dtype=f32, device=dev),
               "ev": [torch.cuda.Event() for _ in range(2)], "wake": 0.0, "side": 0.0,

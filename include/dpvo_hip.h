@@ -157,7 +157,13 @@ int dpvo_se3_log(const float* X, float* a, int64_t n, void* stream);
  */
 typedef struct dpvo_plan_layout_t {
   int64_t perm_k, ku, kx, patch_off, ix, jx, perm_p, pu, pair_off, pair_ij, counts, total_ints;
+  int64_t flow;   /* DPVO_PLAN_FLOW_INTS ints, 16-byte aligned: {qi, qj, n_ij, n_ji} + 2 x DPVO_PLAN_FLOW_CAP patch ids -- the edges of ONE
+                     frame pair in both directions, in edge order, extracted while the plan is built (dpvo_plan_build_window_flow) so
+                     that the keyframe flow test (dpvo.py:257-270) starts from a list instead of three dependent look-ups; every other
+                     builder writes qi = qj = -1 (readers then walk pair_ij / pair_off / perm_p as before: same edges, same order) */
 } dpvo_plan_layout_t;
+#define DPVO_PLAN_FLOW_CAP 256
+#define DPVO_PLAN_FLOW_INTS (4 + 2 * DPVO_PLAN_FLOW_CAP)
 
 int dpvo_plan_layout(int64_t E, dpvo_plan_layout_t* layout);
 size_t dpvo_plan_workspace_bytes(int64_t E);
@@ -177,6 +183,10 @@ int dpvo_plan_build_ranged(const int64_t* ii, const int64_t* jj, const int64_t* 
 int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
                            size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo, int64_t n_patches_win,
                            void* stream);
+/* dpvo_plan_build_window + the flow-test edge list of the frame pair (qi, qj) / (qj, qi) in the plan's `flow` region (qi < 0: none) */
+int dpvo_plan_build_window_flow(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
+                                size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo, int64_t n_patches_win,
+                                int64_t qi, int64_t qj, void* stream);
 
 /* cuda_ba.neighbors(kk, jj) -- ba.cpp:59-97,187: int64 outputs for API parity (device resident). */
 size_t dpvo_neighbors_workspace_bytes(int64_t E);
@@ -360,7 +370,8 @@ int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const fl
  *   3. the edges whose source frame kk / M < n' - removal_window leave to the inactive store (remove_factors(..., store=True),
  *      :305-310; with loop_closure != 0 the long-range edges of :307-308 stay), the others are compacted in order into the
  *      spare arrays (*_b).
- * result (device, 8 x int32 followed by 3 * ceil(E / 1024) ints of scratch; the words are also written to result_host if not
+ * result (device, 8 x int32 followed by 4 + 4 * ceil(E / 1024) ints of look-back scratch that the caller ZEROES ONCE when it allocates
+ * the buffer and never touches again; the words are also written to result_host if not
  * NULL -- pinned host memory, see host_words):
  *   [0] decision, [1] edges kept, [2] edges moved to the inactive store, [3] E, [4] 1 if the inactive room was too small
  *   (nothing written beyond it), [5] how many of the kept edges are long-range ones that stayed only because of the loop-closure
@@ -377,7 +388,7 @@ typedef struct {
   int32_t *keep_idx, *rem_idx;                                                 /* scratch, E ints each */
   int64_t* keep_rows;               /* optional [E]: the kept edges' old row numbers as int64 -- with net == net_b == NULL the hidden
                                        state is NOT moved and this list is what dpvo_update_forward_fused_rows takes as net_rows */
-  int32_t* result; void* result_host;
+  int32_t* result; void* result_host;   /* both 16-byte aligned */
   int32_t host_words;               /* 8: result_host receives the 8 result words; 16: also the 8 words stored in front of `result`
                                        (dpvo_frame_update: flow sums + plan counters).  result_host is device-visible pinned host
                                        memory: the kernel writes it itself, ordered before the completion of the call's last kernel */
@@ -396,7 +407,7 @@ int dpvo_keyframe_step(const dpvo_keyframe_step_t* a, void* stream);
  * buffer (capacity buffers + workspaces sized with the *_workspace_bytes functions for E); ev[0..3] (hipEvent_t or NULL) are
  * recorded before / after the correlation kernel and before / after the update operator (roofline measurement).
  * result_dev: 16 words -- [0..3] flow sums, [4..7] plan counters (float), [8..15] the dpvo_keyframe_step result -- followed by
- * that step's 3 * ceil(E / 1024) ints of scratch.  fs (may be NULL): a dpvo_frame_state to issue first (the new frame's patch
+ * that step's 4 + 4 * ceil(E / 1024) ints of scratch (zeroed once by the caller).  fs (may be NULL): a dpvo_frame_state to issue first (the new frame's patch
  * gathers, state stores and edges: everything between the encoders and the plan), with ev_fs (hipEvent_t or NULL) recorded
  * right behind it. */
 typedef struct {

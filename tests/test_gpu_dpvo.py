@@ -219,7 +219,7 @@ def test_keyframe_step_decision_unit(dev):
         args = fu["args"][par]
         kf = L.KeyframeStep.from_buffer_copy(args.kf)
         flow = torch.tensor([s0, c0, s1, c1, 0, 0, 0, 0] + [0.0] * 8, dtype=torch.float32, device=dev)
-        res = torch.zeros(16 + 3 * (es.cap // 1024 + 2), dtype=torch.float32, device=dev)
+        res = torch.zeros(16 + 4 + 4 * (es.cap // 1024 + 2), dtype=torch.float32, device=dev)
         res[:16] = flow
         kf.flow4, kf.result, kf.result_host, kf.host_words = res.data_ptr(), res.data_ptr() + 32, None, 8
         kf.poses = a.pg.poses_.data_ptr()
