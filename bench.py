@@ -285,10 +285,28 @@ def main():
     # care about a host sync per frame.  Never set for a timed run.
     _SYNC_EVERY_FRAME = bool(int(os.environ.get("DPVO_BENCH_SYNC_EVERY_FRAME", "0")))
 
+    # DPVO_BENCH_HOST_TRACE=1 (diagnosis of a slow frame, never for a quoted run): host wall time of every step and every garbage
+    # collection with its generation and duration, to stderr
+    _HOST_TRACE = [] if os.environ.get("DPVO_BENCH_HOST_TRACE") else None
+    if _HOST_TRACE is not None:
+        import gc
+        _gc_t = [0.0]
+
+        def _gc_cb(phase, info):
+            if phase == "start":
+                _gc_t[0] = time.perf_counter()
+            else:
+                _HOST_TRACE.append(("gc", info["generation"], round(1e3 * (time.perf_counter() - _gc_t[0]), 3), info["collected"]))
+        gc.callbacks.append(_gc_cb)
+
     def step(t):
         # image_ready=False: the frames were staged in HBM and synchronised before the timed region (the metric is quoted with
         # resident inputs), so the encoder stream need not wait for the compute stream
+        if _HOST_TRACE is not None:
+            t0_ = time.perf_counter()
         slam(float(t), frames[t % n_img], intr, image_ready=False)
+        if _HOST_TRACE is not None:
+            _HOST_TRACE.append(("step", t, round(1e3 * (time.perf_counter() - t0_), 3)))
         if _SYNC_EVERY_FRAME:
             torch.cuda.synchronize(device)
 
@@ -305,6 +323,10 @@ def main():
         slam.flush()                                  # the last frame's deferred keyframe decision belongs to the timed region
         cpu1 = time.process_time()
         local = clock.stop()                          # torch.cuda.synchronize() + barrier
+    if _HOST_TRACE is not None:
+        first = preroll + args.warmup
+        print("host trace (ms): " + " ".join(f"{e[1] - first}:{e[2]}" if e[0] == "step" else f"[gc{e[1]} {e[2]} ms, {e[3]} collected]"
+                                             for e in _HOST_TRACE if e[0] == "gc" or e[1] >= first), file=sys.stderr)
     prof = corr_mod.PROFILE
     uprof = net_mod.PROFILE
     corr_mod.PROFILE = None

@@ -14,7 +14,7 @@ class GraphPlan:
     """All views are int32 device tensors into one buffer; `counts` = [n_patches, n_pairs, 0, 0] stays on the
     device (no synchronisation); `n_patches()` / `n_pairs()` synchronise and are for tests / host logic only."""
 
-    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None, n_frames=0, n_patch_ids=0, window=None):
+    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None, n_frames=0, n_patch_ids=0, window=None, flow_pair=None):
         L.require_cuda(ii, jj, kk)
         assert ii.dtype == jj.dtype == kk.dtype == torch.long
         E = ii.numel()
@@ -32,9 +32,12 @@ class GraphPlan:
         # these windows -> counting-sort build (dpvo_plan_build_window); falls back when the windows are too large for it
         rc = -2
         if window is not None:
-            rc = L.lib().dpvo_plan_build_window(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
-                                                ctypes.c_size_t(ws.numel()), L.i64(window[0]), L.i64(window[1]), L.i64(window[2]),
-                                                L.i64(window[3]), L.stream())
+            # flow_pair = (qi, qj): the edges qi -> qj and qj -> qi are listed in the plan's `flow` region on the way (what the
+            # keyframe flow test of dpvo.py:257-270 reads; dpvo_frame_update does this for its own plan)
+            qi, qj = flow_pair if flow_pair is not None else (-1, -1)
+            rc = L.lib().dpvo_plan_build_window_flow(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
+                                                     ctypes.c_size_t(ws.numel()), L.i64(window[0]), L.i64(window[1]), L.i64(window[2]),
+                                                     L.i64(window[3]), L.i64(qi), L.i64(qj), L.stream())
             if rc != -2:
                 L.check(rc, "dpvo_plan_build_window")
         # n_frames / n_patch_ids: optional bounds on the index values (BUFFER_SIZE, BUFFER_SIZE * PATCHES_PER_FRAME): 32-bit keys
@@ -61,6 +64,8 @@ class GraphPlan:
     def __getattr__(self, name):
         if name == "counts":
             v = self.buf[self._lay.counts:self._lay.counts + 4]
+        elif name == "flow":         # {qi, qj, n_ij, n_ji} + 2 x 256 patch ids (dpvo_plan_layout_t.flow)
+            v = self.buf[self._lay.flow:self._lay.flow + 4 + 2 * 256]
         elif name in GraphPlan._VIEWS:
             n, mul = max(self.E, 1), GraphPlan._VIEWS[name]
             cnt = n + 1 if isinstance(mul, tuple) else mul * n

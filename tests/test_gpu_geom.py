@@ -165,3 +165,37 @@ def test_plan_window_reports_ids_outside_the_window(dev):
     for name in ("perm_k", "ku", "ix", "jx", "perm_p", "pu"):
         assert torch.equal(getattr(wide, name), getattr(good, name)), name
     assert wide.counts.cpu().tolist()[:2] == good.counts.cpu().tolist()[:2]
+
+
+def test_plan_flow_list_and_flow_test_bits(dev):
+    """dpvo_plan_build_window_flow: the plan's `flow` region lists the edges of ONE frame pair in both directions, in edge order; the
+    flow test (DPVO.motionmag, dpvo.py:257-270) started from that list gives the same BITS as the walk through pair_ij / pair_off /
+    perm_p; a pair without edges and every other builder leave the readers on the walk"""
+    from dpvo_amd import projective_ops as pops
+    ii, jj, kk = S.replay_graph(20)
+    poses, patches, intr = (t.to(dev) for t in S.make_scene(20))
+    flo, nfw, plo, npw = int(min(ii.min(), jj.min())), int(max(ii.max(), jj.max())) + 1, int(kk.min()), int(kk.max()) + 1
+    win = (flo, nfw - flo, plo, npw - plo)
+    d = lambda t: t.to(dev)
+    plain = GraphPlan(d(ii), d(jj), d(kk), window=win)
+    assert plain.flow.cpu().tolist()[:4] == [-1, -1, 0, 0]
+    ranged = GraphPlan(d(ii), d(jj), d(kk), n_frames=4096, n_patch_ids=4096 * 96)
+    assert ranged.flow.cpu().tolist()[:2] == [-1, -1]
+    for qi, qj in ((14, 16), (16, 14), (3, 19)):
+        listed = GraphPlan(d(ii), d(jj), d(kk), window=win, flow_pair=(qi, qj))
+        fl = listed.flow.cpu().numpy()
+        fwd, bwd = kk[(ii == qi) & (jj == qj)].numpy(), kk[(ii == qj) & (jj == qi)].numpy()
+        assert fl[:4].tolist() == [qi, qj, fwd.size, bwd.size]
+        assert np.array_equal(fl[4:4 + fwd.size], fwd) and np.array_equal(fl[4 + 256:4 + 256 + bwd.size], bwd)
+        for name in ("perm_k", "ku", "ix", "jx", "perm_p", "pu", "counts"):
+            assert torch.equal(getattr(listed, name), getattr(plain, name)), name
+        ng = plain.n_pairs()
+        assert torch.equal(listed.pair_off[:ng + 1], plain.pair_off[:ng + 1]) and torch.equal(listed.pair_ij[:2 * ng], plain.pair_ij[:2 * ng])
+        outs = []
+        for plan in (plain, listed, ranged):
+            host = torch.empty(8, dtype=torch.float32).pin_memory()
+            fin = pops.motionmag_pair(poses, patches, intr, d(ii), d(jj), d(kk), qi, qj, plan=plan, defer=True, host_buf=host)
+            fin()
+            outs.append(host[:4].clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (qi, qj, outs)
+        assert (outs[0][1] == fwd.size) and (outs[0][3] == bwd.size)
