@@ -244,21 +244,9 @@ __device__ __forceinline__ void median_depth_body(float* __restrict__ patches, i
   const int per = M * PP, cnt = 3 * per;
   const float* src = patches + (int64_t)(n - 3) * M * 3 * PP;
   if (threadIdx.x == 0) found_s = 0;
-  // (cnt <= 4096: at most 16 values per thread, all loads in flight before the first LDS store -- as a rolled loop they were up to
-  //  16 dependent global round trips, most of this kernel's 18 us)
-  {
-    float t[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = threadIdx.x + 256 * u;
-      const int f = i / per, r = i - f * per, m = r / PP, p = r - m * PP;
-      t[u] = i < cnt ? src[((int64_t)(f * M + m) * 3 + 2) * PP + p] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = threadIdx.x + 256 * u;
-      if (i < cnt) v[i] = t[u];
-    }
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int f = i / per, r = i - f * per, m = r / PP, p = r - m * PP;
+    v[i] = src[((int64_t)(f * M + m) * 3 + 2) * PP + p];
   }
   __syncthreads();
   const int i = bid * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
@@ -333,21 +321,6 @@ __device__ __forceinline__ void frame_patches_body(const FramePatchesArgs& A, in
   const int fi = fp_floor_int(y), fj = fp_floor_int(x);
   // gmap: 9 window positions x CF channels (channels fastest in both the NHWC source and the channels-last slot)
   // (every output group is optional: a null slot skips it, so the state stores and the feature gathers can be two launches)
-  if (gmap_slot && CF == 128) {
-    // (the usual feature width: 9 x 128 outputs = 4.5 per thread, their 20 taps fetched before the first blend instead of in five
-    //  dependent trips of four)
-    float o[5];
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int e = t + 256 * u, c = e & 127, ab = min(e >> 7, 8), a = ab / 3, b = ab - 3 * a;
-      o[u] = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w, [&](int i, int j) { return (float)fmap[((int64_t)i * w + j) * 128 + c]; });
-    }
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int e = t + 256 * u;
-      if (e < 9 * 128) gmap_slot[(int64_t)m * 9 * 128 + e] = (_Float16)o[u];
-    }
-  } else
   for (int e = t; gmap_slot && e < 9 * CF; e += 256) {
     const int c = e % CF, ab = e / CF, a = ab / 3, b = ab - 3 * a;
     const float o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w,

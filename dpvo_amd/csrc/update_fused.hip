@@ -578,32 +578,17 @@ __global__ __launch_bounds__(384) void softagg_kernel(const _Float16* __restrict
     float m[4], s[4], a[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; s[r] = 0.f; a[r] = 0.f; }
-    // members in batches of 8 per slice: the 8 edge ids first, then the 16 row loads, then the chain in member order (as a
-    // rolled loop every member was two dependent round trips -- id, then row -- in front of its part of the chain)
-    constexpr int UB = 8;
-    for (int p0 = b + q; p0 < e; p0 += 4 * UB) {
-      int id[UB];
+    for (int p = b + q; p < e; p += 4) {
+      const _Float16* rowp = fg + (int64_t)perm[p] * ldfg + 4 * cq;
+      const h4 fx = *reinterpret_cast<const h4*>(rowp), gx = *reinterpret_cast<const h4*>(rowp + D);
 #pragma unroll
-      for (int u = 0; u < UB; ++u) id[u] = (p0 + 4 * u < e) ? perm[p0 + 4 * u] : -1;
-      h4 fx[UB], gx[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const _Float16* rowp = fg + (int64_t)(id[u] < 0 ? 0 : id[u]) * ldfg + 4 * cq;
-        if (id[u] >= 0) { fx[u] = *reinterpret_cast<const h4*>(rowp); gx[u] = *reinterpret_cast<const h4*>(rowp + D); }
-        else { fx[u] = (h4)(_Float16)0.f; gx[u] = (h4)(_Float16)0.f; }
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        if (id[u] < 0) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g_ = (float)gx[u][r];
-          const float mn = fmaxf(m[r], g_);
-          const float sc = __expf(m[r] - mn), w = __expf(g_ - mn);
-          s[r] = s[r] * sc + w;
-          a[r] = a[r] * sc + w * (float)fx[u][r];
-          m[r] = mn;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float g_ = (float)gx[r];
+        const float mn = fmaxf(m[r], g_);
+        const float sc = __expf(m[r] - mn), w = __expf(g_ - mn);
+        s[r] = s[r] * sc + w;
+        a[r] = a[r] * sc + w * (float)fx[r];
+        m[r] = mn;
       }
     }
 #pragma unroll
