@@ -235,8 +235,11 @@ __global__ void motion_model_kernel(float* __restrict__ poses, int n, float scal
 
 // ---- depth initialisation (dpvo.py:427-432): patches[n][:, 2] = median(patches[n-3:n, :, 2]) (torch.median = lower
 //      median of the flattened values).  Rank counting instead of a sort: element i is the lower median iff exactly
-//      (cnt-1)/2 elements precede it in the total order (value, index).  32 elements per block, 8 lanes per element each
-//      counting an eighth of the candidates (LDS, float4 reads); the one block that owns the median writes the new frame.
+//      (cnt-1)/2 elements precede it in the total order (value, index).  kMedPerBlock = 4 elements per block, ONE WAVE per
+//      element: lane l compares against candidates 4 (l + 64 k) .. + 3 (conflict-free 16-byte LDS reads, ~10 trips for the
+//      usual 2 592 values; with 8 lanes per element the 81 trips of a lane were 17 us of the frame's start); the one block
+//      that owns the median writes the new frame.
+constexpr int kMedPerBlock = 4;
 __device__ __forceinline__ void median_depth_body(float* __restrict__ patches, int n, int M, int PP, int bid) {
   __shared__ __attribute__((aligned(16))) float v[4096 + 32];
   __shared__ float med_s;
@@ -249,22 +252,20 @@ __device__ __forceinline__ void median_depth_body(float* __restrict__ patches, i
     v[i] = src[((int64_t)(f * M + m) * 3 + 2) * PP + p];
   }
   __syncthreads();
-  const int i = bid * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
-  const int chunk = (((cnt + 7) >> 3) + 3) & ~3;          // candidates per lane, a multiple of 4
-  const int j0 = part * chunk, j1 = min(cnt, j0 + chunk);
+  const int lane = threadIdx.x & 63;
+  const int i = bid * kMedPerBlock + (threadIdx.x >> 6);
   const float x = i < cnt ? v[i] : 0.f;
   int rank = 0;
-  for (int j = j0; j < j1; j += 4) {
+  for (int j = 4 * lane; j < cnt; j += 256) {
     const float4 y = *reinterpret_cast<const float4*>(v + j);
     rank += (y.x < x) || (y.x == x && j < i);
-    if (j + 1 < j1) rank += (y.y < x) || (y.y == x && j + 1 < i);
-    if (j + 2 < j1) rank += (y.z < x) || (y.z == x && j + 2 < i);
-    if (j + 3 < j1) rank += (y.w < x) || (y.w == x && j + 3 < i);
+    if (j + 1 < cnt) rank += (y.y < x) || (y.y == x && j + 1 < i);
+    if (j + 2 < cnt) rank += (y.z < x) || (y.z == x && j + 2 < i);
+    if (j + 3 < cnt) rank += (y.w < x) || (y.w == x && j + 3 < i);
   }
-  rank += __shfl_xor(rank, 1);
-  rank += __shfl_xor(rank, 2);
-  rank += __shfl_xor(rank, 4);
-  if (part == 0 && i < cnt && rank == (cnt - 1) / 2) { med_s = x; found_s = 1; }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) rank += __shfl_xor(rank, o);
+  if (lane == 0 && i < cnt && rank == (cnt - 1) / 2) { med_s = x; found_s = 1; }
   __syncthreads();
   if (!found_s) return;
   const float med = med_s;
@@ -321,6 +322,34 @@ __device__ __forceinline__ void frame_patches_body(const FramePatchesArgs& A, in
   const int fi = fp_floor_int(y), fj = fp_floor_int(x);
   // gmap: 9 window positions x CF channels (channels fastest in both the NHWC source and the channels-last slot)
   // (every output group is optional: a null slot skips it, so the state stores and the feature gathers can be two launches)
+  if (gmap_slot && imap_slot && !(CF % 8) && !(CI % 8) && 9 * (CF / 8) + CI / 8 <= 256) {
+    // 8 channels (16 bytes) per thread: work items [0, 9 CF/8) = gmap (window position ab, channel group), then CI/8 imap groups;
+    // the four taps of an item are four 16-byte loads in flight together.  (One channel per thread: 18 two-byte loads per
+    // thread in five dependent trips, 7-10 us of part 2.)  Same blend, same rounding per channel.
+    const int ng = 9 * (CF / 8), item = t;
+    if (item < ng + CI / 8) {
+      const bool isg = item < ng;
+      const int grp = isg ? item % (CF / 8) : item - ng, ab = isg ? item / (CF / 8) : 4, a = ab / 3, b = ab - 3 * a;
+      const int C = isg ? CF : CI, i0 = fi + a - 1, j0 = fj + b - 1;           // (imap: the centre position, ab = 4)
+      const _Float16* src = isg ? fmap : imap;
+      const float dx = x - floorf(x), dy = y - floorf(y);
+      h8 tap[2][2];
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int i = i0 + aa, j = j0 + bb;
+          if (i >= 0 && i < h && j >= 0 && j < w) tap[aa][bb] = *reinterpret_cast<const h8*>(src + ((int64_t)i * w + j) * C + 8 * grp);
+          else tap[aa][bb] = (h8)(_Float16)0.f;
+        }
+      h8 o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        o[c] = (_Float16)blend4_ref(dx, dy, (float)tap[0][0][c], (float)tap[0][1][c], (float)tap[1][0][c], (float)tap[1][1][c]);
+      _Float16* dst = isg ? gmap_slot + ((int64_t)m * 9 + ab) * CF + 8 * grp : imap_slot + (int64_t)m * CI + 8 * grp;
+      *reinterpret_cast<h8*>(dst) = o;
+    }
+  } else {
   for (int e = t; gmap_slot && e < 9 * CF; e += 256) {
     const int c = e % CF, ab = e / CF, a = ab / 3, b = ab - 3 * a;
     const float o = fp_blend(x, y, fi + a - 1, fj + b - 1, h, w,
@@ -330,6 +359,7 @@ __device__ __forceinline__ void frame_patches_body(const FramePatchesArgs& A, in
   for (int c = t; imap_slot && c < CI; c += 256) {
     const float o = fp_blend(x, y, fi, fj, h, w, [&](int i, int j) { return (float)imap[((int64_t)i * w + j) * CI + c]; });
     imap_slot[(int64_t)m * CI + c] = (_Float16)o;
+  }
   }
   if (t < 27) {
     if (!patches_slot) return;
@@ -369,7 +399,11 @@ struct FrameStateArgs {
   int64_t *ii, *jj, *kk; float* net; const int64_t* ix; int64_t E0; int ap_n, ap_r, D;
   int n_med, n_pool, n_app;
 };
-__global__ __launch_bounds__(256) void frame_state_kernel(FrameStateArgs S) {
+#ifdef FS_TRACE
+// instrumentation build (tools/fs_trace.sh): start / end of every workgroup of the last launch (100 MHz wall clock)
+__device__ unsigned long long fs_trace_buf[2][4096][2];
+#endif
+__device__ __forceinline__ void frame_state_roles(const FrameStateArgs& S) {
   int b = blockIdx.x;
   if (b < S.fp.M) { frame_patches_body(S.fp, b); return; }
   b -= S.fp.M;
@@ -381,6 +415,24 @@ __global__ __launch_bounds__(256) void frame_state_kernel(FrameStateArgs S) {
   b -= S.n_pool;
   append_edges_body(S.ii, S.jj, S.kk, S.net, S.ix, S.E0, S.ap_n, S.fp.M, S.ap_r, S.D, b, S.n_app);
 }
+__global__ __launch_bounds__(256) void frame_state_kernel(FrameStateArgs S) {
+#ifdef FS_TRACE
+  const int part = S.n_pool ? 1 : 0;
+  if (threadIdx.x == 0 && blockIdx.x < 4096) fs_trace_buf[part][blockIdx.x][0] = wall_clock64();
+#endif
+  frame_state_roles(S);
+#ifdef FS_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 4096) fs_trace_buf[part][blockIdx.x][1] = wall_clock64();
+#endif
+}
+#ifdef FS_TRACE
+}  // namespace
+extern "C" int dpvo_debug_fs_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs_trace_buf), sizeof(fs_trace_buf)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 inline unsigned grid_for(int64_t n, int cap = 4096) {
   int64_t g = cdiv64(n, 256);
@@ -533,7 +585,7 @@ extern "C" int dpvo_frame_state_part(dpvo_frame_state_t* p, int part, void* stre
     const int n = q.ap_n, r = q.ap_r, jlo = n - r > 0 ? n - r : 0;
     const int64_t total = (int64_t)M * ((n - 1 > 0 ? n - 1 : 0) - jlo) + (int64_t)M * (n - jlo);
     p->n_new = total;
-    S.n_med = (3 * M * 9 + 31) / 32;
+    S.n_med = (3 * M * 9 + kMedPerBlock - 1) / kMedPerBlock;
     S.n_app = total > 0 ? (int)grid_for(total * (q.D / 4), 2048) : 0;
   } else {
     S.n_pool = (int)(((int64_t)(q.h / 4) * (q.w / 4) * (q.CF / 8) + 255) / 256);
@@ -564,7 +616,7 @@ extern "C" int dpvo_frame_state(dpvo_frame_state_t* p, void* stream) {
     S.patches_all = p->patches_all; S.md_n = p->md_n; S.P = p->P;
     S.fmap2_slot = (_Float16*)p->fmap2_slot;
     S.ii = p->ii; S.jj = p->jj; S.kk = p->kk; S.net = p->net; S.ix = p->ix; S.E0 = p->E0; S.ap_n = n; S.ap_r = r; S.D = p->D;
-    S.n_med = (3 * M * 9 + 31) / 32;
+    S.n_med = (3 * M * 9 + kMedPerBlock - 1) / kMedPerBlock;
     S.n_pool = (int)(((int64_t)(p->h / 4) * (p->w / 4) * (p->CF / 8) + 255) / 256);
     S.n_app = total > 0 ? (int)grid_for(total * (p->D / 4), 2048) : 0;
     hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(M + 1 + S.n_med + S.n_pool + S.n_app)), dim3(256), 0, (hipStream_t)stream,
@@ -594,7 +646,7 @@ extern "C" int dpvo_motion_model(float* poses, int n, float scale, void* stream)
 extern "C" int dpvo_median_depth(float* patches, int n, int M, int P, void* stream) {
   if (!patches || n < 3 || M <= 0 || P <= 0) return DPVO_E_INVALID;
   if (3 * M * P * P > 4096) return DPVO_E_UNSUPPORTED;
-  hipLaunchKernelGGL(median_depth_kernel, dim3((3 * M * P * P + 31) / 32), dim3(256), 0, (hipStream_t)stream, patches, n, M,
+  hipLaunchKernelGGL(median_depth_kernel, dim3((3 * M * P * P + kMedPerBlock - 1) / kMedPerBlock), dim3(256), 0, (hipStream_t)stream, patches, n, M,
                      P * P);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
