@@ -309,7 +309,20 @@ void kf_apply_launch(const dpvo_keyframe_step_t* a, hipStream_t st) {
 }
 }  // namespace
 
+#ifdef FU_HOST_TRACE
+// instrumentation build (tools/fu_host_trace.sh): host time between the steps of dpvo_frame_update, summed over the calls
+#include <chrono>
+static double fu_ht_sum[16]; static long fu_ht_calls;
+static inline double fu_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HT(i) do { const double t_ = fu_now(); fu_ht_sum[i] += t_ - ht_prev; ht_prev = t_; } while (0)
+extern "C" int dpvo_debug_fu_host_trace(double* out) { for (int i = 0; i < 16; ++i) out[i] = fu_ht_calls ? fu_ht_sum[i] / fu_ht_calls : 0.0; for (int i = 0; i < 16; ++i) fu_ht_sum[i] = 0; fu_ht_calls = 0; return 0; }
+#else
+#define HT(i) do {} while (0)
+#endif
 extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
+#ifdef FU_HOST_TRACE
+  double ht_prev = fu_now(); ++fu_ht_calls;
+#endif
   if (!a || !a->upd || !a->result_dev) return DPVO_E_INVALID;
   const dpvo_keyframe_step_t& K = a->kf;
   const int64_t E = K.E;
@@ -355,6 +368,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
       if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
     }
   }
+  HT(0);     // frame state part 1
   // ---- graph plan: every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
   //      PATCH_LIFETIME frames of it (dpvo.py:305,362-375): counting-sort build over that window, bounds on the group counts
   const int RW = K.removal_window, PL = a->patch_lifetime;
@@ -367,21 +381,23 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   // of the correlation kernel instead of in front of them
   const bool plan_aside = a->plan_stream && a->ev_plan_fork && a->ev_plan_done;
   if ((a->plan_stream || a->ev_plan_fork || a->ev_plan_done) && !plan_aside) return DPVO_E_INVALID;
-  void* pst = stream;
-  if (plan_aside) {
-    pst = a->plan_stream;
-    if (hipEventRecord((hipEvent_t)a->ev_plan_fork, st) != hipSuccess ||
-        hipStreamWaitEvent((hipStream_t)pst, (hipEvent_t)a->ev_plan_fork, 0) != hipSuccess) return DPVO_E_INVALID;
-  }
   // (with the flow test's frame pair (k - 1, k + 1), k = n - KEYFRAME_INDEX, extracted on the way: dpvo_plan_layout_t.flow)
-  rc = dpvo_plan_build_window_flow(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M,
-                                   n - K.keyframe_index - 1, n - K.keyframe_index + 1, pst);
-  if (rc == DPVO_E_UNSUPPORTED)
-    rc = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, pst);
-  if (plan_aside && hipEventRecord((hipEvent_t)a->ev_plan_done, (hipStream_t)pst) != hipSuccess) return DPVO_E_INVALID;
-  if (rc) return rc;
+  auto build_plan = [&](void* pst) -> int {
+    int r = dpvo_plan_build_window_flow(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M,
+                                        n - K.keyframe_index - 1, n - K.keyframe_index + 1, pst);
+    if (r == DPVO_E_UNSUPPORTED)
+      r = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, pst);
+    return r;
+  };
+  // aside: only the fork point is marked here; the plan's launches are ISSUED behind the correlation kernel's -- the front of the
+  // frame is short kernels that the GPU finishes faster than the host enqueues them, so whatever the host issues in front of the
+  // correlation launch delays it, on whichever stream it runs
+  if (plan_aside) { if (hipEventRecord((hipEvent_t)a->ev_plan_fork, st) != hipSuccess) return DPVO_E_INVALID; }
+  else STEP(build_plan(stream));
+  HT(1);     // fork record / plan on the compute stream
   // ---- reproject -> correlation -> update operator (dpvo.py:331-343)
   STEP(dpvo_reproject(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->coords, E, a->P, 1, stream));
+  HT(2);     // reproject
   if (a->fs && a->ev_enc) {
     if (hipStreamWaitEvent(st, (hipEvent_t)a->ev_enc, 0) != hipSuccess) return DPVO_E_INVALID;
     // the encoders wrote the frame's feature map where the host EXPECTED its ring slot to be; a keyframe dropped in between moved
@@ -392,17 +408,30 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
     STEP(dpvo_frame_state_part(a->fs, 2, stream));
     if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
   }
+  HT(3);     // encoder join + part 2
   if (a->ev[0] && hipEventRecord((hipEvent_t)a->ev[0], st) != hipSuccess) return DPVO_E_INVALID;
   STEP(dpvo_corr_pyramid_forward(a->gmap, a->fmap1, a->fmap2, a->coords, K.kk, K.jj, nullptr, a->corr, 896, E, 128, a->P,
                                  (int64_t)a->pmem * M, a->mem, a->H0, a->W0, a->H1, a->W1, 3, stream));
   if (a->ev[1] && hipEventRecord((hipEvent_t)a->ev[1], st) != hipSuccess) return DPVO_E_INVALID;
   if (a->ev[2] && a->ev[2] != a->ev[1] && hipEventRecord((hipEvent_t)a->ev[2], st) != hipSuccess) return DPVO_E_INVALID;   // (one record serves both)
-  if (plan_aside && hipStreamWaitEvent(st, (hipEvent_t)a->ev_plan_done, 0) != hipSuccess) return DPVO_E_INVALID;
+  HT(4);     // correlation (+ profiling events)
+  if (plan_aside) {
+    hipStream_t pst = (hipStream_t)a->plan_stream;
+    if (hipStreamWaitEvent(pst, (hipEvent_t)a->ev_plan_fork, 0) != hipSuccess) return DPVO_E_INVALID;
+    HT(5);   // plan stream waits for the fork
+    STEP(build_plan(a->plan_stream));
+    HT(6);   // plan launches
+    if (hipEventRecord((hipEvent_t)a->ev_plan_done, pst) != hipSuccess) return DPVO_E_INVALID;
+    HT(7);   // plan-done record
+    if (hipStreamWaitEvent(st, (hipEvent_t)a->ev_plan_done, 0) != hipSuccess) return DPVO_E_INVALID;
+    HT(8);   // compute stream waits for the plan
+  }
   float* net = a->net;
   float* target = const_cast<float*>(K.target);
   float* weight = const_cast<float*>(K.weight);
   STEP(dpvo_update_forward_fused_rows(a->upd, net, a->net_rows, a->n_kept, a->imap, K.kk, (int64_t)a->pmem * M, a->corr, 896, a->plan, np_ub, ng_ub,
                                       a->coords, a->P, net, a->delta, weight, target, E, a->ws_update, a->ws_update_bytes, stream));
+  HT(9);     // update operator
   if (a->ev[3] && hipEventRecord((hipEvent_t)a->ev[3], st) != hipSuccess) return DPVO_E_INVALID;
   if (a->ev_update_done && hipEventRecord((hipEvent_t)a->ev_update_done, st) != hipSuccess) return DPVO_E_INVALID;
   // ---- two local BA iterations over the last ba_window poses (dpvo.py:351-354), point cloud (:358-360)
@@ -410,6 +439,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (t0 < 1) t0 = 1;
   STEP(dpvo_ba(a->poses, a->patches, a->intrinsics, target, weight, a->lmbda, K.ii, K.jj, K.kk, a->plan, np_ub, ng_ub, E, a->P, t0, n,
                a->iterations, nullptr, a->ws_ba, a->ws_ba_bytes, stream));
+  HT(10);    // update-done records + BA
   // ---- point cloud, and the keyframe's flow test between frames k - 1 and k + 1 (dpvo.py:266-269), in one launch; then everything
   //      else of the keyframe step on the device
   // Order (round 4): flow test + decision + index lists + RESULT RECORD first, the event the host waits for right behind them,
@@ -433,6 +463,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (a->ev_record && hipEventRecord((hipEvent_t)a->ev_record, st) != hipSuccess) return DPVO_E_INVALID;
   STEP(dpvo_point_cloud(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, a->P, stream));
   kf_apply_launch(&kf, st);
+  HT(11);    // keyframe step + record + point cloud
   DPVO_LAUNCH_CHECK();
 #undef STEP
   return DPVO_OK;

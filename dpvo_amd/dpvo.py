@@ -58,7 +58,12 @@ _STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
 _HOST_TRACE = [] if __import__('os').environ.get('DPVO_HOST_TRACE') else None      # (dev aid: host time stamps around the frame call)
 _PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
 _BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
-_PLAN_ASIDE = bool(int(__import__('os').environ.get('DPVO_PLAN_ASIDE', '1')))          # 0: the graph plan in front of the reprojection, on the compute stream (rounds 1-3)
+# DPVO_PLAN_ASIDE=1: the graph plan's five launches on the side stream (dpvo_frame_update_t.plan_stream), forked behind the new
+# frame's edges and joined in front of the update operator.  Measured (profiles/README.md, round 4): -36 us per frame on a box
+# whose MFMA kernels run at 60 % speed, -25 .. +10 us elsewhere, and +300 us of host CPU per frame in every case -- on this ROCm a
+# stream wait for an event that is still pending when it is issued is resolved by a runtime thread, not by the queues.  Off.
+_PLAN_ASIDE = bool(int(__import__('os').environ.get('DPVO_PLAN_ASIDE', '0')))
+_PLAN_OWN_STREAM = bool(int(__import__('os').environ.get('DPVO_PLAN_OWN_STREAM', '0')))   # (with it: a third stream instead of the encoders')
 _EARLY_RECORD = bool(int(__import__('os').environ.get('DPVO_EARLY_RECORD', '1')))      # 0: wait for the end of the whole frame call (round 3)
 _MAX_SLEEP_S = 2.0e-3      # no single pacing sleep is longer than this, whatever the running mean says
 _MAX_FRAME_S = 4.0e-3      # a wait longer than this is not a frame's GPU time (first frames, a paused caller): clamped in the mean
@@ -662,7 +667,12 @@ class DPVO:
                 evs = fu["ev_plan"] = [torch.cuda.Event(), torch.cuda.Event()]
                 for e_ in evs:
                     e_.record()         # (creates the handles)
-            a.plan_stream, a.ev_plan_fork, a.ev_plan_done = self._enc_stream.cuda_stream, evs[0].cuda_event, evs[1].cuda_event
+            ps = self._enc_stream
+            if _PLAN_OWN_STREAM:
+                ps = fu.get("plan_stream")
+                if ps is None:
+                    ps = fu["plan_stream"] = torch.cuda.Stream(device=self.device)
+            a.plan_stream, a.ev_plan_fork, a.ev_plan_done = ps.cuda_stream, evs[0].cuda_event, evs[1].cuda_event
         else:
             a.plan_stream = a.ev_plan_fork = a.ev_plan_done = None
         self._stamp(3)

@@ -494,3 +494,31 @@ print("ok", poses.shape)
 """
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_plan_on_the_side_stream_is_bit_identical(dev):
+    """dpvo_frame_update_t.plan_stream (DPVO_PLAN_ASIDE=1, off by default): the graph plan issued on the encoders' stream, forked behind
+    the new frame's edges and joined in front of the update operator -- same tracker state, bit for bit, with unscripted keyframe
+    decisions (the flow test reads the plan's edge list) and with a third stream"""
+    import dpvo_amd.dpvo as dpvo_mod
+    _, probe = _run_unforced(dev, -1.0, n_frames=30, overlap_encoders=True, defer_keyframe=True)
+    thr = float(np.median([f for _, f in probe]))
+    before = (dpvo_mod._PLAN_ASIDE, dpvo_mod._PLAN_OWN_STREAM)
+    runs = []
+    try:
+        for aside, own in ((False, False), (True, False), (True, True)):
+            dpvo_mod._PLAN_ASIDE, dpvo_mod._PLAN_OWN_STREAM = aside, own
+            slam, log = _run_unforced(dev, thr, n_frames=40, overlap_encoders=True, defer_keyframe=True)
+            torch.cuda.synchronize()
+            runs.append((slam, log))
+            if aside:
+                assert slam._fu is not None and slam._fu.get("ev_plan") is not None, "the side-stream plan was not exercised"
+    finally:
+        dpvo_mod._PLAN_ASIDE, dpvo_mod._PLAN_OWN_STREAM = before
+    a = runs[0][0]
+    assert any(d for d, _ in runs[0][1]) and not all(d for d, _ in runs[0][1])
+    for b, log in runs[1:]:
+        assert [d for d, _ in log] == [d for d, _ in runs[0][1]] and a.n == b.n
+        for k in ("ii", "jj", "kk", "net", "target", "weight"):
+            assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)), k
+        assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
