@@ -49,19 +49,30 @@ __device__ __forceinline__ void ba_patch_body(const int64_t* __restrict__ ii, co
     int ix = -1;
     if (k < np) {
       const int b0 = patch_off[k], b1 = patch_off[k + 1];
-      for (int p = b0 + sub; p < b1; p += 8) {
-        const int e = perm_k[p];
-        const f4* eb = reinterpret_cast<const f4*>(edgebuf + (int64_t)e * kEdgeStride);
-        const f4 v0 = eb[0], v1 = eb[1], v2 = eb[2], v3 = eb[3];
-        C += v0[0]; u += v0[1];
-        Ei[0] += v0[2]; Ei[1] += v0[3]; Ei[2] += v1[0]; Ei[3] += v1[1]; Ei[4] += v1[2]; Ei[5] += v1[3];
-        ix = (int)ii[e] - t0;
-        const int jx = (int)jj[e] - t0;
-        if (jx >= 0 && jx < N) {
-          // distinct (patch, j) edges own distinct slots; duplicates (if any) are folded by the LDS add
-          atomicAdd(&col[pl][6 * jx + 0], v2[0]); atomicAdd(&col[pl][6 * jx + 1], v2[1]);
-          atomicAdd(&col[pl][6 * jx + 2], v2[2]); atomicAdd(&col[pl][6 * jx + 3], v2[3]);
-          atomicAdd(&col[pl][6 * jx + 4], v3[0]); atomicAdd(&col[pl][6 * jx + 5], v3[1]);
+      // two edges per lane and trip (a patch has ~14 edges: one trip of the offset -> edge id -> record chain instead of two);
+      // the sums keep the order p, p + 8
+      for (int p = b0 + sub; p < b1; p += 16) {
+        const bool two = p + 8 < b1;
+        const int e0 = perm_k[p], e1 = two ? perm_k[p + 8] : e0;
+        const f4* eb0 = reinterpret_cast<const f4*>(edgebuf + (int64_t)e0 * kEdgeStride);
+        const f4* eb1 = reinterpret_cast<const f4*>(edgebuf + (int64_t)e1 * kEdgeStride);
+        const f4 a0 = eb0[0], a1 = eb0[1], a2 = eb0[2], a3 = eb0[3];
+        const f4 c0 = eb1[0], c1 = eb1[1], c2 = eb1[2], c3 = eb1[3];
+        const int i0 = (int)ii[e0], j0 = (int)jj[e0], i1 = (int)ii[e1], j1 = (int)jj[e1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !two) break;
+          const f4 v0 = h ? c0 : a0, v1 = h ? c1 : a1, v2 = h ? c2 : a2, v3 = h ? c3 : a3;
+          C += v0[0]; u += v0[1];
+          Ei[0] += v0[2]; Ei[1] += v0[3]; Ei[2] += v1[0]; Ei[3] += v1[1]; Ei[4] += v1[2]; Ei[5] += v1[3];
+          ix = (h ? i1 : i0) - t0;
+          const int jx = (h ? j1 : j0) - t0;
+          if (jx >= 0 && jx < N) {
+            // distinct (patch, j) edges own distinct slots; duplicates (if any) are folded by the LDS add
+            atomicAdd(&col[pl][6 * jx + 0], v2[0]); atomicAdd(&col[pl][6 * jx + 1], v2[1]);
+            atomicAdd(&col[pl][6 * jx + 2], v2[2]); atomicAdd(&col[pl][6 * jx + 3], v2[3]);
+            atomicAdd(&col[pl][6 * jx + 4], v3[0]); atomicAdd(&col[pl][6 * jx + 5], v3[1]);
+          }
         }
       }
     }
@@ -94,21 +105,36 @@ __device__ __forceinline__ void ba_patch_body(const int64_t* __restrict__ ii, co
     const int k = ch * kPatchChunk + pl;
     if (k < np) Ecol[(int64_t)r * ldE + k] = col[pl][r];
   }
-  // partial S and y of this block
+  // partial S and y of this block on the matrix core:  [S | y] (n6 x (n6 + 1)) = col^T (Q col | Q u),  16 x 16 tiles, K = the 32
+  // patches in 8 steps of v_mfma_f32_16x16x4_f32 (an exact f32 fma chain in patch order).  (As 3 660 scalar dot products of
+  // length 32 this was 350 k LDS reads per block: 5 of the kernel's 21 us.)
   float* sp = spart + (int64_t)ch * kSEntries;
-  for (int ent = tid; ent < nent; ent += 256) {
-    float sum = 0.f;
-    if (ent < n6 * n6) {
-      const int a = ent / n6, b = ent - a * n6;
-#pragma unroll 8
-      for (int pl = 0; pl < kPatchChunk; ++pl) sum += qv[pl] * col[pl][a] * col[pl][b];
-    } else {
-      const int a = ent - n6 * n6;
-#pragma unroll 8
-      for (int pl = 0; pl < kPatchChunk; ++pl) sum += qv[pl] * uv[pl] * col[pl][a];
+  {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int nti = (n6 + 15) >> 4, ntj = (n6 + 1 + 15) >> 4;
+    for (int T = wave; T < nti * ntj; T += 4) {
+      const int ti = T / ntj, tj = T - ti * ntj;
+      const int ra = 16 * ti + li, cb = 16 * tj + li;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < kPatchChunk / 4; ++t) {
+        const int pl = 4 * t + lk;
+        const float a = ra < n6 ? col[pl][ra] : 0.f;
+        const float q = qv[pl];
+        const float b = cb < n6 ? q * col[pl][cb] : (cb == n6 ? q * uv[pl] : 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + 4 * lk + r;
+        if (row < n6) {
+          if (cb < n6) sp[row * n6 + cb] = acc[r];
+          else if (cb == n6) sp[n6 * n6 + row] = acc[r];
+        }
+      }
     }
-    sp[ent] = sum;
   }
+  (void)nent;
 }
 
 // ---------------------------------------------------------------------------------------------------
