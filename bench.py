@@ -21,7 +21,8 @@ launch path and the host-side cost, flagged in `config.parallelism`; not a scali
 
 The JSON line also carries
   roofline     -- the correlation kernel (corr_pyramid_kernel), mean launch duration from HIP events on the launch stream
-                  inside the timed region, against the 8 TB/s HBM3E peak, three ways:
+                  inside the timed region (around every 4th launch, `launches` of them: DPVO_PROFILE_EVERY), against the
+                  8 TB/s HBM3E peak, three ways:
                     frac = frac_counter: bytes per launch seen by the memory-side counters (`traffic`, committed PMC pass
                       profiles/rNN_corr_pmc.json, corrected as MI355X_MICROARCH.md prescribes) / duration / peak -- what the
                       memory system actually moved (Infinity-Cache hits included);
@@ -37,7 +38,8 @@ The JSON line also carries
                   same steady state (E = 45 312): frames/sec over 20 frames, rank 0 at N = 1 only; null when oracle/_ref is absent.
                   A reported baseline (the only same-node comparator north_star's ">= reference frames/sec" has), never `value`;
   box          -- the shader clock this box sustains under a full-chip / quarter-chip MFMA load (tools/probes/clock_probe.hip);
-  frame_period_ms -- device-side frame period (correlation start to correlation start) over the timed frames: median, p90, max;
+  frame_period_ms -- device-side frame period (correlation start to correlation start, averaged over windows of `window_frames`
+                  frames: the HIP events sit on every 4th frame) over the timed region: median, p90, max;
   state        -- whether the tracker state after the run is sane (finite poses, fraction of edges that project in
                   bounds): with random weights nothing guarantees that, and a diverged state would make the correlation
                   kernel skip its work; such a run carries an "error" field.
@@ -246,6 +248,9 @@ def main():
         dist = multiseq.init_distributed(backend, device)          # (raises if RCCL cannot be brought up: never a silent gloo run)
 
     os.environ.setdefault("DPVO_PROFILE_EVENTS", "1")      # the tracker creates its pool of timing events up front (warm-up), not in the timed region
+    # HIP events around the correlation kernel / the update operator on every 4th timed frame: each event record is a marker the
+    # stream stalls on, three of them per frame cost ~10 us of every frame (946-955 -> 957-960 frames/sec on one box, 963 without any)
+    os.environ.setdefault("DPVO_PROFILE_EVERY", "4")
     from dpvo_amd import altcorr
     from dpvo_amd.altcorr import correlation as corr_mod
     from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML, FAST_YAML
@@ -368,11 +373,13 @@ def main():
     # frame-to-frame period on the device (start of one frame's correlation kernel to the next one's): with 20-60 timed frames one
     # hiccup moves `value` by several per cent -- the median says what the steady state is, the max what the hiccup was
     period = None
+    stride = max(1, int(os.environ.get("DPVO_PROFILE_EVERY", "1")))     # (events on every stride-th frame: a window is stride frames)
     if len(prof) > 2:
-        raw = [prof[i][0].elapsed_time(prof[i + 1][0]) for i in range(len(prof) - 1)]
+        raw = [prof[i][0].elapsed_time(prof[i + 1][0]) / stride for i in range(len(prof) - 1)]
         per = sorted(raw)
         period = {"median": round(per[len(per) // 2], 4), "p90": round(per[int(0.9 * (len(per) - 1))], 4), "max": round(per[-1], 4),
-                  "max_at_frame": raw.index(per[-1]) + 1, "frames_per_sec_at_median": round(1e3 / per[len(per) // 2], 1)}
+                  "max_at_frame": stride * (raw.index(per[-1]) + 1), "frames_per_sec_at_median": round(1e3 / per[len(per) // 2], 1),
+                  "window_frames": stride}
     roof = None
     if corr_ms:
         avg_ms = sum(corr_ms) / len(corr_ms)
