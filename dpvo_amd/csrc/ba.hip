@@ -9,13 +9,14 @@
 //                         Jacobians; the pair's 13x13 Gram block  sum_rows w [Ji Jj r]^T [Ji Jj r]  (= Hii, Hij, Hjj,
 //                         vi, vj) is reduced on the matrix core with v_mfma_f32_16x16x4_f32 (exact f32 fma chain)
 //                         from an LDS row image -> pairbuf[g][16x16]; per-edge depth terms (c, u, Ei, Ej) -> edgebuf.
-//   2. ba_patch_kernel    a block owns 32 patches (CSR by patch), 8 lanes gather one patch's edges: builds the Schur
-//                         column e_k (6N) in LDS, stores Q, u, e_k, and the block's partial  sum_k Q_k e_k e_k^T,
-//                         sum_k Q_k u_k e_k  -> spart[block].  The same launch carries one extra block per free pose
-//                         that assembles its block row of B and v from pairbuf in a fixed order -> Bbuf (independent
-//                         work: it used to sit in front of the Schur subtraction in the next launch).
-//   3. ba_assemble_kernel six blocks per free pose, 4 lanes per entry of a row of S / y: B, v (Bbuf) minus the Schur
-//                         partials, plus the reference's damping S += I*(1e-4*S + 1)  -> Sg, yg.
+//   2. ba_patch_kernel    a block owns 32 patches (CSR by patch), 8 lanes gather one patch's edges (two per lane and trip): builds
+//                         the Schur column e_k (6N) in LDS, stores Q, u, e_k, and the block's partial  sum_k Q_k e_k e_k^T,
+//                         sum_k Q_k u_k e_k  (16 x 16 tiles on v_mfma_f32_16x16x4_f32) -> spart[block].  The same launch carries
+//                         one extra block per free pose that assembles its block row of B and v from pairbuf in a fixed order
+//                         (match list + direct pair tables, ba_bpart_body) -> Bbuf: independent work.
+//   3. ba_assemble_kernel six blocks per free pose, 16 lanes per entry of a row of S / y: B, v (Bbuf) minus the Schur
+//                         partials (all of an entry's loads in flight together), plus the reference's damping
+//                         S += I*(1e-4*S + 1)  -> Sg, yg.
 //   4. ba_solve60_kernel  n6 <= 60: one workgroup, 6x6-blocked right-looking Cholesky of [S; y^T] in LDS, blocked backward
 //                         substitution -> dX;  ba_solve_kernel (n6 <= 120): left-looking Cholesky in LDS (one barrier per
 //                         column), column-oriented triangular solves.
@@ -37,8 +38,11 @@ __device__ __forceinline__ void ba_patch_body(const int64_t* __restrict__ ii, co
   __shared__ float col[kPatchChunk][kMaxDim + 1];
   __shared__ float qv[kPatchChunk], uv[kPatchChunk];
   const int n6 = 6 * N;
-  const int np = *n_patches;
   const int tid = threadIdx.x;
+  // (the patch's edge range is fetched together with the patch count, not behind it: patch_off has an entry for every k a launch
+  //  sized from the E upper bound can reach -- it is E + 1 ints inside the plan buffer -- and the values are only used when k < np)
+  const int b0s = patch_off[ch * kPatchChunk + (tid >> 3)], b1s = patch_off[ch * kPatchChunk + (tid >> 3) + 1];
+  const int np = *n_patches;
   const int nent = n6 * n6 + n6;                       // S entries followed by y entries
   for (int a = tid; a < kPatchChunk * (kMaxDim + 1); a += 256) (&col[0][0])[a] = 0.f;
   __syncthreads();
@@ -48,7 +52,7 @@ __device__ __forceinline__ void ba_patch_body(const int64_t* __restrict__ ii, co
     float C = 0.f, u = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0};
     int ix = -1;
     if (k < np) {
-      const int b0 = patch_off[k], b1 = patch_off[k + 1];
+      const int b0 = b0s, b1 = b1s;
       // two edges per lane and trip (a patch has ~14 edges: one trip of the offset -> edge id -> record chain instead of two);
       // the sums keep the order p, p + 8
       for (int p = b0 + sub; p < b1; p += 16) {
@@ -143,99 +147,136 @@ __device__ __forceinline__ void ba_patch_body(const int64_t* __restrict__ ii, co
 //    waves 1..3: off-diagonal blocks (two binary searches in the LDS copy of the sorted pair list);
 //    then all threads: subtract the Schur partials (4 lanes per entry) and apply the damping.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kMaxPairsLds = 4096;
-
-__device__ __forceinline__ int find_pair(const int2* pl, int ng, int i, int j) {
-  int lo = 0, hi = ng - 1;
-  while (lo <= hi) {
-    const int mid = (lo + hi) >> 1;
-    const int2 v = pl[mid];
-    if (v.x == i && v.y == j) return mid;
-    if (v.x < i || (v.x == i && v.y < j)) lo = mid + 1; else hi = mid - 1;
-  }
-  return -1;
-}
+constexpr int kDiagSlices = 6;       // 42 entries x 6 interleaved slices of the match list = 252 threads
+constexpr int kMaxMatch = 256;       // pairs that touch one pose (<= 2 x the frames a pose shares edges with; ~50 in the tracker)
 
 // B part of block row p (and v of pose p) from the pair blocks, in a fixed order -> Bbuf[p][6][kMaxDim + 1] (column kMaxDim
 // holds v).  Independent of the per-patch kernel, whose launch it shares.
+//   phase 0  one scan of the pair list: the pairs with i == f or j == f go into a match list in pair order (wave ballots: the
+//            order is the pair order whatever the timing), and into two direct tables tabA[q] / tabB[q] = the pair (f, t0 + q) /
+//            (t0 + q, f) (round 3 found them by two binary searches per matrix entry: 18 dependent LDS reads);
+//   phase 1  the diagonal block + v as 42 entries x 6 interleaved slices of the match list (252 threads, four matches per trip),
+//            the off-diagonal blocks two entries per thread;
+//   phase 2  the six slices added in order, the row stored.
+// (Round 3's version -- per-thread 42-entry partial sums over a strided pair scan, 42 wave reductions, binary searches -- was the
+//  longest workgroup of the launch: 17 us against 7-12 for the per-patch blocks, tools/ba_trace.sh.)
 __device__ __forceinline__ void ba_bpart_body(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
                                               const float* __restrict__ pairbuf, int t0, int N, int p, float* __restrict__ Bbuf) {
-  __shared__ int2 plist[kMaxPairsLds];
-  __shared__ float rowS[6][kMaxDim];      // block row p of B (then S)
-  __shared__ float rowy[6];
+  __shared__ int mlist[kMaxMatch], mflag[kMaxMatch];
+  __shared__ int tabA[kMaxN], tabB[kMaxN];
+  __shared__ int wcnt[4], s_nm;
+  __shared__ float rowS[6][kMaxDim];      // block row p of B
+  __shared__ float dsl[kDiagSlices][42];  // diagonal block (36) + v (6), one row per slice of the match list
   const int n6 = 6 * N;
   const int ng = *n_pairs;
-  const int ngl = ng < kMaxPairsLds ? ng : kMaxPairsLds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = t0 + p;
   const int2* pg = reinterpret_cast<const int2*>(pair_ij);
-  for (int g = tid; g < ngl; g += 256) plist[g] = pg[g];
+  if (tid < kMaxN) { tabA[tid] = -1; tabB[tid] = -1; }
+  if (tid == 0) s_nm = 0;
   for (int a = tid; a < 6 * kMaxDim; a += 256) (&rowS[0][0])[a] = 0.f;
   __syncthreads();
-  const int2* pl = (ng <= kMaxPairsLds) ? plist : pg;   // (global fallback for very large graphs)
-  __shared__ float dpart[4][42];
-  {
-    // diagonal block + y: all 256 threads stride over the pairs, per-thread partial sums, fixed-order reduction
-    // (butterfly inside a wave, then waves 0..3 in order)
-    float acc[42];
+  // ---- phase 0
+  for (int g0 = 0; g0 < ng; g0 += 256) {
+    const int g = g0 + tid;
+    int2 ij = {-1, -1};
+    if (g < ng) ij = pg[g];
+    const bool hit = g < ng && (ij.x == f || ij.y == f);
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = s_nm;
+    for (int w = 0; w < wave; ++w) base += wcnt[w];
+    if (hit) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1));
+      if (pos < kMaxMatch) { mlist[pos] = g; mflag[pos] = (ij.x == f ? 1 : 0) | (ij.y == f ? 2 : 0); }
+      if (ij.x == f) { const int q = ij.y - t0; if (q >= 0 && q < N) tabA[q] = g; }
+      if (ij.y == f) { const int q = ij.x - t0; if (q >= 0 && q < N) tabB[q] = g; }
+    }
+    __syncthreads();
+    if (tid == 0) s_nm += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int nm = s_nm;
+  if (nm <= kMaxMatch) {
+    // ---- phase 1: diagonal block + v.  Thread (sl, en): slice sl = tid / 42 of the matches (m = sl, sl + 4, ...), entry en
+    if (tid < 42 * kDiagSlices) {
+      const int sl = tid / 42, en = tid - 42 * sl;
+      const int a = en < 36 ? en / 6 : en - 36, b = en < 36 ? en - 6 * (en / 6) : 0;
+      // the entry's offset inside a pair block on the i-side / the j-side, and the two cross terms of a self edge
+      const int oi = en < 36 ? a * 16 + b : a * 16 + 12, oj = en < 36 ? (6 + a) * 16 + 6 + b : (6 + a) * 16 + 12;
+      const int ox1 = a * 16 + 6 + b, ox2 = b * 16 + 6 + a;
+      const float si = en < 36 ? 1.f : -1.f;                                      // v -= w r Ji, v += w r Jj
+      float acc = 0.f;
+      for (int m0 = sl; m0 < nm; m0 += 4 * kDiagSlices) {                         // four matches per trip, their loads in flight together
+        float vi[4], vj[4], vx[4];
 #pragma unroll
-    for (int a = 0; a < 42; ++a) acc[a] = 0.f;
-    for (int g = tid; g < ng; g += 256) {
-      const int2 ij = pl[g];
-      if (ij.x != f && ij.y != f) continue;
-      const float* pb = pairbuf + (int64_t)g * kPairStride;
-      if (ij.x == f) {                                            // i-side: + w Ji Ji^T, v -= w r Ji
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + u * kDiagSlices;
+          vi[u] = vj[u] = vx[u] = 0.f;
+          if (m < nm) {
+            const int g = mlist[m], fl = mflag[m];
+            const float* pb = pairbuf + (int64_t)g * kPairStride;
+            if (fl & 1) vi[u] = pb[oi];
+            if (fl & 2) vj[u] = pb[oj];
+            if (fl == 3 && en < 36) vx[u] = -pb[ox1] - pb[ox2];
+          }
+        }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-          for (int b = 0; b < 6; ++b) acc[a * 6 + b] += pb[a * 16 + b];
-          acc[36 + a] -= pb[a * 16 + 12];
+        for (int u = 0; u < 4; ++u) { acc += si * vi[u]; acc += vj[u]; acc += vx[u]; }
+      }
+      dsl[sl][en] = acc;
+    }
+  } else {
+    // (more pairs at one pose than the list holds: one thread per entry walks the whole pair list)
+    if (tid < 42) {
+      const int en = tid, a = en < 36 ? en / 6 : en - 36, b = en < 36 ? en - 6 * (en / 6) : 0;
+      float acc = 0.f;
+      for (int g = 0; g < ng; ++g) {
+        const int2 ij = pg[g];
+        if (ij.x != f && ij.y != f) continue;
+        const float* pb = pairbuf + (int64_t)g * kPairStride;
+        if (en < 36) {
+          if (ij.x == f) acc += pb[a * 16 + b];
+          if (ij.y == f) acc += pb[(6 + a) * 16 + 6 + b];
+          if (ij.x == f && ij.y == f) acc += -pb[a * 16 + 6 + b] - pb[b * 16 + 6 + a];
+        } else {
+          if (ij.x == f) acc -= pb[a * 16 + 12];
+          if (ij.y == f) acc += pb[(6 + a) * 16 + 12];
         }
       }
-      if (ij.y == f) {                                            // j-side: + w Jj Jj^T, v += w r Jj
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-          for (int b = 0; b < 6; ++b) acc[a * 6 + b] += pb[(6 + a) * 16 + 6 + b];
-          acc[36 + a] += pb[(6 + a) * 16 + 12];
-        }
-      }
-      if (ij.x == f && ij.y == f) {                               // self edge: both cross terms land here
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < 6; ++b) acc[a * 6 + b] += -pb[a * 16 + 6 + b] - pb[b * 16 + 6 + a];
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 42; ++a) {
-      const float s = wave_sum(acc[a]);
-      if (lane == 0) dpart[wave][a] = s;
-    }
-    // off-diagonal blocks (two binary searches in the LDS copy of the sorted pair list)
-    for (int ent = tid; ent < (N - 1) * 36; ent += 256) {
-      int q = ent / 36; const int r = ent - q * 36;
-      if (q >= p) q += 1;
-      const int a = r / 6, b = r - a * 6;
-      const int g1 = find_pair(pl, ng, f, t0 + q);     // i = p, j = q: block (ix,jx) gets -w Ji Jj^T   (:342-345)
-      const int g2 = find_pair(pl, ng, t0 + q, f);     // i = q, j = p: block (jx,ix) gets -w Jj Ji^T
-      float s = 0.f;
-      if (g1 >= 0) s += -pairbuf[(int64_t)g1 * kPairStride + a * 16 + 6 + b];
-      if (g2 >= 0) s += -pairbuf[(int64_t)g2 * kPairStride + b * 16 + 6 + a];
-      rowS[a][6 * q + b] = s;
+      dsl[0][en] = acc;
+      for (int k = 1; k < kDiagSlices; ++k) dsl[k][en] = 0.f;
     }
   }
-  __syncthreads();
-  if (tid < 42) {
-    const float s = ((dpart[0][tid] + dpart[1][tid]) + dpart[2][tid]) + dpart[3][tid];
-    if (tid < 36) rowS[tid / 6][6 * p + tid % 6] = s; else rowy[tid - 36] = s;
+  // off-diagonal blocks: entry (q, a, b) of block row p gets  -w Ji Jj^T  of the pair (p, q) and  -w Jj Ji^T  of the pair (q, p)   (:342-345)
+  for (int ent = tid; ent < (N - 1) * 36; ent += 256) {
+    int q = ent / 36; const int r = ent - q * 36;
+    if (q >= p) q += 1;
+    const int a = r / 6, b = r - a * 6;
+    const int g1 = tabA[q], g2 = tabB[q];
+    float sv = 0.f;
+    if (g1 >= 0) sv += -pairbuf[(int64_t)g1 * kPairStride + a * 16 + 6 + b];
+    if (g2 >= 0) sv += -pairbuf[(int64_t)g2 * kPairStride + b * 16 + 6 + a];
+    rowS[a][6 * q + b] = sv;
   }
   __syncthreads();
+  // ---- phase 2
   float* dst = Bbuf + (int64_t)p * 6 * (kMaxDim + 1);
+  if (tid < 42) {
+    float sv = dsl[0][tid];
+#pragma unroll
+    for (int k = 1; k < kDiagSlices; ++k) sv += dsl[k][tid];
+    if (tid < 36) rowS[tid / 6][6 * p + tid % 6] = sv; else dst[(tid - 36) * (kMaxDim + 1) + kMaxDim] = sv;
+  }
+  __syncthreads();
   for (int a = tid; a < 6 * n6; a += 256) { const int r = a / n6, c = a - r * n6; dst[r * (kMaxDim + 1) + c] = rowS[r][c]; }
-  if (tid < 6) dst[tid * (kMaxDim + 1) + kMaxDim] = rowy[tid];
 }
 
+#ifdef BA_TRACE
+// instrumentation build (tools/ba_trace.sh): start / end of every workgroup of the last ba_patch_kernel launch (100 MHz wall clock)
+__device__ unsigned long long ba_trace_buf[1024][2];
+#endif
 __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
                                                        const int32_t* __restrict__ perm_k,
                                                        const int32_t* __restrict__ patch_off,
@@ -246,65 +287,68 @@ __global__ __launch_bounds__(256) void ba_patch_kernel(const int64_t* __restrict
                                                        int patch_blocks, const int32_t* __restrict__ pair_ij,
                                                        const int32_t* __restrict__ n_pairs, const float* __restrict__ pairbuf,
                                                        float* __restrict__ Bbuf) {
+#ifdef BA_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 1024) ba_trace_buf[blockIdx.x][0] = wall_clock64();
+#endif
   if ((int)blockIdx.x < patch_blocks)
     ba_patch_body(ii, jj, perm_k, patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, ldE, spart, blockIdx.x);
   else
     ba_bpart_body(pair_ij, n_pairs, pairbuf, t0, N, (int)blockIdx.x - patch_blocks, Bbuf);
+#ifdef BA_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { ba_trace_buf[blockIdx.x][1] = wall_clock64(); if (blockIdx.x == 0) ba_trace_buf[1023][0] = patch_blocks; }
+#endif
 }
+#ifdef BA_TRACE
+}  // namespace
+extern "C" int dpvo_debug_ba_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_trace_buf), sizeof(ba_trace_buf)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // 3. assemble kernel: block (p, ra) = row 6p + ra of S and y[6p + ra]: B (from Bbuf) minus the Schur partials, damping
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_assemble_kernel(const float* __restrict__ Bbuf, const float* __restrict__ spart,
-                                                          int n_spart, int N, float* __restrict__ Sg, float* __restrict__ yg) {
+__global__ __launch_bounds__(1024) void ba_assemble_kernel(const float* __restrict__ Bbuf, const float* __restrict__ spart,
+                                                           int n_spart, int N, float* __restrict__ Sg, float* __restrict__ yg) {
   const int n6 = 6 * N;
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
   const float* brow = Bbuf + ((int64_t)p * 6 + blockIdx.y) * (kMaxDim + 1);
   // Schur complement (ba_cuda.cu:557-558) + damping (:560).  blockIdx.y = row ra of the pose's block row: its n6 entries of
-  // S and its entry of y, 4 lanes per entry; four partial matrices per trip so that their loads overlap (the adds keep
-  // the order b, b+4, ...).  (Six row-workgroups per pose: the 69 partial matrices are a chain of dependent global round
-  // trips worth splitting six ways.)
+  // S and its entry of y, SIXTEEN lanes per entry: lane `sub` adds the partial matrices sub, sub + 16, ... (eight loads in flight
+  // per trip: the ~70 partials of an entry are one round trip instead of the five of the 4-lane version), then a fixed-order
+  // butterfly over the 16 lanes.
   const int ra = blockIdx.y;
   const int nrow = n6 + 1;
-  constexpr int kIt = (kMaxDim + 1 + 63) / 64;          // 2
-  const int sub = tid & 3;
-  float sc[kIt];
-  int gent[kIt];
+  const int sub = tid & 15;
+  for (int e0 = 0; e0 < nrow; e0 += 64) {
+    const int e4 = e0 + (tid >> 4);
+    const int gent = (e4 < n6) ? (6 * p + ra) * n6 + e4 : n6 * n6 + 6 * p + ra;
+    float sc = 0.f;
+    if (e4 < nrow)
+      for (int b0 = sub; b0 < n_spart; b0 += 128) {
+        float v[8];
 #pragma unroll
-  for (int it = 0; it < kIt; ++it) {
-    const int e4 = it * 64 + (tid >> 2);
-    sc[it] = 0.f;
-    gent[it] = (e4 < n6) ? (6 * p + ra) * n6 + e4 : n6 * n6 + 6 * p + ra;
-    if (e4 >= nrow) gent[it] = -1;
-  }
-  for (int b0 = sub; b0 < n_spart; b0 += 16) {
-    float v[4][kIt];
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + 16 * u;
+          v[u] = b < n_spart ? spart[(int64_t)b * kSEntries + gent] : 0.f;
+        }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int b = b0 + 4 * u;
-      const float* sp = spart + (int64_t)(b < n_spart ? b : 0) * kSEntries;
-#pragma unroll
-      for (int it = 0; it < kIt; ++it) v[u][it] = (b < n_spart && gent[it] >= 0) ? sp[gent[it]] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int it = 0; it < kIt; ++it) sc[it] += v[u][it];
-  }
-#pragma unroll
-  for (int it = 0; it < kIt; ++it) {
-    float v = sc[it];
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    const int e4 = it * 64 + (tid >> 2);
+        for (int u = 0; u < 8; ++u) sc += v[u];
+      }
+    sc += __shfl_xor(sc, 1);
+    sc += __shfl_xor(sc, 2);
+    sc += __shfl_xor(sc, 4);
+    sc += __shfl_xor(sc, 8);
     if (e4 < nrow && sub == 0) {
       if (e4 < n6) {
-        float sv = brow[e4] - v;
+        float sv = brow[e4] - sc;
         if (6 * p + ra == e4) sv += 1e-4f * sv + 1.0f;                // S += I * (1e-4 * S + 1.0)
-        Sg[gent[it]] = sv;
+        Sg[gent] = sv;
       } else {
-        yg[6 * p + ra] = brow[kMaxDim] - v;
+        yg[6 * p + ra] = brow[kMaxDim] - sc;
       }
     }
   }
@@ -708,7 +752,7 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
                        plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, np_h, spart, (int)patch_blocks,
                        plan + PL.pair_ij, n_pairs, pairbuf, Bbuf);
     if (N > 0) {
-      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(256), 0, st, Bbuf, spart, (int)patch_blocks, N, Sg, yg);
+      hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(1024), 0, st, Bbuf, spart, (int)patch_blocks, N, Sg, yg);
       if (6 * N <= 60)
         hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, st, Sg, yg, N, dX, info ? info + itr : nullptr);
       else if (6 * N <= 64)

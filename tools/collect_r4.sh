@@ -18,6 +18,8 @@ python tools/ba_bench.py 2>&1 | grep -v amdgpu > $out/ba_bench.txt
 python tools/host_time.py tottime 2>&1 | grep -v amdgpu | head -30 > $out/host_profile.txt
 python -m pytest tests/test_gpu_ref.py tests/test_gpu_ref_pipeline.py tests/test_gpu_update.py -q -s -m gpu 2>&1 | grep -v "amdgpu\|Warning\|autocast" > $out/ref_parity.txt
 python tools/enc_bench.py 2>&1 | grep -v amdgpu > $out/enc_bench.txt
+[ -f dpvo_amd/libdpvo_hip_kft.so ] && DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_kft.so python tools/kf_trace.py 2>&1 | grep -v amdgpu > $out/kf_phases.txt
+[ -f dpvo_amd/libdpvo_hip_fst.so ] && DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_fst.so python tools/fs_trace.py 2>&1 | grep -v amdgpu > $out/frame_state_workgroups.txt
 [ -x tools/probes/clock_probe.bin ] && tools/probes/clock_probe.bin > $out/clock_probe.txt 2>&1
 ls -la $out
 # (gpurun merges at most 64 MiB back: the raw counter / trace csvs stay on the box)
