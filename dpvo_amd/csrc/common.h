@@ -66,3 +66,11 @@ __device__ __forceinline__ void pool4_nhwc_body(const _Float16* __restrict__ in,
   }
 }
 
+// ---- internal entry points (between the translation units of this library; not part of include/dpvo_hip.h) -----------------------
+extern "C" int dpvo_plan_window_counters(int64_t E, void* ws, size_t ws_bytes, int32_t** ptr, int64_t* count);
+extern "C" int dpvo_plan_build_window_job(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
+                                          size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
+                                          int64_t n_patches_win, int64_t qi, int64_t qj, int counters_cleared, const float* r_poses,
+                                          const float* r_patches, const float* r_intr, float* r_coords, int r_P, void* stream);
+extern "C" int dpvo_frame_state_part_clear(dpvo_frame_state_t* p, int part, int32_t* clear_ptr, int64_t clear_count, void* stream);
+

@@ -398,6 +398,7 @@ struct FrameStateArgs {
   _Float16* fmap2_slot;
   int64_t *ii, *jj, *kk; float* net; const int64_t* ix; int64_t E0; int ap_n, ap_r, D;
   int n_med, n_pool, n_app;
+  int32_t* clear_ptr; int clear_n;      // an int region some other launch wants cleared (the graph plan's counters): blocks behind the rest
 };
 #ifdef FS_TRACE
 // instrumentation build (tools/fs_trace.sh): start / end of every workgroup of the last launch (100 MHz wall clock)
@@ -413,7 +414,10 @@ __device__ __forceinline__ void frame_state_roles(const FrameStateArgs& S) {
   b -= S.n_med;
   if (b < S.n_pool) { pool4_nhwc_body(S.fp.fmap, S.fmap2_slot, S.fp.h, S.fp.w, S.fp.CF, b, S.n_pool); return; }
   b -= S.n_pool;
-  append_edges_body(S.ii, S.jj, S.kk, S.net, S.ix, S.E0, S.ap_n, S.fp.M, S.ap_r, S.D, b, S.n_app);
+  if (b < S.n_app) { append_edges_body(S.ii, S.jj, S.kk, S.net, S.ix, S.E0, S.ap_n, S.fp.M, S.ap_r, S.D, b, S.n_app); return; }
+  b -= S.n_app;
+  const int i = b * 256 + threadIdx.x;
+  if (i < S.clear_n) S.clear_ptr[i] = 0;
 }
 __global__ __launch_bounds__(256) void frame_state_kernel(FrameStateArgs S) {
 #ifdef FS_TRACE
@@ -559,7 +563,12 @@ extern "C" int dpvo_frame_patches(const void* fmap, const void* imap, const void
 // level 1.  dpvo_frame_update issues part 1, the plan and the reprojection BEFORE it makes its stream wait for the side stream's
 // encoders, and part 2 behind that wait: ~45 us of small launches that no longer sit between "encoders done" and the correlation.
 extern "C" int dpvo_frame_state_part(dpvo_frame_state_t* p, int part, void* stream) {
+  return dpvo_frame_state_part_clear(p, part, nullptr, 0, stream);
+}
+// (internal, csrc/common.h)  the same; part 1 also clears clear_count ints at clear_ptr with a few extra workgroups
+extern "C" int dpvo_frame_state_part_clear(dpvo_frame_state_t* p, int part, int32_t* clear_ptr, int64_t clear_count, void* stream) {
   if (!p || part < 0 || part > 2) return DPVO_E_INVALID;
+  if (clear_ptr && (part != 1 || clear_count <= 0 || clear_count > (1 << 24))) return DPVO_E_INVALID;
   if (part == 0) return dpvo_frame_state(p, stream);
   dpvo_frame_state_t q = *p;
   if (part == 1) { q.gmap_slot = q.imap_slot = q.fmap2_slot = nullptr; }
@@ -581,6 +590,8 @@ extern "C" int dpvo_frame_state_part(dpvo_frame_state_t* p, int part, void* stre
   S.fmap2_slot = (_Float16*)q.fmap2_slot;
   S.ii = q.ii; S.jj = q.jj; S.kk = q.kk; S.net = q.net; S.ix = q.ix; S.E0 = q.E0; S.ap_n = q.ap_n; S.ap_r = q.ap_r; S.D = q.D;
   S.n_med = 0; S.n_pool = 0; S.n_app = 0;
+  S.clear_ptr = clear_ptr; S.clear_n = clear_ptr ? (int)clear_count : 0;
+  const int n_clr = (S.clear_n + 255) / 256;
   if (part == 1) {
     const int n = q.ap_n, r = q.ap_r, jlo = n - r > 0 ? n - r : 0;
     const int64_t total = (int64_t)M * ((n - 1 > 0 ? n - 1 : 0) - jlo) + (int64_t)M * (n - jlo);
@@ -590,7 +601,7 @@ extern "C" int dpvo_frame_state_part(dpvo_frame_state_t* p, int part, void* stre
   } else {
     S.n_pool = (int)(((int64_t)(q.h / 4) * (q.w / 4) * (q.CF / 8) + 255) / 256);
   }
-  hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(M + 1 + S.n_med + S.n_pool + S.n_app)), dim3(256), 0, (hipStream_t)stream, S);
+  hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(M + 1 + S.n_med + S.n_pool + S.n_app + n_clr)), dim3(256), 0, (hipStream_t)stream, S);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
@@ -619,6 +630,7 @@ extern "C" int dpvo_frame_state(dpvo_frame_state_t* p, void* stream) {
     S.n_med = (3 * M * 9 + kMedPerBlock - 1) / kMedPerBlock;
     S.n_pool = (int)(((int64_t)(p->h / 4) * (p->w / 4) * (p->CF / 8) + 255) / 256);
     S.n_app = total > 0 ? (int)grid_for(total * (p->D / 4), 2048) : 0;
+    S.clear_ptr = nullptr; S.clear_n = 0;
     hipLaunchKernelGGL(frame_state_kernel, dim3((unsigned)(M + 1 + S.n_med + S.n_pool + S.n_app)), dim3(256), 0, (hipStream_t)stream,
                        S);
     DPVO_LAUNCH_CHECK();

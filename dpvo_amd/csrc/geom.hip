@@ -118,43 +118,7 @@ __global__ void reproject_kernel(const float* __restrict__ poses, const float* _
                                  const float* __restrict__ intr, const int64_t* __restrict__ ii,
                                  const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
                                  float* __restrict__ coords, int64_t E, int P, int clamp_z) {
-  const int PP = P * P;
-  const int64_t total = E * PP;
-  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < total; n += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = n / PP;
-    const int a = (int)(n - e * PP);
-    const int64_t i = ii[e], j = jj[e], k = kk[e];
-    const float* pk = patches + k * 3 * PP;
-    float x1, y1;
-    if (clamp_z) {
-      const Pose Gij = se3_mul(load_pose(poses + 7 * j), se3_inv(load_pose(poses + 7 * i)));
-      const float* Ki = intr + 4 * i; const float* Kj = intr + 4 * j;
-      const float X0[4] = {(pk[a] - Ki[2]) / Ki[0], (pk[PP + a] - Ki[3]) / Ki[1], 1.0f, pk[2 * PP + a]};
-      float X1[4];
-      se3_act4(Gij, X0, X1);
-      const float d = 1.0f / fmaxf(X1[2], 0.1f);
-      x1 = Kj[0] * (d * X1[0]) + Kj[2];
-      y1 = Kj[1] * (d * X1[1]) + Kj[3];
-    } else {
-      const float* pi = poses + 7 * i; const float* pj = poses + 7 * j;
-      const Quat qi = {pi[3], pi[4], pi[5], pi[6]}, qj = {pj[3], pj[4], pj[5], pj[6]};
-      Quat qij;
-      qij.x = -qj.w * qi.x + qj.x * qi.w - qj.y * qi.z + qj.z * qi.y;
-      qij.y = -qj.w * qi.y + qj.y * qi.w - qj.z * qi.x + qj.x * qi.z;
-      qij.z = -qj.w * qi.z + qj.z * qi.w - qj.x * qi.y + qj.y * qi.x;
-      qij.w = qj.w * qi.w + qj.x * qi.x + qj.y * qi.y + qj.z * qi.z;
-      const Vec3 r = qrot(qij, {pi[0], pi[1], pi[2]});
-      const float tij[3] = {pj[0] - r.x, pj[1] - r.y, pj[2] - r.z};
-      const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-      const float X0[4] = {(pk[a] - cx) / fx, (pk[PP + a] - cy) / fy, 1.0f, pk[2 * PP + a]};
-      const Vec3 R = qrot(qij, {X0[0], X0[1], X0[2]});
-      const float X = R.x + X0[3] * tij[0], Y = R.y + X0[3] * tij[1], Z = R.z + X0[3] * tij[2];
-      x1 = fx * (X / Z) + cx;
-      y1 = fy * (Y / Z) + cy;
-    }
-    coords[(e * 2 + 0) * PP + a] = x1;
-    coords[(e * 2 + 1) * PP + a] = y1;
-  }
+  reproject_body(poses, patches, intr, ii, jj, kk, coords, E, P, clamp_z, blockIdx.x, gridDim.x);
 }
 
 __global__ void flow_mag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,

@@ -9,6 +9,7 @@
 // Integer results are bit-exact with the oracle (tests/test_graph_*).
 #include <cstring>
 #include "common.h"
+#include "se3_dev.h"      // (reproject_body: the reprojection can ride in the histogram launch; this unit is built without packed-FP32 ops)
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -142,14 +143,20 @@ __device__ __forceinline__ void win_bins(const WinArgs& W, int64_t e, int& ba, i
   bb = ic * W.nfw + jc;
 }
 
-__global__ __launch_bounds__(1024) void win_zero_kernel(int32_t* __restrict__ p, int n, int32_t* __restrict__ flow, int qi, int qj) {
+__global__ __launch_bounds__(1024) void win_zero_kernel(int32_t* __restrict__ p, int n) {
   const int i = blockIdx.x * 1024 + threadIdx.x;
   if (i < n) p[i] = 0;
-  if (i < 4) flow[i] = i == 0 ? qi : (i == 1 ? qj : 0);
 }
 
-__global__ __launch_bounds__(1024) void win_hist_kernel(WinArgs W) {
+// an independent job that may share the histogram launch (its blocks follow the tiles'): the reprojection of the same edges
+struct ReprojJob { const float *poses, *patches, *intr; float* coords; int P, nblk; };
+__global__ __launch_bounds__(1024) void win_hist_kernel(WinArgs W, int tiles, ReprojJob R) {
+  if ((int)blockIdx.x >= tiles) {
+    reproject_body(R.poses, R.patches, R.intr, W.ii, W.jj, W.kk, R.coords, W.E, R.P, 1, (int)blockIdx.x - tiles, R.nblk);
+    return;
+  }
   __shared__ int32_t h[kWinBins];
+  if (blockIdx.x == 0 && threadIdx.x < 4) W.flow[threadIdx.x] = threadIdx.x == 0 ? W.qi : (threadIdx.x == 1 ? W.qj : 0);   // flow-list header
   const int nb_b = W.nfw * W.nfw;
   for (int b = threadIdx.x; b < kWinBins; b += 1024) h[b] = 0;
   __syncthreads();
@@ -459,6 +466,28 @@ extern "C" int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, cons
 extern "C" int dpvo_plan_build_window_flow(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
                                            void* ws, size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
                                            int64_t n_patches_win, int64_t qi, int64_t qj, void* stream) {
+  return dpvo_plan_build_window_job(ii, jj, kk, E, plan, ws, ws_bytes, frame_lo, n_frames_win, patch_lo, n_patches_win, qi, qj, 0, nullptr,
+                                    nullptr, nullptr, nullptr, 0, stream);
+}
+
+// (internal, csrc/common.h)  where the window build keeps the counters it needs cleared before its histogram launch
+extern "C" int dpvo_plan_window_counters(int64_t E, void* ws, size_t ws_bytes, int32_t** ptr, int64_t* count) {
+  WsLayout L;
+  if (E <= 0 || !ws || !ptr || !count || ws_layout(E, &L) != 0 || ws_bytes < L.total) return DPVO_E_INVALID;
+  const int tiles = (int)cdiv64(E, kWinTile);
+  int32_t* T = (int32_t*)((char*)ws + L.win);
+  *ptr = T + (size_t)tiles * kWinBins + kWinBins + 2;          // = W.tot (flag follows)
+  *count = kWinBins + 1;
+  return DPVO_OK;
+}
+
+// (internal)  the window build with two options of the frame call: counters_cleared != 0 -- the caller has cleared the region
+// dpvo_plan_window_counters names (dpvo_frame_update lets the frame-state launch do it: one launch less); r_poses != NULL -- the
+// reprojection of the same edges (dpvo_reproject(..., clamp_z = 1) into r_coords) rides in the histogram launch as extra blocks
+extern "C" int dpvo_plan_build_window_job(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan,
+                                          void* ws, size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
+                                          int64_t n_patches_win, int64_t qi, int64_t qj, int counters_cleared, const float* r_poses,
+                                          const float* r_patches, const float* r_intr, float* r_coords, int r_P, void* stream) {
   if (E < 0 || !plan || frame_lo < 0 || patch_lo < 0 || n_frames_win <= 0 || n_patches_win <= 0) return DPVO_E_INVALID;
   if (n_frames_win * n_frames_win > kWinB || n_patches_win > kWinA || E >= (1 << 24)) return DPVO_E_UNSUPPORTED;
   const int shift = bits_for(frame_lo + n_frames_win);
@@ -490,12 +519,18 @@ extern "C" int dpvo_plan_build_window_flow(const int64_t* ii, const int64_t* jj,
   W.flow = plan + P.flow;
   const bool with_flow = qi >= 0 && qj >= 0 && qi != qj && qi < (1ll << 30) && qj < (1ll << 30);
   W.qi = with_flow ? (int)qi : -1; W.qj = with_flow ? (int)qj : -1;
-  hipLaunchKernelGGL(win_zero_kernel, dim3((kWinBins + 1 + 1023) / 1024), dim3(1024), 0, st, W.tot, kWinBins + 1, W.flow, W.qi, W.qj);
+  if (!counters_cleared) hipLaunchKernelGGL(win_zero_kernel, dim3((kWinBins + 1 + 1023) / 1024), dim3(1024), 0, st, W.tot, kWinBins + 1);
   W.tmp_key = (uint32_t*)(w + L.keys_a); W.tmp_e = (int32_t*)(w + L.vals_in);
   W.perm_k = plan + P.perm_k; W.perm_p = plan + P.perm_p;
   W.ku = plan + P.ku; W.kx = plan + P.kx; W.patch_off = plan + P.patch_off; W.ix = plan + P.ix; W.jx = plan + P.jx;
   W.pu = plan + P.pu; W.pair_off = plan + P.pair_off; W.pair_ij = plan + P.pair_ij; W.counts = plan + P.counts;
-  hipLaunchKernelGGL(win_hist_kernel, dim3(tiles), dim3(1024), 0, st, W);
+  ReprojJob R = {r_poses, r_patches, r_intr, r_coords, r_P, 0};
+  if (r_poses) {
+    if (!r_patches || !r_intr || !r_coords || r_P <= 0) return DPVO_E_INVALID;
+    const int64_t nb = cdiv64(E * r_P * r_P, 1024);
+    R.nblk = (int)(nb < 1 ? 1 : (nb > 16384 ? 16384 : nb));
+  }
+  hipLaunchKernelGGL(win_hist_kernel, dim3(tiles + R.nblk), dim3(1024), 0, st, W, tiles, R);
   const int chunks_a = (int)cdiv64(W.npw, 1024), chunks_b = (int)cdiv64((int64_t)W.nfw * W.nfw, 1024);
   hipLaunchKernelGGL(win_scan_kernel, dim3(chunks_a + chunks_b), dim3(1024), 0, st, W, tiles, chunks_a);
   hipLaunchKernelGGL(win_scatter_kernel, dim3(tiles), dim3(1024), 0, st, W);

@@ -337,6 +337,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (a->net_rows && (a->n_kept < 0 || a->n_kept > E)) return DPVO_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  int32_t* plan_clear = nullptr; int64_t plan_clear_n = 0;
 #define STEP(...) do { rc = (__VA_ARGS__); if (rc) return rc; } while (0)
   // ---- the new frame's state (patch gathers, motion model, depth median, pyramid level 1, its edges): dpvo.py:400-459
   if (a->fs) {
@@ -362,8 +363,12 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
     }
     // ev_enc (the side stream's "encoders done"): only the feature gathers and the pyramid's level 1 need the encoders' outputs,
     // so the state stores, the new edges, the plan and the reprojection go first and the stream waits just in front of part 2
-    if (a->ev_enc) STEP(dpvo_frame_state_part(a->fs, 1, stream));
-    else {
+    if (a->ev_enc) {
+      // (part 1 also clears the counters of the plan's window build: one launch less in front of the correlation)
+      if (!(a->plan_stream && a->ev_plan_fork && a->ev_plan_done) &&
+          dpvo_plan_window_counters(E, a->ws_plan, a->ws_plan_bytes, &plan_clear, &plan_clear_n) != DPVO_OK) plan_clear = nullptr;
+      STEP(dpvo_frame_state_part_clear(a->fs, 1, plan_clear, plan_clear ? plan_clear_n : 0, stream));
+    } else {
       STEP(dpvo_frame_state(a->fs, stream));
       if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;
     }
@@ -382,9 +387,15 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   const bool plan_aside = a->plan_stream && a->ev_plan_fork && a->ev_plan_done;
   if ((a->plan_stream || a->ev_plan_fork || a->ev_plan_done) && !plan_aside) return DPVO_E_INVALID;
   // (with the flow test's frame pair (k - 1, k + 1), k = n - KEYFRAME_INDEX, extracted on the way: dpvo_plan_layout_t.flow)
-  auto build_plan = [&](void* pst) -> int {
-    int r = dpvo_plan_build_window_flow(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M,
-                                        n - K.keyframe_index - 1, n - K.keyframe_index + 1, pst);
+  // On the compute stream the reprojection (independent of the plan, same edges) rides in the plan's histogram launch and the
+  // counters were cleared by part 1 of the frame state: the front of the frame is 6 launches instead of 8 -- a launch costs ~5 us
+  // here whatever it does (win_zero_kernel: 6 145 stores, 4.9 us)
+  bool reprojected = false;
+  auto build_plan = [&](void* pst, bool with_reproject) -> int {
+    int r = dpvo_plan_build_window_job(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, flo, n - flo, flo * M, (n - flo) * (int64_t)M,
+                                       n - K.keyframe_index - 1, n - K.keyframe_index + 1, plan_clear != nullptr && pst == stream,
+                                       with_reproject ? a->poses : nullptr, a->patches, a->intrinsics, a->coords, a->P, pst);
+    if (r == DPVO_OK) reprojected = with_reproject;
     if (r == DPVO_E_UNSUPPORTED)
       r = dpvo_plan_build_ranged(K.ii, K.jj, K.kk, E, a->plan, a->ws_plan, a->ws_plan_bytes, a->n_buffer, a->n_buffer * M, pst);
     return r;
@@ -393,10 +404,10 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   // frame is short kernels that the GPU finishes faster than the host enqueues them, so whatever the host issues in front of the
   // correlation launch delays it, on whichever stream it runs
   if (plan_aside) { if (hipEventRecord((hipEvent_t)a->ev_plan_fork, st) != hipSuccess) return DPVO_E_INVALID; }
-  else STEP(build_plan(stream));
+  else STEP(build_plan(stream, true));
   HT(1);     // fork record / plan on the compute stream
   // ---- reproject -> correlation -> update operator (dpvo.py:331-343)
-  STEP(dpvo_reproject(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->coords, E, a->P, 1, stream));
+  if (!reprojected) STEP(dpvo_reproject(a->poses, a->patches, a->intrinsics, K.ii, K.jj, K.kk, a->coords, E, a->P, 1, stream));
   HT(2);     // reproject
   if (a->fs && a->ev_enc) {
     if (hipStreamWaitEvent(st, (hipEvent_t)a->ev_enc, 0) != hipSuccess) return DPVO_E_INVALID;
@@ -419,7 +430,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
     hipStream_t pst = (hipStream_t)a->plan_stream;
     if (hipStreamWaitEvent(pst, (hipEvent_t)a->ev_plan_fork, 0) != hipSuccess) return DPVO_E_INVALID;
     HT(5);   // plan stream waits for the fork
-    STEP(build_plan(a->plan_stream));
+    STEP(build_plan(a->plan_stream, false));
     HT(6);   // plan launches
     if (hipEventRecord((hipEvent_t)a->ev_plan_done, pst) != hipSuccess) return DPVO_E_INVALID;
     HT(7);   // plan-done record
