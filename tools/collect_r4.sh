@@ -20,6 +20,7 @@ python -m pytest tests/test_gpu_ref.py tests/test_gpu_ref_pipeline.py tests/test
 python tools/enc_bench.py 2>&1 | grep -v amdgpu > $out/enc_bench.txt
 [ -f dpvo_amd/libdpvo_hip_kft.so ] && DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_kft.so python tools/kf_trace.py 2>&1 | grep -v amdgpu > $out/kf_phases.txt
 [ -f dpvo_amd/libdpvo_hip_fst.so ] && DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_fst.so python tools/fs_trace.py 2>&1 | grep -v amdgpu > $out/frame_state_workgroups.txt
+[ -f dpvo_amd/libdpvo_hip_bat.so ] && DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_bat.so python tools/ba_trace.py 2>&1 | grep -v amdgpu > $out/ba_patch_workgroups.txt
 [ -x tools/probes/clock_probe.bin ] && tools/probes/clock_probe.bin > $out/clock_probe.txt 2>&1
 ls -la $out
 # (gpurun merges at most 64 MiB back: the raw counter / trace csvs stay on the box)

@@ -5,7 +5,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-key = sys.argv[3] if len(sys.argv) > 3 else 'win_zero_kernel'      # once per frame on the compute stream (frame_state_kernel runs twice since round 4)
+key = sys.argv[3] if len(sys.argv) > 3 else 'win_hist_kernel'      # once per frame on the compute stream (frame_state_kernel runs twice, win_zero_kernel not at all inside the frame call since round 4)
 idx = [i for i, r in enumerate(rows) if key in r['Kernel_Name']]
 a, b = idx[-back - 1], idx[-back]
 t0 = int(rows[a]['Start_Timestamp'])
