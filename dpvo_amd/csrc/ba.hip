@@ -374,13 +374,20 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
-                                                         float* __restrict__ dX, int32_t* __restrict__ info) {
+#ifdef BA_TRACE
+__device__ unsigned long long ba_solve_trace[40];
+#define SVT(i) do { if (threadIdx.x == 0) ba_solve_trace[i] = wall_clock64(); } while (0)
+#else
+#define SVT(i) do {} while (0)
+#endif
+__device__ __forceinline__ void solve60_body(const float* __restrict__ Sg, const float* __restrict__ yg, int N, float* __restrict__ dX,
+                                             int32_t* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) float A[61 * kLd60];
   __shared__ float Lbb[10][28];              // per block: L_bb (lower, packed by rows: 21) and 1 / diag (6)
   __shared__ float zs[64];
   __shared__ int s_bad;
   const int n6 = 6 * N, tid = threadIdx.x;
+  SVT(0);
   // lower triangle of S and y as row n6: thread (ty, tx) of a 16 x 16 grid owns the elements (ty + 16 i, tx + 16 j); all 16
   // loads are issued before the first LDS store (as a nested loop they were 16 dependent global round trips)
   {
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
   }
   if (tid == 0) s_bad = 0;
   __syncthreads();
+  SVT(1);
   for (int B = 0; B < N; ++B) {
     const int o = 6 * B;
     const int r = o + tid;
@@ -458,45 +466,53 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
         if (bad && s_bad == 0) s_bad = bad;
       }
     }
+    if (B < 10) SVT(2 + 3 * B);
     __syncthreads();
+    if (B < 10) SVT(3 + 3 * B);
     // trailing update: rows rr (0..m, row m = y), columns cc <= min(rr, m - 1), relative to o + 6.  Thread (ty, tx) of a
-    // 16 x 16 grid owns the elements (ty + 16 i, tx + 16 j): all its operand rows are fetched first (independent LDS
-    // reads), then the <= 16 dot products, then the read-modify-writes.
+    // 16 x 16 grid owns the elements (ty + 16 i, tx + 16 j): all its operand rows are fetched first (independent 8-byte LDS
+    // reads), then the dot products, then the read-modify-writes.  Only the 16 x 16 blocks that exist at this step and touch the
+    // lower triangle are visited (j <= i, 16 i <= m, 16 j < m: uniform branches) -- visiting all sixteen with predicates made
+    // this phase 0.8-1.1 us of every block step whatever m, 8 of the kernel's 19 us (tools/ba_trace.sh); 42 of the 144 blocks of a
+    // 60 x 60 solve are left.
     const int m = n6 - o - 6;
     if (m > 0) {
       const float* base = A + (o + 6) * kLd60 + o;
       const int ty = tid >> 4, tx = tid & 15;
-      float ar[4][6], ac[4][6];
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      f2v ar[4][3], ac[4][3];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int rr = ty + 16 * i, cc = tx + 16 * i;
-        const float* pr = base + (rr <= m ? rr : m) * kLd60;
-        const float* pc = base + (cc < m ? cc : m - 1) * kLd60;
+        if (16 * i <= m) {
+          const int rr = ty + 16 * i;
+          const f2v* pr = reinterpret_cast<const f2v*>(base + (rr <= m ? rr : m) * kLd60);       // (rows and o are even: 8-byte aligned)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { ar[i][k] = pr[k]; ac[i][k] = pc[k]; }
-      }
-      float cur[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rr = ty + 16 * i, cc = tx + 16 * j;
-          const bool on = rr <= m && cc < m && cc <= rr;
-          cur[i][j] = on ? A[(o + 6 + rr) * kLd60 + o + 6 + cc] : 0.f;
+          for (int k = 0; k < 3; ++k) ar[i][k] = pr[k];
         }
+        if (16 * i < m) {
+          const int cc = tx + 16 * i;
+          const f2v* pc = reinterpret_cast<const f2v*>(base + (cc < m ? cc : m - 1) * kLd60);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) ac[i][k] = pc[k];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rr = ty + 16 * i, cc = tx + 16 * j;
-          if (rr <= m && cc < m && cc <= rr) {
-            const float sum = ar[i][0] * ac[j][0] + ar[i][1] * ac[j][1] + ar[i][2] * ac[j][2] + ar[i][3] * ac[j][3] +
-                              ar[i][4] * ac[j][4] + ar[i][5] * ac[j][5];
-            A[(o + 6 + rr) * kLd60 + o + 6 + cc] = cur[i][j] - sum;
+        for (int j = 0; j <= i; ++j) {
+          if (16 * i <= m && 16 * j < m) {
+            const int rr = ty + 16 * i, cc = tx + 16 * j;
+            if (rr <= m && cc < m && cc <= rr) {
+              float* el = A + (o + 6 + rr) * kLd60 + o + 6 + cc;
+              const float sum = ar[i][0][0] * ac[j][0][0] + ar[i][0][1] * ac[j][0][1] + ar[i][1][0] * ac[j][1][0] + ar[i][1][1] * ac[j][1][1] +
+                                ar[i][2][0] * ac[j][2][0] + ar[i][2][1] * ac[j][2][1];
+              *el = *el - sum;
+            }
           }
         }
     }
     __syncthreads();
+    if (B < 10) SVT(4 + 3 * B);
   }
   // backward substitution L^T x = z (z = row n6), wave 0, lane c owns z[c]
   if (tid < 64) {
@@ -528,8 +544,20 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict
     }
     if (tid < n6) dX[tid] = xv;
     if (tid == 0 && info) *info = s_bad;
+    SVT(32);
   }
 }
+__global__ __launch_bounds__(256) void ba_solve60_kernel(const float* __restrict__ Sg, const float* __restrict__ yg, int N,
+                                                         float* __restrict__ dX, int32_t* __restrict__ info) {
+  solve60_body(Sg, yg, N, dX, info);
+}
+#ifdef BA_TRACE
+}  // namespace
+extern "C" int dpvo_debug_ba_solve_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_solve_trace), sizeof(ba_solve_trace)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // 4. solve kernel: one workgroup, thread r owns row r.  n6 <= 64: a single wave, no barriers at all
@@ -751,6 +779,9 @@ extern "C" int dpvo_ba(float* poses, float* patches, const float* intrinsics, co
     hipLaunchKernelGGL(ba_patch_kernel, dim3(patch_blocks + (unsigned)N), dim3(256), 0, st, ii, jj, plan + PL.perm_k,
                        plan + PL.patch_off, n_patches, edgebuf, lmbda, t0, N, Qbuf, ubuf, Ecol, np_h, spart, (int)patch_blocks,
                        plan + PL.pair_ij, n_pairs, pairbuf, Bbuf);
+    // (assemble + solve as ONE launch -- the last assemble workgroup to finish runs the solve -- was measured: 93 -> 128 us per call.
+    //  Workgroups of one launch that hand data to each other need agent-scope release / acquire, i.e. write-backs and invalidations of
+    //  the per-XCD L2s; a launch boundary does the same once and costs ~5 us.)
     if (N > 0) {
       hipLaunchKernelGGL(ba_assemble_kernel, dim3(N, 6), dim3(1024), 0, st, Bbuf, spart, (int)patch_blocks, N, Sg, yg);
       if (6 * N <= 60)

@@ -28,3 +28,11 @@ print(f"ba_patch_kernel: {len(used)} workgroups ({pb} per-patch + {len(used) - p
 for name, sel in (("per-patch", used[used < pb]), ("B-row", used[used >= pb])):
     v = a[sel] - t0
     print(f"   {name:10s} n = {len(sel):4d}  start {v[:, 0].min():5.1f} .. {v[:, 0].max():5.1f}   end {v[:, 1].min():5.1f} .. {v[:, 1].max():5.1f}   longest {np.max(v[:, 1] - v[:, 0]):5.1f} us")
+
+sb = (ctypes.c_ulonglong * 40)()
+assert L.lib().dpvo_debug_ba_solve_trace(sb) == 0
+t = np.array(list(sb), dtype=np.int64) / 100.0
+t -= t[0]
+print(f"ba_solve60_kernel (thread 0): load + first barrier {t[1]:.1f} us; block steps (panel | barrier | trailing + barrier): " +
+      ", ".join(f"{t[2 + 3 * B] - (t[1] if B == 0 else t[4 + 3 * (B - 1)]):.2f}|{t[3 + 3 * B] - t[2 + 3 * B]:.2f}|{t[4 + 3 * B] - t[3 + 3 * B]:.2f}" for B in range(10)) +
+      f"; backward substitution {t[32] - t[31]:.1f} us; total {t[32]:.1f} us")
