@@ -320,13 +320,18 @@ class DPVO:
         (ii, jj, kk) = indicies if indicies is not None else (self.pg.ii, self.pg.jj, self.pg.kk)
         return pops.transform_coords(self.poses, self.patches, self.intrinsics, ii, jj, kk)
 
-    def append_factors(self, ii, jj):
-        """generic append (loop-closure edges): ii = patch ids, jj = target frames (dpvo.py:215-221)"""
-        self.pg.edges.append(self.ix[ii], jj, ii)
+    def append_factors(self, ii, jj, lr_count=None):
+        """generic append (loop-closure edges): ii = patch ids, jj = target frames (dpvo.py:215-221).  lr_count: how many of them are
+        long-range by update()'s test (PatchGraph.edges_loop knows: loop_lr_count); None = counted on the device (one read-back)"""
+        src = self.ix[ii]
+        self.pg.edges.append(src, jj, ii)
         self._plan = None
         # edges from outside the tracker's own bookkeeping (loop closure): no window / bound assumptions while they are active; the
-        # keyframe step reports when the last of them has left the active list (_lr_active back to 0)
-        self._lr_active += int(ii.numel())
+        # keyframe step reports when the last of them has left the active list (_lr_active back to 0).  _lr_active is EXACTLY the
+        # number of active edges with ii < n - REMOVAL_WINDOW - 1: update() decides on it instead of asking the device (dpvo.py:348)
+        if lr_count is None:
+            lr_count = int((src < self.n - self.cfg.REMOVAL_WINDOW - 1).sum().item()) if ii.numel() else 0
+        self._lr_active += int(lr_count)
 
     def append_frame_factors(self):
         """append_factors(*edges_forw) + append_factors(*edges_back) (dpvo.py:458-459) as one kernel"""
@@ -780,7 +785,7 @@ class DPVO:
         full_kk = torch.cat((self.pg.kk_inac, self.pg.kk))
 
         self.pg.normalize()
-        t0 = self.pg.ii.min().item()
+        t0 = int(self.pg.edges.host()["ii"].min()) if self.pg.edges.mirror else self.pg.ii.min().item()      # (the host mirror: no device wait)
         fastba.BA(self.poses, self.patches, self.intrinsics,
                   full_target, full_weight, 1e-4, full_ii, full_jj, full_kk, t0, self.n, M=self.M, iterations=2,
                   eff_impl=True)
@@ -860,8 +865,12 @@ class DPVO:
         with Timer("BA", enabled=self.enable_timing):
             try:
                 # run global bundle adjustment if there exist long-range edges
-                if self.cfg.LOOP_CLOSURE and (self.pg.ii < self.n - self.cfg.REMOVAL_WINDOW - 1).any() \
-                        and not self.ran_global_ba[self.n]:
+                # (long-range edges active?  The reference asks the device, `(ii < n - REMOVAL_WINDOW - 1).any()`: a host wait for the
+                #  update operator in front of the global BA's own host work.  The tracker knows: _lr_active is that count)
+                long_range = self._lr_active > 0
+                if _CHECK_MIRROR and self.cfg.LOOP_CLOSURE:
+                    assert long_range == bool((self.pg.ii < self.n - self.cfg.REMOVAL_WINDOW - 1).any()), "long-range edge count diverged"
+                if self.cfg.LOOP_CLOSURE and long_range and not self.ran_global_ba[self.n]:
                     self.__run_global_BA()
                 else:
                     t0 = self.n - self.cfg.OPTIMIZATION_WINDOW if self.is_initialized else 1
@@ -1193,7 +1202,7 @@ class DPVO:
                 self._loop_try = None
                 if lii.numel() > 0:
                     self.last_global_ba = self.n
-                    self.append_factors(lii, ljj)
+                    self.append_factors(lii, ljj, lr_count=getattr(self.pg, "loop_lr_count", None))
 
         # Add forward and backward factors
         if not appended:

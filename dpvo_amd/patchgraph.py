@@ -387,6 +387,7 @@ class PatchGraph:
         lc_range = self.cfg.MAX_EDGE_AGE
         l = n - self.cfg.REMOVAL_WINDOW  # l is the upper bound for "old" patches
         dev = self.poses_.device
+        self.loop_lr_count = 0
         if l <= 0:
             return torch.empty(2, 0, dtype=torch.long, device=dev)
 
@@ -410,6 +411,10 @@ class PatchGraph:
         es = reduce_edges(flow_mag[mask].cpu().numpy(), ii[::self.M][mask].cpu().numpy(),
                           jj[::self.M][mask].cpu().numpy(), max_num_edges=1000, nms=1)
 
+        # how many of the edges this call returns are long-range ones by update()'s test `ii < n - REMOVAL_WINDOW - 1` (dpvo.py:348)
+        # at the frame count they were evaluated for: known here on the host, the tracker need not ask the device
+        es_np = np.asarray(es).reshape(-1, 2)
+        self.loop_lr_count = int(np.count_nonzero(es_np[:, 0] < n - self.cfg.REMOVAL_WINDOW - 1)) * self.M
         edges = torch.as_tensor(es, device=dev).reshape(-1, 2)
         ii = edges[:, 0][:, None].expand(-1, self.M)
         jj = edges[:, 1][:, None].expand(-1, self.M)
