@@ -169,14 +169,24 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
 
 // Block row p of S and y[p] (see the file header).  grid (N, split), 1024 threads = 16 waves: the 16 * split waves of a row
 // each own the column blocks whose pose q has q % (16 * split) == their number; wave 0 of the first workgroup also owns y.
-// split = gridDim.y is chosen by the launcher: 4 for N <= 128, 2 for N <= 400, else 1 -- more chains per row shorten a short
-// call (N = 49: 0.44 -> 0.21 ms) but every wave scans every block of every source frame, which is what a long call pays for
-// (N = 799: 1.9 ms with 4 or 16 waves per row, 2.4 with 64).
+// split = gridDim.y is chosen by the launcher so that every workgroup of the launch is resident at once (a 1 024-thread workgroup
+// of this kernel takes a CU): 4 for N <= 64, 2 for N <= 128, else 1.  (Round 4's first rule -- 4 up to 128, 2 up to 400 -- put 396
+// workgroups on 256 CUs at N = 99: a second round started 150 us in, tools/gba_trace.sh; linearise + Schur 1.02 -> 0.80 ms there.)
+// A wave finds ITS blocks of a source frame with one 64-wide fetch of the frame's targets and a ballot (it used to read the targets
+// one by one, a dependent round trip per block whether the block was its own or not).
 // (A row is one dependent chain per wave -- ~28 source frames x its share of their ~28 blocks, each a round trip for the block
 // operands and one for the read-modify-write: with 4 waves per row the kernel took 0.45-1.9 ms, with 16 0.3-1.9; measured
 // alternative: the frame's blocks staged in LDS + the row in an LDS strip, 16 waves: slower (two barriers and a 64 KB copy per
 // source frame); the atomics version this replaces: 0.28 ms.)  `S` and `y` must be zero on entry.
 constexpr int kRowWaves = 16;
+#ifdef GBA_TRACE
+// instrumentation build (tools/gba_trace.sh): wave 0 of the workgroup of the middle pose stamps the 100 MHz wall clock
+__device__ unsigned long long gba_trace_buf[96];
+__device__ unsigned long long gba_wg_buf[4096][3];     // start, end, source frames walked -- of every workgroup (pose x split)
+#define GT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x == (int)gridDim.x / 2 && (i) < 96) gba_trace_buf[i] = wall_clock64(); } while (0)
+#else
+#define GT(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ n_pairs,
                                                       const int32_t* __restrict__ run_lo, const int32_t* __restrict__ tgt_off,
                                                       const int32_t* __restrict__ tgt_list, const float* __restrict__ pairbuf,
@@ -185,6 +195,11 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
                                                       int f0, int n_frames, int t0, int N, float* __restrict__ S,
                                                       float* __restrict__ y) {
   const int p = blockIdx.x, j = p + t0;
+  GT(0);
+#ifdef GBA_TRACE
+  const int wg_ = (int)blockIdx.x * (int)gridDim.y + (int)blockIdx.y;
+  if (threadIdx.x == 0 && wg_ < 4096) gba_wg_buf[wg_][0] = wall_clock64();
+#endif
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) + kRowWaves * (int)blockIdx.y);
   const int kRowCls = kRowWaves * (int)gridDim.y;
   const int64_t n6 = 6 * (int64_t)N;
@@ -212,9 +227,11 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   }
   // ---- Schur terms: every source frame f that has a block with pose p -- the sources of the target list, and j itself (its
   //      self block; a pair (j, j) of self edges is in the target list too) -- in ascending f
-  int q = tl0;
+  GT(1);
+  int q = tl0, it_ = 0;
   bool self_done = !own;
   while (q < tl1 || !self_done) {
+    GT(2 + it_); ++it_;
     int f, ga_;                                                    // the next frame and, if it comes from the list, its pair
     const int gq = q < tl1 ? tgt_list[q] : -1;
     const int fq = gq >= 0 ? pair_ij[2 * gq] : 0x7fffffff;
@@ -230,9 +247,19 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
       const float* Ea;
       if (which == 0) { if (ga_ < 0) continue; Ea = Ecol + (int64_t)ga_ * M * 6; }
       else { if (f != j) continue; Ea = Eself + (int64_t)fr * M * 6; }
-      for (int b = 0; b <= P; ++b) {
-        const int pb_ = (b < P ? pair_ij[2 * (g0 + b) + 1] : f) - t0;
-        if (pb_ < 0 || pb_ >= N || (pb_ % kRowCls) != wave) continue;
+      // f's blocks that are THIS wave's (column pose mod #waves), in ascending block order: the lanes fetch the targets of 64 blocks at
+      // once and the wave walks the set bits of a ballot -- as a scalar loop over all P + 1 blocks every wave paid a dependent global
+      // round trip per block just to find out that it was not its own (28 source frames x 28 blocks: most of the kernel's 0.6 ms)
+      for (int b0 = 0; b0 <= P; b0 += 64) {
+       const int bl_ = b0 + lane;
+       int pbl = -1;
+       if (bl_ <= P) pbl = (bl_ < P ? pair_ij[2 * (g0 + bl_) + 1] : f) - t0;
+       unsigned long long todo = __ballot(bl_ <= P && pbl >= 0 && pbl < N && (pbl % kRowCls) == wave);
+       while (todo) {
+        const int bit = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const int b = b0 + bit;
+        const int pb_ = __builtin_amdgcn_readlane(pbl, bit);
         const float* Eb = b < P ? Ecol + (int64_t)(g0 + b) * M * 6 : Eself + (int64_t)fr * M * 6;
         float acc[36];
 #pragma unroll
@@ -255,6 +282,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
           for (int k = 0; k < 36; ++k) v = (k == lane) ? acc[k] : v;
           Srow[(int64_t)r36 * n6 + 6 * pb_ + c36] -= v;
         }
+       }
       }
       if (wave == 0) {                                             // right-hand side: y[p] -= sum_slot Q u ea
         float acc[6] = {0, 0, 0, 0, 0, 0};
@@ -274,6 +302,12 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
       }
     }
   }
+  GT(90);
+#ifdef GBA_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_ < 4096) { gba_wg_buf[wg_][1] = wall_clock64(); gba_wg_buf[wg_][2] = it_; }
+  if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x == (int)gridDim.x / 2) gba_trace_buf[95] = it_;
+#endif
 }
 
 // dZ = Q (u - sum_blocks e_block . dX[pose(block)]) per (frame, slot) that owns edges; then retractions
@@ -373,7 +407,7 @@ extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, cons
                      edgebuf, Ecol, M);
   hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
                      plan + PL.patch_off, plan + PL.kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself);
-  hipLaunchKernelGGL(gba_row_kernel, dim3((unsigned)N, N <= 128 ? 4u : (N <= 400 ? 2u : 1u)), dim3(64 * kRowWaves), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
+  hipLaunchKernelGGL(gba_row_kernel, dim3((unsigned)N, N <= 64 ? 4u : (N <= 128 ? 2u : 1u)), dim3(64 * kRowWaves), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
                      pairbuf, Q, U, Ecol, Eself, M, f0, n_frames, t0, N, S, y);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
@@ -399,3 +433,12 @@ extern "C" int dpvo_gba_retract(float* poses, float* patches, const int32_t* pla
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }
+
+#ifdef GBA_TRACE
+extern "C" int dpvo_debug_gba_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gba_trace_buf), sizeof(gba_trace_buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int dpvo_debug_gba_wg_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gba_wg_buf), sizeof(gba_wg_buf)) == hipSuccess ? 0 : 1;
+}
+#endif

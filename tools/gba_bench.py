@@ -19,7 +19,8 @@ def main():
     M = int(os.environ.get("M", "96"))
     print(f"{'N free':>7s} {'edges':>8s} {'patches':>8s} | " + " | ".join(f"{n:>42s}" for n in
           ("linearise + Schur", "damping + Cholesky + substitutions (chol.hip)", "back-substitution + retraction")) + " | total ms (2 iterations)")
-    for n in (50, 100, 200, 400, 800):
+    sizes = tuple(int(v) for v in os.environ.get("GBA_SIZES", "50,100,200,400,800").split(","))
+    for n in sizes:
         cfg = S.GraphCfg(M=M, REMOVAL_WINDOW=10 * n, PATCH_LIFETIME=13)
         ii, jj, kk = S.replay_graph(n, cfg)
         old = torch.arange(3, n - 40, max(1, (n - 43) // 12))[:12]
@@ -49,6 +50,28 @@ def main():
         names = ("linearise + Schur", "damping + Cholesky + substitutions (chol.hip)", "back-substitution + retraction")
         print(f"{n - 1:7d} {ii.numel():8d} {plan.n_patches():8d} | " + " | ".join(f"{acc[k]:42.3f}" for k in names) +
               f" | {sum(acc.values()):.3f}")
+        if os.environ.get("GBA_TRACE"):          # (library built by tools/gba_trace.sh: phase stamps of one wave of gba_row_kernel)
+            import ctypes
+            import numpy as np
+            from dpvo_amd import _lib as L
+            buf = (ctypes.c_ulonglong * 96)()
+            assert L.lib().dpvo_debug_gba_trace(buf) == 0
+            t = np.array(list(buf), dtype=np.int64)
+            its = int(t[95]); t = t / 100.0
+            step = [t[2 + i + 1] - t[2 + i] for i in range(min(its, 80) - 1)]
+            print(f"    gba_row_kernel, wave 0 of the middle pose: B / v part {t[1] - t[0]:.1f} us, {its} source frames, per frame "
+                  f"median {np.median(step):.1f} max {np.max(step):.1f} us, total {t[90] - t[0]:.1f} us")
+            wb = (ctypes.c_ulonglong * (4096 * 3))()
+            assert L.lib().dpvo_debug_gba_wg_trace(wb) == 0
+            w = np.array(list(wb), dtype=np.int64).reshape(4096, 3)
+            split = 4 if n - 1 <= 128 else (2 if n - 1 <= 400 else 1)
+            nwg = min(4096, (n - 1) * split)
+            w = w[:nwg]; t0_ = w[:, 0].min()
+            dur = (w[:, 1] - w[:, 0]) / 100.0
+            order = np.argsort(-dur)[:6]
+            print(f"    {nwg} workgroups: start {(w[:, 0].max() - t0_) / 100.0:.1f} us apart, duration median {np.median(dur):.1f} max {dur.max():.1f} us, "
+                  f"last end {(w[:, 1].max() - t0_) / 100.0:.1f} us; longest: " +
+                  ", ".join(f"pose {i // split} part {i % split}: {dur[i]:.0f} us, {int(w[i, 2])} frames" for i in order))
 
 
 if __name__ == "__main__":
