@@ -96,6 +96,7 @@ class DPVO:
         # dpvo.py:266-270 (True = drop keyframe n - KEYFRAME_INDEX); the test kernel and its read-back still run.  For workloads
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
+        self._loop_pairs_total = 0  # edges ever appended from outside the tracker's own bookkeeping (bounds the pair count of the global plan)
         self._lr_active = 0         # long-range (loop-closure) edges in the active list: > 0 => update() owes a global BA (dpvo.py:348)
         self._enc_done_ev = None    # the side stream's "encoders done" events (two, alternating)
         self._fs_join = None        # (encoders-done event handle, speculative feature-map slot) handed to the next frame call
@@ -332,6 +333,7 @@ class DPVO:
         if lr_count is None:
             lr_count = int((src < self.n - self.cfg.REMOVAL_WINDOW - 1).sum().item()) if ii.numel() else 0
         self._lr_active += int(lr_count)
+        self._loop_pairs_total += int(ii.numel())          # (an upper bound on the frame pairs these edges add to any plan)
 
     def append_frame_factors(self):
         """append_factors(*edges_forw) + append_factors(*edges_back) (dpvo.py:458-459) as one kernel"""
@@ -786,9 +788,24 @@ class DPVO:
 
         self.pg.normalize()
         t0 = int(self.pg.edges.host()["ii"].min()) if self.pg.edges.mirror else self.pg.ii.min().item()      # (the host mirror: no device wait)
+        # The plan of active + inactive edges with BOUNDS on its group counts and on the frame range instead of read-backs (the kernels
+        # read the exact counts on the device, the bounds size launches and workspaces): patches <= n M; frame pairs <= the tracker's
+        # own (every frame with its 2 PATCH_LIFETIME + 2 neighbours) + every loop-closure pair ever appended; frames [0, n).  With the
+        # long-range test and t0 answered from the host's bookkeeping the host does not wait for the device anywhere in a global-BA
+        # frame: it used to four times, each time with the GPU idle behind it.
+        plan = None
+        if not _PLAN_SYNC:
+            E_all = int(full_ii.numel())
+            ub_p = min(E_all, self.n * self.M)
+            ub_g = min(E_all, self.n * (2 * self.cfg.PATCH_LIFETIME + 2) + self._loop_pairs_total + self.n)
+            plan = GraphPlan(full_ii.contiguous(), full_jj.contiguous(), full_kk.contiguous(), n_patches_ub=ub_p, n_pairs_ub=ub_g,
+                             n_frames=self.N, n_patch_ids=self.N * self.M)
+            if _CHECK_MIRROR:
+                c = plan.counts.cpu().tolist()
+                assert c[0] <= ub_p and c[1] <= ub_g, ("global plan bounds", c, ub_p, ub_g)
         fastba.BA(self.poses, self.patches, self.intrinsics,
                   full_target, full_weight, 1e-4, full_ii, full_jj, full_kk, t0, self.n, M=self.M, iterations=2,
-                  eff_impl=True)
+                  eff_impl=True, plan=plan, f0=0 if plan is not None else None, n_frames=self.n if plan is not None else None)
         self.ran_global_ba[self.n] = True
 
     def plan_sync(self):
@@ -802,6 +819,13 @@ class DPVO:
         the side stream behind that event only (the caller runs plan_sync() before the first reader on the main stream)."""
         if self._plan is None or self._plan.E != self.pg.ii.numel():
             ub_p = ub_g = window = None
+            if self._lr_active > 0 and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
+                # long-range edges active: no window, but still bounds (sources inside the removal window + one patch / one frame pair
+                # per long-range edge at most + the targets of foreign edges that are not long-range by the test): no read-back
+                nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
+                E_ = int(self.pg.ii.numel())
+                ub_p = min(E_, nf * self.M + self._lr_active)
+                ub_g = min(E_, nf * (2 * self.cfg.PATCH_LIFETIME + 2) + self._lr_active + self.n)
             if self._lr_active == 0 and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
                 # every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
                 # PATCH_LIFETIME frames of the source: bounds on #patches / #frame pairs, no device read-back needed

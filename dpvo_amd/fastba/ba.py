@@ -40,7 +40,7 @@ def reproject(poses, patches, intrinsics, ii, jj, kk, clamp_z=False):
 
 
 def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, eff_impl=False, plan=None,
-       info=None):
+       info=None, f0=None, n_frames=None):
     """cuda_ba.forward (ba.py:7-8, ba_cuda.cu:433-582): updates `poses` and `patches` storage IN PLACE, returns [].
 
     `plan` (a GraphPlan of the same ii,jj,kk) may be passed to reuse the per-frame index structures."""
@@ -54,7 +54,9 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M,
     N = t1 - t0
     if eff_impl or 6 * N > 120:
         from .global_ba import global_BA
-        return global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, plan=plan)
+        # (f0 / n_frames: a frame range that covers every source frame, from the caller's bookkeeping: no read-back of min / max kk)
+        return global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, plan=plan, f0=f0,
+                         n_frames=n_frames)
     ii = ii.long().contiguous(); jj = jj.long().contiguous(); kk = kk.long().contiguous()
     target = target.reshape(-1, 2).float().contiguous()
     weight = weight.reshape(-1, 2).float().contiguous()

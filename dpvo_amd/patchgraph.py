@@ -428,7 +428,7 @@ class PatchGraph:
         self.poses_[:self.n, :3] *= s
         for t, (t0, dP) in self.delta.items():
             self.delta[t] = (t0, dP.scale(s))
-        self.poses_[:self.n] = (SE3(self.poses_[:self.n]) * SE3(self.poses_[[0]]).inv()).data
+        self.poses_[:self.n] = (SE3(self.poses_[:self.n]) * SE3(self.poses_[0:1]).inv()).data
 
         points = pops.point_cloud(self.poses, self.patches[:, :self.m], self.intrinsics, self.ix[:self.m])
         self.points_[:len(points)] = points[:]

@@ -40,5 +40,5 @@ gb = [r[1] for r in rows if r[2]]; oc = [r[1] for r in rows if r[3] and not r[2]
 print(f"global-BA frames: {len(gb)}, mean {sum(gb) / max(len(gb), 1):.3f} ms; one-call frames: {len(oc)}, mean {sum(oc) / max(len(oc), 1):.3f} ms; "
       f"other: {len(other)}, mean {sum(other) / max(len(other), 1):.3f} ms  (every frame followed by a device sync: {sync})")
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(38)
+pstats.Stats(pr, stream=s).sort_stats(os.environ.get("LC_SORT", "cumulative")).print_stats(38)
 print(s.getvalue()[:7000])
