@@ -183,6 +183,7 @@ constexpr int kRowWaves = 16;
 // instrumentation build (tools/gba_trace.sh): wave 0 of the workgroup of the middle pose stamps the 100 MHz wall clock
 __device__ unsigned long long gba_trace_buf[96];
 __device__ unsigned long long gba_wg_buf[4096][3];     // start, end, source frames walked -- of every workgroup (pose x split)
+__device__ unsigned int gba_wave_buf[1024][16][2];     // per wave: ticks from the workgroup's start to the wave's end, blocks it owned
 #define GT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x == (int)gridDim.x / 2 && (i) < 96) gba_trace_buf[i] = wall_clock64(); } while (0)
 #else
 #define GT(i) do {} while (0)
@@ -228,18 +229,35 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   // ---- Schur terms: every source frame f that has a block with pose p -- the sources of the target list, and j itself (its
   //      self block; a pair (j, j) of self edges is in the target list too) -- in ascending f
   GT(1);
+#ifdef GBA_TRACE
+  int nblk_ = 0;
+  const unsigned long long wstart_ = wall_clock64();
+#endif
   int q = tl0, it_ = 0;
   bool self_done = !own;
+  // the list's metadata -- pair, its source frame, that frame's pair run -- for 64 entries at a time in the lanes (three round trips per
+  // 64 frames instead of three per frame), handed out with readlane
+  int qbase = tl0 - 64, m_g = -1, m_f = 0x7fffffff, m_g0 = 0, m_g1 = 0;
   while (q < tl1 || !self_done) {
     GT(2 + it_); ++it_;
-    int f, ga_;                                                    // the next frame and, if it comes from the list, its pair
-    const int gq = q < tl1 ? tgt_list[q] : -1;
-    const int fq = gq >= 0 ? pair_ij[2 * gq] : 0x7fffffff;
-    if (!self_done && j <= fq) { f = j; ga_ = (fq == j) ? gq : -1; self_done = true; if (fq == j) ++q; }
-    else { f = fq; ga_ = gq; ++q; }
+    if (q < tl1 && q - qbase >= 64) {
+      qbase = q;
+      const int qi_ = q + lane;
+      m_g = qi_ < tl1 ? tgt_list[qi_] : -1;
+      m_f = m_g >= 0 ? pair_ij[2 * m_g] : 0x7fffffff;
+      const int mfr = m_f - f0;
+      const bool fin = m_g >= 0 && mfr >= 0 && mfr < n_frames;
+      m_g0 = fin ? run_lo[mfr] : 0; m_g1 = fin ? run_lo[mfr + 1] : 0;
+    }
+    int f, ga_, g0, g1;                                            // the next frame, its pair run and, if it comes from the list, its pair
+    const int ql = __builtin_amdgcn_readfirstlane(q < tl1 ? q - qbase : 0);
+    const int gq = q < tl1 ? __builtin_amdgcn_readlane(m_g, ql) : -1;
+    const int fq = gq >= 0 ? __builtin_amdgcn_readlane(m_f, ql) : 0x7fffffff;
+    if (!self_done && j <= fq) { f = j; ga_ = (fq == j) ? gq : -1; self_done = true; if (fq == j) ++q; g0 = ja; g1 = jb; }
+    else { f = fq; ga_ = gq; ++q; g0 = __builtin_amdgcn_readlane(m_g0, ql); g1 = __builtin_amdgcn_readlane(m_g1, ql); }
     const int fr = f - f0;
     if (fr < 0 || fr >= n_frames) continue;
-    const int g0 = run_lo[fr], g1 = run_lo[fr + 1], P = g1 - g0;
+    const int P = g1 - g0;
     const float* Qf = Q + (int64_t)fr * M;
     const float* Uf = U + (int64_t)fr * M;
     // the (at most two) blocks of f whose pose is p: its pair (f, j) if any, and the self block when f == j
@@ -248,62 +266,86 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
       if (which == 0) { if (ga_ < 0) continue; Ea = Ecol + (int64_t)ga_ * M * 6; }
       else { if (f != j) continue; Ea = Eself + (int64_t)fr * M * 6; }
       // f's blocks that are THIS wave's (column pose mod #waves), in ascending block order: the lanes fetch the targets of 64 blocks at
-      // once and the wave walks the set bits of a ballot -- as a scalar loop over all P + 1 blocks every wave paid a dependent global
-      // round trip per block just to find out that it was not its own (28 source frames x 28 blocks: most of the kernel's 0.6 ms)
+      // once and the wave walks the set bits of a ballot (as a scalar loop over all P + 1 blocks every wave paid a dependent global
+      // round trip per block just to find out that it was not its own).  The products run on the matrix core, two of the wave's
+      // blocks per tile:  D (16 x 16) += A (16 x 4) B (4 x 16) over the M patch slots, four per v_mfma_f32_16x16x4_f32 -- rows 0..5 of A =
+      // e_a of the slot, columns 0..5 / 6..11 of B = Q e_b of the first / second block, column 12 (wave 0 only) = Q u: the right-hand
+      // side comes with it.  An exact f32 fma chain in slot order; every entry of the row is still written by one wave in program
+      // order.  (One lane per slot with 36 accumulators and 36 wave reductions per block took 7.5 us per block, tools/gba_trace.sh.)
+      const int li = lane & 15, lk = lane >> 4;
+      auto tile = [&](const float* Eb0, int pb0, const float* Eb1, int pb1, bool rhs) {
+        const float* Eb = li < 6 ? Eb0 : (li < 12 ? Eb1 : nullptr);
+        const int cj = li < 6 ? li : li - 6;
+        const bool rl = rhs && li == 12;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the row's current values travel with the operands (the read-modify-write's read is not a round trip of its own)
+        float cur[4] = {0.f, 0.f, 0.f, 0.f};
+        float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * lk + r;
+          if (i < 6) {
+            if (li < 6) { if (Eb0) dst[r] = Srow + (int64_t)i * n6 + 6 * pb0 + li; }
+            else if (li < 12) { if (Eb1) dst[r] = Srow + (int64_t)i * n6 + 6 * pb1 + (li - 6); }
+            else if (rl) dst[r] = y + 6 * p + i;
+          }
+          if (dst[r]) cur[r] = *dst[r];
+        }
+        for (int s0 = 0; s0 < M; s0 += 48) {                         // 48 slots per trip: their 36 loads in flight, then 12 MFMAs
+          float av[12], qv[12], bv[12];
+#pragma unroll
+          for (int u = 0; u < 12; ++u) {
+            const int s_ = s0 + 4 * u + lk;
+            const bool sv = s_ < M;
+            av[u] = (li < 6 && sv) ? Ea[s_ * 6 + li] : 0.f;
+            qv[u] = sv ? Qf[s_] : 0.f;
+            bv[u] = 0.f;
+            if (Eb && sv) bv[u] = Eb[s_ * 6 + cj];
+            if (rl && sv) bv[u] = Uf[s_];
+          }
+#pragma unroll
+          for (int u = 0; u < 12; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], qv[u] * bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                                  // acc[r] = D[4 lk + r][li]
+          if (dst[r]) *dst[r] = cur[r] - acc[r];
+      };
+      bool rhs_due = wave == 0;                                      // right-hand side: y[p] -= sum_slot Q u e_a, once per (f, which)
       for (int b0 = 0; b0 <= P; b0 += 64) {
-       const int bl_ = b0 + lane;
-       int pbl = -1;
-       if (bl_ <= P) pbl = (bl_ < P ? pair_ij[2 * (g0 + bl_) + 1] : f) - t0;
-       unsigned long long todo = __ballot(bl_ <= P && pbl >= 0 && pbl < N && (pbl % kRowCls) == wave);
-       while (todo) {
-        const int bit = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        todo &= todo - 1;
-        const int b = b0 + bit;
-        const int pb_ = __builtin_amdgcn_readlane(pbl, bit);
-        const float* Eb = b < P ? Ecol + (int64_t)(g0 + b) * M * 6 : Eself + (int64_t)fr * M * 6;
-        float acc[36];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) acc[k] = 0.f;
-        for (int s_ = lane; s_ < M; s_ += 64) {
-          const float qv = Qf[s_];
-          float ea[6], eb[6];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) { ea[r] = Ea[s_ * 6 + r]; eb[r] = Eb[s_ * 6 + r]; }
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += qv * (ea[r] * eb[c]);      // (commutative inner product: S stays symmetric)
-        }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) acc[k] = wave_sum(acc[k]);
-        if (lane < 36) {
-          float v = 0.f;
-#pragma unroll
-          for (int k = 0; k < 36; ++k) v = (k == lane) ? acc[k] : v;
-          Srow[(int64_t)r36 * n6 + 6 * pb_ + c36] -= v;
-        }
-       }
-      }
-      if (wave == 0) {                                             // right-hand side: y[p] -= sum_slot Q u ea
-        float acc[6] = {0, 0, 0, 0, 0, 0};
-        for (int s_ = lane; s_ < M; s_ += 64) {
-          const float qu = Qf[s_] * Uf[s_];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) acc[r] += qu * Ea[s_ * 6 + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane < 6) {
-          float v = 0.f;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) v = (r == lane) ? acc[r] : v;
-          y[6 * p + lane] -= v;
+        const int bl_ = b0 + lane;
+        int pbl = -1;
+        if (bl_ <= P) pbl = (bl_ < P ? pair_ij[2 * (g0 + bl_) + 1] : f) - t0;
+        unsigned long long todo = __ballot(bl_ <= P && pbl >= 0 && pbl < N && (pbl % kRowCls) == wave);
+        while (todo) {
+          const int bit0 = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+          todo &= todo - 1;
+          const int bA = b0 + bit0, pA = __builtin_amdgcn_readlane(pbl, bit0);
+          const float* EA = bA < P ? Ecol + (int64_t)(g0 + bA) * M * 6 : Eself + (int64_t)fr * M * 6;
+          const float* EB = nullptr;
+          int pB = 0;
+          if (todo) {                                                // a second block for the same tile -- unless it is the same pose
+            const int bit1 = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);     // (a self pair + the self block)
+            const int pC = __builtin_amdgcn_readlane(pbl, bit1);
+            if (pC != pA) {
+              todo &= todo - 1;
+              const int bB = b0 + bit1;
+              pB = pC;
+              EB = bB < P ? Ecol + (int64_t)(g0 + bB) * M * 6 : Eself + (int64_t)fr * M * 6;
+            }
+          }
+#ifdef GBA_TRACE
+          nblk_ += EB ? 2 : 1;
+#endif
+          tile(EA, pA, EB, pB, rhs_due);
+          rhs_due = false;
         }
       }
+      if (rhs_due) tile(nullptr, 0, nullptr, 0, true);
     }
   }
   GT(90);
 #ifdef GBA_TRACE
+  if (lane == 0 && wg_ < 1024) { gba_wave_buf[wg_][threadIdx.x >> 6][0] = (unsigned int)(wall_clock64() - wstart_); gba_wave_buf[wg_][threadIdx.x >> 6][1] = nblk_; }
   __syncthreads();
   if (threadIdx.x == 0 && wg_ < 4096) { gba_wg_buf[wg_][1] = wall_clock64(); gba_wg_buf[wg_][2] = it_; }
   if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x == (int)gridDim.x / 2) gba_trace_buf[95] = it_;
@@ -437,6 +479,9 @@ extern "C" int dpvo_gba_retract(float* poses, float* patches, const int32_t* pla
 #ifdef GBA_TRACE
 extern "C" int dpvo_debug_gba_trace(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gba_trace_buf), sizeof(gba_trace_buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int dpvo_debug_gba_wave_trace(unsigned int* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gba_wave_buf), sizeof(gba_wave_buf)) == hipSuccess ? 0 : 1;
 }
 extern "C" int dpvo_debug_gba_wg_trace(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gba_wg_buf), sizeof(gba_wg_buf)) == hipSuccess ? 0 : 1;

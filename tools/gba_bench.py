@@ -64,7 +64,7 @@ def main():
             wb = (ctypes.c_ulonglong * (4096 * 3))()
             assert L.lib().dpvo_debug_gba_wg_trace(wb) == 0
             w = np.array(list(wb), dtype=np.int64).reshape(4096, 3)
-            split = 4 if n - 1 <= 128 else (2 if n - 1 <= 400 else 1)
+            split = 4 if n - 1 <= 64 else (2 if n - 1 <= 128 else 1)
             nwg = min(4096, (n - 1) * split)
             w = w[:nwg]; t0_ = w[:, 0].min()
             dur = (w[:, 1] - w[:, 0]) / 100.0
@@ -72,6 +72,13 @@ def main():
             print(f"    {nwg} workgroups: start {(w[:, 0].max() - t0_) / 100.0:.1f} us apart, duration median {np.median(dur):.1f} max {dur.max():.1f} us, "
                   f"last end {(w[:, 1].max() - t0_) / 100.0:.1f} us; longest: " +
                   ", ".join(f"pose {i // split} part {i % split}: {dur[i]:.0f} us, {int(w[i, 2])} frames" for i in order))
+            vb = (ctypes.c_uint * (1024 * 16 * 2))()
+            assert L.lib().dpvo_debug_gba_wave_trace(vb) == 0
+            v = np.array(list(vb), dtype=np.int64).reshape(1024, 16, 2)[:min(nwg, 1024)]
+            wt, wb = v[:, :, 0] / 100.0, v[:, :, 1]
+            print(f"    waves (after the B / v part): blocks per wave min {wb.min()} median {int(np.median(wb))} max {wb.max()}; time per wave median {np.median(wt):.1f} "
+                  f"max {wt.max():.1f} us; us per block (waves with > 4 blocks) median {np.median((wt / np.maximum(wb, 1))[wb > 4]):.2f}; "
+                  f"slowest wave: {wt.max():.0f} us with {wb.reshape(-1)[wt.argmax()]} blocks; corr(time, blocks) {np.corrcoef(wt.reshape(-1), wb.reshape(-1))[0, 1]:.2f}")
 
 
 if __name__ == "__main__":
