@@ -9,9 +9,9 @@
 // (i,j) (patch slot = kk % M) plus one "self" block per source frame (the -w Jz Ji side, summed over all edges of the
 // patch).  Everything is indexed by the device-built graph plan (pairs sorted by (i,j), so the pairs of one source
 // frame are a contiguous run) -- no host tables.
-//   gba_scatter_kernel   edge records -> Ecol[pair][slot][6]: a block per pair, a thread per patch slot sums that slot's
+//   gba_scatter_kernel   edge records -> Ecol[pair][6][slot]: a block per pair, a thread per patch slot sums that slot's
 //                        edges in list order (duplicates of a (patch, frame) edge fold in a fixed order)
-//   gba_patch_kernel     per patch (CSR): C, u, Ei -> Q, u, Eself[frame][slot][6]
+//   gba_patch_kernel     per patch (CSR): C, u, Ei -> Q, u, Eself[frame][6][slot]
 //   gba_index_kernel     pairs by TARGET pose (tgt_off / tgt_list, ascending pair index) and the pair run of every source frame
 //   gba_row_kernel       one workgroup per free pose p builds block row p of S = B - E Q E^T and y[p] = v - E Q u: the B / v
 //                        terms of the pairs that touch p, then, for every source frame that sees p (ascending), the Schur
@@ -75,9 +75,9 @@ __global__ __launch_bounds__(128) void gba_scatter_kernel(const int64_t* __restr
             }
       }
       if (slot < M) {
-        float* dst = Ecol + ((int64_t)g * M + slot) * 6;
+        float* dst = Ecol + (int64_t)g * 6 * M + slot;                  // [pair][6][M]: component-major (see gba_row_kernel)
 #pragma unroll
-        for (int a = 0; a < 6; ++a) dst[a] = acc[a];
+        for (int a = 0; a < 6; ++a) dst[(int64_t)a * M] = acc[a];
       }
     }
   }
@@ -104,7 +104,7 @@ __global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32
     Q[o] = 1.0f / (C + lmbda);
     U[o] = u;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) Eself[o * 6 + a] = Ei[a];
+    for (int a = 0; a < 6; ++a) Eself[((int64_t)fr * 6 + a) * M + slot] = Ei[a];          // [frame][6][M]
   }
 }
 
@@ -291,20 +291,38 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
           }
           if (dst[r]) cur[r] = *dst[r];
         }
-        for (int s0 = 0; s0 < M; s0 += 48) {                         // 48 slots per trip: their 36 loads in flight, then 12 MFMAs
-          float av[12], qv[12], bv[12];
+        // operands: the blocks are stored component-major ([6][M]), so a lane's operands of FOUR chain steps are one 16-byte load: in
+        // step (u, c) the four k-lanes of the tile take the slots 16 u + 4 lk + c.  48 slots per trip: 9 loads in flight, then 12
+        // MFMAs.  (Slot-major blocks meant 72 four-byte gathers per tile and wave; a CU's 16 waves push them through one texture
+        // path: that, not the arithmetic, was what a block cost.)
+        const bool vec = (M & 3) == 0;
+        auto ld4 = [&](const float* row, int s_, bool on) -> f4 {
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (on) {
+            if (vec) v = *reinterpret_cast<const f4*>(row + s_);
+            else {
 #pragma unroll
-          for (int u = 0; u < 12; ++u) {
-            const int s_ = s0 + 4 * u + lk;
-            const bool sv = s_ < M;
-            av[u] = (li < 6 && sv) ? Ea[s_ * 6 + li] : 0.f;
-            qv[u] = sv ? Qf[s_] : 0.f;
-            bv[u] = 0.f;
-            if (Eb && sv) bv[u] = Eb[s_ * 6 + cj];
-            if (rl && sv) bv[u] = Uf[s_];
+              for (int c = 0; c < 4; ++c) if (s_ + c < M) v[c] = row[s_ + c];
+            }
+          }
+          return v;
+        };
+        const float* arow = Ea + (int64_t)(li < 6 ? li : 0) * M;
+        const float* brow = Eb ? Eb + (int64_t)cj * M : (rl ? Uf : nullptr);
+        for (int s0 = 0; s0 < M; s0 += 48) {
+          f4 a4[3], b4[3], q4[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int s_ = s0 + 16 * u + 4 * lk;
+            const bool on = s_ < M;
+            a4[u] = ld4(arow, s_, on && li < 6);
+            q4[u] = ld4(Qf, s_, on);
+            b4[u] = ld4(brow, s_, on && brow != nullptr);
           }
 #pragma unroll
-          for (int u = 0; u < 12; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], qv[u] * bv[u], acc, 0, 0, 0);
+          for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][c], q4[u][c] * b4[u][c], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)                                  // acc[r] = D[4 lk + r][li]
@@ -371,16 +389,16 @@ __global__ __launch_bounds__(128) void gba_retr_kernel(float* __restrict__ poses
     float s = 0.f;
     const int ix = f - t0;
     if (ix >= 0 && ix < N) {
-      const float* e = Eself + ((int64_t)fr * M + slot) * 6;
+      const float* e = Eself + (int64_t)fr * 6 * M + slot;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) s += e[r] * dX[6 * ix + r];
+      for (int r = 0; r < 6; ++r) s += e[(int64_t)r * M] * dX[6 * ix + r];
     }
     for (int g = ga; g < gb; ++g) {
       const int jx = pair_ij[2 * g + 1] - t0;
       if (jx < 0 || jx >= N) continue;
-      const float* e = Ecol + ((int64_t)g * M + slot) * 6;
+      const float* e = Ecol + (int64_t)g * 6 * M + slot;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) s += e[r] * dX[6 * jx + r];
+      for (int r = 0; r < 6; ++r) s += e[(int64_t)r * M] * dX[6 * jx + r];
     }
     const int64_t o = (int64_t)fr * M + slot;
     const float dZ = Q[o] * (U[o] - s);
