@@ -126,12 +126,12 @@ def test_ctypes_structs_match_the_header(tmp_path):
     import subprocess
     from dpvo_amd import _lib as L
     from dpvo_amd.net import _UpdParams, _UpdFusedParams
-    probes = {"dpvo_plan_layout_t": (L.PlanLayout, ["perm_k", "counts", "total_ints"]),
+    probes = {"dpvo_plan_layout_t": (L.PlanLayout, ["perm_k", "counts", "total_ints", "flow"]),
               "dpvo_update_fused_params_t": (_UpdFusedParams, ["w", "b", "ln_g", "ln_b", "d_w", "w_b", "tiling", "start_skew"]),
               "dpvo_ring_t": (L.Ring, ["base", "slot_bytes", "ring"]),
               "dpvo_keyframe_step_t": (L.KeyframeStep, ["ii", "weight_b", "ii_inac", "inac_room", "flow4", "keep_rows", "result_host", "host_words", "ring", "n_ring",
                                                         "E", "n", "forced", "keyframe_thresh"]),
-              "dpvo_frame_update_t": (L.FrameUpdate, ["kf", "fs", "ev_fs", "ev_update_done", "fs_auto", "index_map", "net", "net_rows", "n_kept", "poses", "upd", "ws_ba", "ws_plan_bytes", "result_dev", "ev", "m", "n_buffer",
+              "dpvo_frame_update_t": (L.FrameUpdate, ["kf", "fs", "ev_fs", "ev_enc", "fmap_spec", "ev_record", "ev_update_done", "plan_stream", "ev_plan_fork", "ev_plan_done", "fs_auto", "index_map", "net", "net_rows", "n_kept", "poses", "upd", "ws_ba", "ws_plan_bytes", "result_dev", "ev", "m", "n_buffer",
                                                       "P", "iterations", "lmbda", "mm_beta"]),
               "dpvo_update_params_t": (_UpdParams, ["c0_w", "g1_b2", "w_b"]),
               "dpvo_frame_state_t": (L.FrameState, ["fmap", "index_map", "poses", "ix", "frame_next", "n_new", "res", "mm_scale", "M",
