@@ -151,3 +151,11 @@ def test_ctypes_structs_match_the_header(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), cname
         for f in fields:
             assert int(out[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
+def test_plan_layout_flow_region():
+    """dpvo_plan_layout: the flow-test list sits 16-byte aligned at the end of the plan, 4 + 2 x 256 ints, for every E"""
+    from dpvo_amd import _lib as L
+    for E in (0, 1, 2, 3, 5, 96, 1023, 45312, 47712):
+        lay = L.plan_layout(E)
+        assert lay.flow % 4 == 0 and lay.flow >= lay.counts + 4 and lay.total_ints == lay.flow + 4 + 2 * 256, E
