@@ -75,6 +75,7 @@ __device__ unsigned long long kf_trace_buf[2][16];
 #define KFT(i) do {} while (0)
 #endif
 constexpr int KF_CHUNK = 1024;
+constexpr int KF_SPIN_LIMIT = 1 << 18;   // x s_sleep(8) = 512 cycles: ~0.2 s at 100 MHz granularity before a look-back gives up
 constexpr int KF_HDR = 4;         // scratch behind the 8 result words: [0] generation, [1] workgroups done, then per chunk {kept, removed, long-range, flag}
 // ONE launch (rounds 2-3: a count kernel and a select kernel, 21 + 20 us): every 1024-edge chunk classifies its edges, publishes its
 // three counts with a flag (= the call's generation number, so nothing has to be cleared between calls) and reads the counts of the
@@ -85,7 +86,7 @@ constexpr int KF_HDR = 4;         // scratch behind the 8 result words: [0] gene
 // sums in F.out for the record and the host.  Same code, same reduction tree as dpvo_motionmag: same bits in every block.
 __global__ __launch_bounds__(KF_CHUNK) void kf_decide_kernel(const dpvo_keyframe_step_t a, int32_t* __restrict__ sc, const MotionPlanArgs F) {
   __shared__ int wsum[3][16];
-  __shared__ int pre[3];
+  __shared__ int pre[4];            // look-back prefixes {kept, removed, long-range}; [3]: a look-back gave up
   __shared__ float fl4[8];
   __shared__ __attribute__((aligned(16))) int rec[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_decide_kernel(const dpvo_keyframe
   KFT(0);
   const int gen = __hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   const float* flow4 = a.flow4;
-  if (tid < 3) pre[tid] = 0;
+  if (tid < 4) pre[tid] = 0;
   float statv = 0.f;                              // (the plan counters of the host record: fetched here, used at the very end)
   if (F.poses) {
     if (blk == last && tid >= 4 && tid < 8) statv = (float)F.n_pairs[tid - 5];
@@ -137,7 +138,13 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_decide_kernel(const dpvo_keyframe
     int ak = 0, ar = 0, al = 0;
     for (int b = tid; b < blk; b += KF_CHUNK) {
       const int32_t* o = sc + KF_HDR + 4 * b;
-      while (__hip_atomic_load(&o[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) __builtin_amdgcn_s_sleep(1);
+      // (bounded: a scratch that was cleared or reused between calls, or a launch that died half way, leaves flags this call never
+      //  sees -- ~0.2 s of polling, then the chunk gives up and the record says so (RES_OVERFLOW bit 1) instead of hanging the queue)
+      int spins = 0;
+      while (__hip_atomic_load(&o[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+        if (++spins > KF_SPIN_LIMIT) { pre[3] = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
       ak += __hip_atomic_load(&o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ar += __hip_atomic_load(&o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       al += __hip_atomic_load(&o[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_decide_kernel(const dpvo_keyframe
     if (tid == 0) {
       int nrem = pre[1] + tr, ovf = 0;
       if (nrem > a.inac_room) { nrem = (int)a.inac_room; ovf = 1; }
+      if (pre[3]) ovf |= 2;                       // (the look-back gave up: counts and index lists are not to be trusted)
       rec[8 + RES_DECISION] = d; rec[8 + RES_KEEP] = pre[0] + tk; rec[8 + RES_REM] = nrem; rec[8 + RES_E] = (int32_t)a.E;
       rec[8 + RES_OVERFLOW] = ovf; rec[8 + RES_LONG_RANGE] = pre[2] + tl; rec[8 + 6] = rec[8 + 7] = 0;
     }
@@ -414,7 +422,7 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
     // the encoders wrote the frame's feature map where the host EXPECTED its ring slot to be; a keyframe dropped in between moved
     // the slot down by one (dpvo.py:289-299 shifts the ring, the new frame lands at n - 1)
     if (a->fmap_spec && a->fmap_spec != a->fs->fmap &&
-        hipMemcpyAsync(const_cast<void*>(a->fs->fmap), a->fmap_spec, (size_t)K.ring[6].slot_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        hipMemcpyAsync(const_cast<void*>(a->fs->fmap), a->fmap_spec, (size_t)a->H0 * a->W0 * 128 * 2 /* [H0][W0][128] f16, the map dpvo_corr_pyramid_forward reads below */, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return DPVO_E_INVALID;
     STEP(dpvo_frame_state_part(a->fs, 2, stream));
     if (a->ev_fs && hipEventRecord((hipEvent_t)a->ev_fs, st) != hipSuccess) return DPVO_E_INVALID;

@@ -97,8 +97,10 @@ class DPVO:
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
         self._loop_pairs_total = 0  # edges ever appended from outside the tracker's own bookkeeping (bounds the pair count of the global plan)
+        self._bound_watch = []      # plans built with host-side bounds whose exact counts are on their way back (_watch_plan_bounds)
         self._lr_active = 0         # long-range (loop-closure) edges in the active list: > 0 => update() owes a global BA (dpvo.py:348)
         self._enc_done_ev = None    # the side stream's "encoders done" events (two, alternating)
+        self._rng_done_ev = None    # the side stream's "random draws done" events (two, alternating)
         self._fs_join = None        # (encoders-done event handle, speculative feature-map slot) handed to the next frame call
         self._loop_try = None       # this frame's PatchGraph.edges_loop() result when it was evaluated ahead of the frame call
         self.last_keyframe = None   # (decision, (sum_ij, count_ij, sum_ji, count_ji)) of the last resolved keyframe test
@@ -272,6 +274,7 @@ class DPVO:
         for _ in range(12):
             self.ran_global_ba[self.n] = False
             self.update()
+        self._check_plan_bounds(wait=True)
 
         """ interpolate missing poses """
         self.traj = {}
@@ -425,6 +428,8 @@ class DPVO:
         if self._fu_pending is not None:
             pending, self._fu_pending = self._fu_pending, None
             self._frame_update_finish(*pending)
+        if self._bound_watch:
+            self._check_plan_bounds()
 
     def keyframe(self):
         pending = self._keyframe_begin()
@@ -488,9 +493,11 @@ class DPVO:
             to_remove, staged = self._removal_mask(es.host()), None
 
         self.remove_factors(to_remove, store=True, staged=staged)
-        if self.cfg.LOOP_CLOSURE:
+        if self.cfg.LOOP_CLOSURE or self._lr_active > 0:
             # what the device-side step reports in its result word [5]: the edges the rule of dpvo.py:307-308 kept alive.  With the
-            # next frame counted (n + 1) they satisfy ii < n - REMOVAL_WINDOW - 1 of dpvo.py:348
+            # next frame counted (n + 1) they satisfy ii < n - REMOVAL_WINDOW - 1 of dpvo.py:348.  (Also without LOOP_CLOSURE once a
+            # caller has appended old patches through append_factors(): the removal above has dropped them, the count returns to 0
+            # and with it the window plan / the one-call path -- ADVICE r4: it used to stick)
             self._lr_active = int(np.count_nonzero(es.host()["ii"] < self.n - self.cfg.REMOVAL_WINDOW))
         if _CHECK_MIRROR:       # tests: the host mirror must track the device arrays exactly
             h = es.host()
@@ -800,6 +807,7 @@ class DPVO:
             ub_g = min(E_all, self.n * (2 * self.cfg.PATCH_LIFETIME + 2) + self._loop_pairs_total + self.n)
             plan = GraphPlan(full_ii.contiguous(), full_jj.contiguous(), full_kk.contiguous(), n_patches_ub=ub_p, n_pairs_ub=ub_g,
                              n_frames=self.N, n_patch_ids=self.N * self.M)
+            self._watch_plan_bounds(plan, "global BA plan (active + inactive edges)")
             if _CHECK_MIRROR:
                 c = plan.counts.cpu().tolist()
                 assert c[0] <= ub_p and c[1] <= ub_g, ("global plan bounds", c, ub_p, ub_g)
@@ -807,6 +815,30 @@ class DPVO:
                   full_target, full_weight, 1e-4, full_ii, full_jj, full_kk, t0, self.n, M=self.M, iterations=2,
                   eff_impl=True, plan=plan, f0=0 if plan is not None else None, n_frames=self.n if plan is not None else None)
         self.ran_global_ba[self.n] = True
+
+    def _watch_plan_bounds(self, plan, what):
+        """A plan sized by BOUNDS from the host's bookkeeping instead of a read-back (long-range edges active, global BA): the kernels
+        read the exact group counts on the device and launches / workspaces are sized by the bounds, so a violated bound would
+        truncate silently.  The exact counts therefore follow the plan to the host through a non-blocking copy, and
+        _check_plan_bounds() -- at the start of the following frames, in flush-free code, and in terminate() -- RAISES if a bound
+        did not hold (this was only asserted under DPVO_CHECK_MIRROR)."""
+        if plan is None or plan.exact:
+            return
+        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        host.copy_(plan.counts[:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._bound_watch.append((host, ev, plan.n_patches_host, plan.n_pairs_host, what, self.n))
+
+    def _check_plan_bounds(self, wait=False):
+        while self._bound_watch and (wait or len(self._bound_watch) > 4 or self._bound_watch[0][1].query()):
+            host, ev, ub_p, ub_g, what, n = self._bound_watch.pop(0)
+            ev.synchronize()
+            c = host.tolist()
+            if c[0] > ub_p or c[1] > ub_g:
+                raise L.DPVOHipError(f"dpvo_amd: {what} built at frame {n} has {c[0]} patches / {c[1]} frame pairs, more than the "
+                                     f"bounds {ub_p} / {ub_g} its launches and workspaces were sized for: results since then are invalid "
+                                     "(set DPVO_PLAN_SYNC=1 for exact plans and report this)")
 
     def plan_sync(self):
         """order the main stream behind a plan that was built on the side stream (no-op otherwise)"""
@@ -841,6 +873,8 @@ class DPVO:
             if edges_ready is None or ub_p is None:       # (an exact plan reads its counts back: nothing to overlap)
                 self.plan_sync()
                 self._plan = build()
+                if window is None and ub_p is not None:
+                    self._watch_plan_bounds(self._plan, "plan of the active edges while long-range edges are active")
             else:
                 if self._plan_stream is None:
                     self._plan_stream = torch.cuda.Stream(device=self.device, priority=-1)   # small kernels beside a chip-filling one
@@ -952,7 +986,7 @@ class DPVO:
         image_u8 = image.contiguous()
         H, W = image_u8.shape[-2:]
         hip_enc = self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM'
-        side = pre_rng = fs_deferred = None
+        side = pre_rng = fs_deferred = rng_done = None
         appended = False
         if hip_enc and self.overlap_encoders:
             if self._enc_stream is None:
@@ -987,6 +1021,13 @@ class DPVO:
                            torch.rand(1, self.M, 1, 1, dtype=torch.float32, device=self.device))
                 for t_ in pre_rng:
                     t_.record_stream(main_stream)        # allocated on the side stream, read on the main one
+                # ... and PRODUCED on the side stream: the main stream's first reader (frame-state part 1: coordinate / depth
+                # patches) must wait for the draws themselves, not only for the allocator (record_stream orders nothing).  The
+                # one-call path joins the encoders late (ev_enc, in front of part 2), so this event is what orders part 1
+                if self._rng_done_ev is None:
+                    self._rng_done_ev = [torch.cuda.Event(), torch.cuda.Event()]
+                rng_done = self._rng_done_ev[self.counter & 1]
+                rng_done.record(side)
             self._stamp(1)
             img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
             img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
@@ -1110,6 +1151,8 @@ class DPVO:
                     # the frame call waits for the encoders itself, behind its plan and reprojection (dpvo_frame_update_t.ev_enc)
                     self._fs_join = (enc_done.cuda_event if side is not None else None,
                                      slot_spec.data_ptr() if slot is not slot_spec else None)
+                    if rng_done is not None:        # (normally long complete: the draws are the side stream's first work)
+                        main_stream.wait_event(rng_done)
                     if side is None and slot is not slot_spec:
                         join()
                 es.appended_frame(n + 1, self.M, self.cfg.PATCH_LIFETIME, total)

@@ -20,7 +20,7 @@ def stream(n, ht, wd, device, seed=1234):
 
 
 def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, overlap=True, buffer=256, ref_over=None, ours=True,
-               delta_scale=1.0, **cfg_over):
+               delta_scale=1.0, delta_bias=None, **cfg_over):
     """(ours, theirs, cfg): both trackers on default.yaml + overrides, the same random-init VONet weights (strict load on both sides),
     the initialisation probe accepted on both (random weights)"""
     from oracle import ref_pipeline as RP
@@ -41,6 +41,12 @@ def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, over
         with torch.no_grad():
             net.update.d[1].weight.mul_(delta_scale)
             net.update.d[1].bias.mul_(delta_scale)
+    if delta_bias is not None:
+        # a COHERENT flow on top: every edge is asked to move by the same (bx, by) pixels per update -- an image-wide shift, i.e. what a
+        # rotating camera produces, which bundle adjustment can explain with the poses (well conditioned), where per-edge noise of a
+        # static scene can only be absorbed by depths and scale (ill conditioned: the run-away of tools/ref_parity.py scenario A)
+        with torch.no_grad():
+            net.update.d[1].bias.add_(torch.tensor(delta_bias, dtype=net.update.d[1].bias.dtype))
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}        # (DPVO casts the encoder towers to f16 in place)
     if ours:
         ours = DPVO(cfg, net, ht=ht, wd=wd, device=dev, defer_keyframe=defer, overlap_encoders=overlap)
@@ -57,6 +63,105 @@ def build_pair(dev, ht=480, wd=640, M=96, seed=1234, feed=True, defer=True, over
         return v
     theirs.motionmag = mm
     return ours, theirs, cfg
+
+
+class BACapture:
+    """Records every fastba.BA call of the reference's tracker (dpvo.py:323-324,353-354): the arguments as they are when the call
+    starts (clones of poses / patches: cuda_ba updates them in place) and the poses / patches it leaves.  One hook on the staged
+    reference module serves every tracker; `on` switches the recording."""
+
+    def __init__(self, RP):
+        self.calls, self.on = [], False
+        fb = RP.load().dpvo_module.fastba
+        if not hasattr(fb, "_real_BA"):
+            fb._real_BA = fb.BA
+        self.real = real = fb._real_BA
+        cap = self
+
+        def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M, iterations, eff_impl=False):
+            if not cap.on:
+                return real(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M=M, iterations=iterations, eff_impl=eff_impl)
+            c = dict(poses=poses.data.clone(), patches=patches.clone(), intrinsics=intrinsics.clone(), target=target.clone(),
+                     weight=weight.clone(), lmbda=lmbda.clone(), ii=ii.clone(), jj=jj.clone(), kk=kk.clone(), t0=int(t0), t1=int(t1), M=M,
+                     iterations=iterations, eff_impl=eff_impl)
+            out = real(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M=M, iterations=iterations, eff_impl=eff_impl)
+            c["poses_after"], c["patches_after"] = poses.data.clone(), patches.clone()
+            cap.calls.append(c)
+            return out
+        fb.BA = BA
+
+    def rerun(self, c, ba=None, target=None, weight=None):
+        """the captured call once more on fresh copies of its inputs -> (poses, patches) it leaves.  ba: another implementation with
+        the reference's signature (dpvo_amd.fastba.BA); target / weight: another update operator's outputs for the same edges"""
+        p, pt = c["poses"].clone(), c["patches"].clone()
+        tg = c["target"] if target is None else target.reshape(c["target"].shape).to(c["target"].dtype)
+        wg = c["weight"] if weight is None else weight.reshape(c["weight"].shape).to(c["weight"].dtype)
+        (ba or self.real)(p, pt, c["intrinsics"].clone(), tg.clone(), wg.clone(), c["lmbda"].clone(), c["ii"], c["jj"], c["kk"], c["t0"], c["t1"],
+                          M=c["M"], iterations=c["iterations"], eff_impl=c["eff_impl"])
+        return p, pt
+
+
+def pose_dist(a, b, n):
+    """max |component difference| of the first n poses of two [1,N,7] / [N,7] tensors (quaternion sign fixed)"""
+    a, b = a.reshape(-1, 7)[:n].double(), b.reshape(-1, 7)[:n].double()
+    sgn = torch.sign((a[:, 3:] * b[:, 3:]).sum(-1, keepdim=True))
+    sgn[sgn == 0] = 1
+    return float(torch.cat([a[:, :3] - b[:, :3], a[:, 3:] * sgn - b[:, 3:]], -1).abs().max()) if n > 0 else 0.0
+
+
+def our_outputs_at_ba_time(c, ours, e_inac_before):
+    """OUR update operator's targets / weights for exactly the edge list of the captured call `c`.  When the frame is over the
+    keyframe step has split that list -- kept edges stay (same order) in the active store, removed ones sit at the tail of the
+    inactive store (dpvo.py:305-310; a global BA's list starts with the inactive store as it was, dpvo.py:315-319) -- so the arrays
+    are put together again through the (patch, target frame) keys, and every piece is checked against the captured list.
+    None when that does not work out (a keyframe was dropped in between: frames and patches were renumbered)."""
+    key = lambda kk, jj: kk.long() * 65536 + jj.long()
+    pg = ours.pg
+    kc = key(c["kk"], c["jj"])
+    off = e_inac_before if c["eff_impl"] else 0
+    if off > kc.numel() or pg.kk_inac.numel() < off or (off and not torch.equal(kc[:off], key(pg.kk_inac[:off], pg.jj_inac[:off]))):
+        return None
+    ka, kept = kc[off:], key(pg.kk, pg.jj)
+    n_rem = ka.numel() - kept.numel()
+    if n_rem < 0 or pg.kk_inac.numel() < e_inac_before + n_rem:
+        return None
+    sl = slice(e_inac_before, e_inac_before + n_rem)
+    mask = torch.isin(ka, kept)
+    if int(mask.sum()) != kept.numel() or not torch.equal(ka[mask], kept) or not torch.equal(ka[~mask], key(pg.kk_inac[sl], pg.jj_inac[sl])):
+        return None
+    out = []
+    for act, inac in ((pg.target[0], pg.target_inac[0]), (pg.weight[0], pg.weight_inac[0])):
+        v = torch.empty(ka.numel(), 2, dtype=act.dtype, device=act.device)
+        v[mask] = act
+        v[~mask] = inac[sl]
+        out.append(torch.cat((inac[:off], v)) if off else v)
+    return out
+
+
+def attribute(cap, c, ours, e_inac_before=0, reruns=3):
+    """One captured BA call of the reference, taken apart:
+      yard     -- the reference against ITSELF: the same call re-run `reruns` times on the same inputs (float atomics in
+                  ba_cuda.cu:335-373 are its only source of difference); what conditioning makes of summation-order noise, on this box
+      ba_dist  -- OUR bundle adjustment (dpvo_amd.fastba.BA through the C ABI) on the reference's inputs against the reference's result
+      attr_dist-- the reference's OWN bundle adjustment on OUR update operator's targets / weights against OUR poses of this frame:
+                  small means the whole pose difference of the frame is what the reference's solver makes of the (separately asserted)
+                  differences of the update operator's outputs -- i.e. conditioning, not an implementation"""
+    from dpvo_amd import fastba as our_fastba
+    n = c["t1"]
+    out = {"yard": 0.0, "eff_impl": bool(c["eff_impl"]), "E_ba": int(c["ii"].numel())}
+    for _ in range(reruns):
+        p, _pt = cap.rerun(c)
+        out["yard"] = max(out["yard"], pose_dist(p, c["poses_after"], n))
+    p, pt = cap.rerun(c, ba=our_fastba.BA)
+    out["ba_dist"] = pose_dist(p, c["poses_after"], n)
+    m = n * c["M"]
+    da, db = pt.reshape(-1, 3, 3, 3)[:m, 2, 1, 1], c["patches_after"].reshape(-1, 3, 3, 3)[:m, 2, 1, 1]
+    out["ba_depth_rel_p90"] = float(torch.quantile(((da - db).abs() / db.abs().clamp_min(1e-2))[::max(1, m // 4096)], 0.9)) if m else 0.0
+    tw = our_outputs_at_ba_time(c, ours, e_inac_before)
+    if tw is not None and ours.n == n:
+        p, _pt = cap.rerun(c, target=tw[0], weight=tw[1])
+        out["attr_dist"] = pose_dist(p, ours.pg.poses_, n)
+    return out
 
 
 def compare(so, sr):
@@ -94,7 +199,7 @@ def sync_from_reference(ours, theirs):
 
 
 def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, flush_each=True, log=None, stop_on_mismatch=True,
-                 teacher=False):
+                 teacher=False, attribute_ba=False):
     """frame t: same seed -> our call (+ flush) -> [our encoder outputs handed to the reference] -> same seed -> reference call ->
     compare.  Returns the list of per-frame distance records (each carries `t` and the two keyframe decisions).
     teacher: after the comparison our tracker's float state is overwritten with the reference's (sync_from_reference), so that every
@@ -104,6 +209,7 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
     from oracle import ref_pipeline as RP
     recs = []
     n_img = frames.shape[0]
+    cap = BACapture(RP) if attribute_ba else None
     for t in range(n_frames):
         img = frames[t % n_img]
         n_o, n_r = ours.n, theirs.n
@@ -120,7 +226,13 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
             RP.feed(theirs, ours._fmap1_cl[(ours.n - 1) % ours.mem], ours._imap_full)
         nf = len(theirs._flows)
         torch.manual_seed(seed0 + t)
+        if cap is not None:
+            cap.calls.clear()
+            cap.on = True
+            e_inac_before = int(theirs.pg.ii_inac.numel())
         RP.call(theirs, float(t), img, intr)
+        if cap is not None:
+            cap.on = False
         if not flush_each:
             continue
         d = compare(RP.snapshot(ours), RP.snapshot(theirs))
@@ -142,6 +254,13 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
             if hasattr(theirs.pg, "target") and theirs.pg.target.shape[1] == d["E"]:      # (set by the first update, dpvo.py:342-343)
                 d["target_max"] = float((ours.pg.target[0] - theirs.pg.target[0]).abs().max())
                 d["weight_max"] = float((ours.pg.weight[0] - theirs.pg.weight[0]).abs().max())
+        if cap is not None and cap.calls and d["int_equal"] and hasattr(ours, "flush"):
+            # (the frame's LAST bundle adjustment: the only one, except in the initialisation frame's 12 updates.  With a keyframe
+            #  dropped behind it the poses have moved down a slot and the edges were renumbered: the BA-on-the-same-inputs figures do
+            #  not care, the attribution against our final poses is not available for that frame)
+            with torch.no_grad():
+                d.update(attribute(cap, cap.calls[-1], ours, e_inac_before=e_inac_before))
+            cap.calls.clear()
         recs.append(d)
         if log is not None:
             log(d)
@@ -168,7 +287,16 @@ def summarise(recs):
                    weight_max=max((r.get("weight_max", 0.0) for r in ok), default=None),
                    pose_max_first28=max((r["pose_max"] for r in ok if r["t"] < 28), default=None),
                    pose_max_first24=max((r["pose_max"] for r in ok if r["t"] < 24), default=None),
+                   pose_max_first16=max((r["pose_max"] for r in ok if r["t"] < 16), default=None),
+                   above_1e3=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}"), r.get("yard"), r.get("ba_dist"),
+                               r.get("attr_dist")] for r in ok if r["pose_max"] > 1e-3 * max(1.0, r["extent"])],
                    pose_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}")] for r in ok[::4]])
+    at = [r for r in ok if "ba_dist" in r]
+    if at:
+        out.update(yard_max=max(r["yard"] for r in at), ba_dist_max=max(r["ba_dist"] for r in at),
+                   attr_dist_max=max((r["attr_dist"] for r in at if "attr_dist" in r), default=None),
+                   ba_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['yard']:.3g}"), float(f"{r['ba_dist']:.3g}"),
+                               float(f"{r.get('attr_dist', float('nan')):.3g}")] for r in at[::4]])
     dec = [(r["t"], r["drop_ours"], r["drop_ref"], r["flow_ours"], r["flow_ref"]) for r in recs if r.get("flow_ref") is not None]
     out["decisions"] = len(dec)
     out["drops_ref"] = sum(1 for x in dec if x[2])

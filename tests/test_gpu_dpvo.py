@@ -202,6 +202,34 @@ def test_unforced_keyframe_decision_on_the_device(dev):
     assert torch.equal(a.pg.poses_[:a.n], b.pg.poses_[:b.n]) and torch.equal(a.pg.patches_[:a.n], b.pg.patches_[:b.n])
 
 
+def test_side_stream_draws_are_ordered_before_their_reader(dev):
+    """with overlapped encoders the frame's three random draws (net.py:132-133, dpvo.py:427) are PRODUCED on the
+    side stream, and the one-call frame path joins the encoders only in front of frame-state part 2 -- part 1 (coordinate / depth
+    patches) reads the draws earlier.  With image_ready=None the side stream waits for the caller's stream position, so the draws and
+    part 1 become runnable at the same moment: a stall on the main stream in front of the call (torch.cuda._sleep) makes that the
+    normal case.  The patch coordinates the frame stored must be the draws of this frame's seed."""
+    slam, _ = _run_unforced(dev, -1.0, n_frames=20, overlap_encoders=True, defer_keyframe=True)
+    assert slam._fu is not None, "the one-call frame path must be the one exercised"
+    ht, wd, seed = 96, 128, 11
+    g = torch.Generator().manual_seed(seed)
+    tex = torch.rand(3, ht + 64, wd + 64, generator=g)
+    tex = torch.nn.functional.avg_pool2d(tex[None], 5, 1, 2)[0]
+    tex = (255 * (tex - tex.min()) / (tex.max() - tex.min())).to(torch.uint8)
+    intr = torch.tensor([100.0, 100.0, wd / 2, ht / 2], device=dev)
+    for t in range(20, 32):
+        img = tex[:, (2 * t) % 64:(2 * t) % 64 + ht, (3 * t) % 64:(3 * t) % 64 + wd].contiguous().to(dev)
+        torch.cuda.synchronize()
+        torch.cuda._sleep(30_000_000)                       # ~15-20 ms in front of everything this call enqueues
+        torch.manual_seed(900 + t)
+        slam(float(t), img, intr)                           # image_ready=None: the side stream waits behind the stall
+        slam.flush()
+        torch.manual_seed(900 + t)
+        xs = torch.randint(1, wd // 4 - 1, size=[1, slam.M], device=dev)
+        ys = torch.randint(1, ht // 4 - 1, size=[1, slam.M], device=dev)
+        p = slam.pg.patches_[slam.n - 1]
+        assert torch.equal(p[:, 0, 1, 1], xs[0].float()) and torch.equal(p[:, 1, 1, 1], ys[0].float()), t
+
+
 def test_keyframe_step_decision_unit(dev):
     """dpvo_keyframe_step's decision from synthetic flow sums, incl. the empty-direction case: mean of an empty tensor is NaN in the
     reference (dpvo.py:264) and `NaN / 2 < thresh` is False -> keep"""

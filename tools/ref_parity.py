@@ -28,7 +28,10 @@ def main():
     ap.add_argument("--wd", type=int, default=640)
     ap.add_argument("--patches", type=int, default=96)
     ap.add_argument("--delta-scale", type=float, default=1.0, help="scale of the flow head's last layer (see tests/ref_harness.py)")
+    ap.add_argument("--delta-bias", default=None, help="bx,by: a coherent image-wide shift added to the flow head's bias (tests/ref_harness.py)")
+    ap.add_argument("--attribute", action="store_true", help="teacher-forced scenarios: take every frame's BA apart (yard / ba_dist / attr_dist)")
     args = ap.parse_args()
+    args.delta_bias = None if args.delta_bias is None else tuple(float(v) for v in args.delta_bias.split(","))
     from oracle import ref_pipeline as RP
     if not RP.available():
         print(json.dumps({"error": "oracle/_ref is not built (run oracle/build_ref.py where /root/reference exists)"}))
@@ -52,7 +55,7 @@ def main():
 
     if "A" in todo or "A2" in todo or "C" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, KEYFRAME_THRESH=-1.0)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, KEYFRAME_THRESH=-1.0)
         recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=True)
         flows_A = [r["flow_ref"] for r in recs if r.get("flow_ref") is not None]
         final_A = RP.snapshot(ours)
@@ -67,7 +70,7 @@ def main():
         del ours, theirs
     if "A2" in todo and final_A is not None:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, KEYFRAME_THRESH=-1.0)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, KEYFRAME_THRESH=-1.0)
         with torch.no_grad():
             for t in range(args.frames):
                 torch.manual_seed(5000 + t)
@@ -80,14 +83,14 @@ def main():
         del ours, theirs
     if "B" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, feed=False, KEYFRAME_THRESH=-1.0)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, feed=False, KEYFRAME_THRESH=-1.0)
         recs = H.run_lockstep(ours, theirs, frames, min(args.frames, 40), intr, feed=False)
         emit("B", "as A but fully end-to-end: the reference runs its own encoders (torch / MIOpen convolutions under autocast)", recs, None, t0)
         del ours, theirs
     if "C" in todo and flows_A:
         t0 = time.perf_counter()
         thr = float(np.median(flows_A))
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, KEYFRAME_THRESH=thr)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, KEYFRAME_THRESH=thr)
         recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=True, stop_on_mismatch=True)
         emit("C", f"unscripted keyframe decisions: KEYFRAME_THRESH = {thr:.4f} (median flow of scenario A), no override on either side", recs,
              {"thresh": thr, "decisions_list": [(r["t"], int(r["drop_ours"]), int(r["drop_ref"]), r["flow_ours"], r["flow_ref"])
@@ -95,28 +98,28 @@ def main():
         del ours, theirs
     if "T" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, KEYFRAME_THRESH=-1.0)
-        recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=True, teacher=True)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, KEYFRAME_THRESH=-1.0)
+        recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=True, teacher=True, attribute_ba=args.attribute)
         emit("T", "as A with teacher forcing: after every frame our float state (poses, depths, hidden state) is reset to the reference's, "
                   "so each frame measures one frame's divergence at the bench configuration", recs, None, t0)
         del ours, theirs
     if "TB" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, feed=False, KEYFRAME_THRESH=-1.0)
-        recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=False, teacher=True)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, feed=False, KEYFRAME_THRESH=-1.0)
+        recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=False, teacher=True, attribute_ba=args.attribute)
         emit("TB", "as T, fully end-to-end (the reference runs its own torch / MIOpen encoders)", recs, None, t0)
         del ours, theirs
     if "TD" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, buffer=512, LOOP_CLOSURE=True, KEYFRAME_THRESH=-1.0)
-        recs = H.run_lockstep(ours, theirs, frames, max(args.frames, 85), intr, feed=True, teacher=True)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, buffer=512, LOOP_CLOSURE=True, KEYFRAME_THRESH=-1.0)
+        recs = H.run_lockstep(ours, theirs, frames, max(args.frames, 85), intr, feed=True, teacher=True, attribute_ba=args.attribute)
         emit("TD", "LOOP_CLOSURE=True (BASELINE config 5) with teacher forcing: loop edges + global BA on both sides", recs,
              {"global_ba_runs_ours": int(ours.ran_global_ba.sum()), "global_ba_runs_ref": int(theirs.ran_global_ba.sum()),
               "inactive_edges": int(theirs.pg.ii_inac.numel())}, t0)
         del ours, theirs
     if "F" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, KEYFRAME_THRESH=-1.0, ref_over={"MIXED_PRECISION": False})
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, KEYFRAME_THRESH=-1.0, ref_over={"MIXED_PRECISION": False})
         recs = H.run_lockstep(ours, theirs, frames, args.frames, intr, feed=True)
         emit("F", "as A, but the reference runs with MIXED_PRECISION=False: f32 feature buffers, so its correlation kernel accumulates in "
                   "f32 like ours (the update operator stays under autocast, dpvo.py:332) -- isolates the reference's f16 correlation arithmetic",
@@ -124,14 +127,14 @@ def main():
         del ours, theirs
     if "R" in todo:
         t0 = time.perf_counter()
-        ra, rb, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, feed=False, ours=False, KEYFRAME_THRESH=-1.0)
+        ra, rb, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, feed=False, ours=False, KEYFRAME_THRESH=-1.0)
         recs = H.run_lockstep(ra, rb, frames, args.frames, intr, feed=False)
         emit("R", "the reference against ITSELF (two instances, same inputs): its own run-to-run distance (float atomics in BA, "
                   "ba_cuda.cu:335-373) amplified by the same dynamics -- the yard-stick for A", recs, None, t0)
         del ra, rb
     if "D" in todo:
         t0 = time.perf_counter()
-        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, buffer=512, LOOP_CLOSURE=True, KEYFRAME_THRESH=-1.0)
+        ours, theirs, cfg = H.build_pair(dev, ht, wd, M, delta_scale=args.delta_scale, delta_bias=args.delta_bias, buffer=512, LOOP_CLOSURE=True, KEYFRAME_THRESH=-1.0)
         recs = H.run_lockstep(ours, theirs, frames, max(args.frames, 85), intr, feed=True)
         emit("D", "LOOP_CLOSURE=True (BASELINE config 5): loop edges + global BA on both sides", recs,
              {"global_ba_runs_ours": int(ours.ran_global_ba.sum()), "global_ba_runs_ref": int(theirs.ran_global_ba.sum()),
