@@ -12,7 +12,7 @@
 //   SA  segmented softmax-sum of f by g over the kk groups (softagg_kernel of update.hip)   (blocks.py:41-43)
 //   K5  y[ku] -> agg_kk.h -> net += ; f | g of agg_ij                                        (net.py:87-88)
 //   SA  ... over the (ii, jj) groups
-//   K7  y[pu] -> agg_ij.h -> net += ; 2 x (LayerNorm, x + gate(x) * res(x)); heads           (net.py:88-92)
+//   K7  y[pu] -> agg_ij.h -> net += ; 2 x (LayerNorm, x + gate(x) * res(x)); heads           (net.py:88-92)   [update_fused_k7.hip]
 //
 // (h is applied to the gathered group row of every edge instead of once per group: same bits per row, 2 x 14 GFLOP of
 // extra MFMA work, two launches and two dependent small GEMMs less.)
@@ -324,197 +324,6 @@ __global__ __launch_bounds__(256, OCC) void k_chain(const P2 p) {
   }
 }
 
-// K7 -----------------------------------------------------------------------------------------------
-struct P7 {
-  Lin h;
-  Lin gate[2], res0[2], res2[2];
-  const float *ln_g[2], *ln_b[2];
-  const _Float16 *d_w, *d_b, *w_w, *w_b;            // heads: [2,384], [2] f16, feature order
-  const _Float16* y; const int32_t* rows;           // y[pu]
-  const float* img;
-  const float* coords; int pp;                      // optional: target = coords[..., P/2, P/2] + delta
-  float *net_out, *delta, *weight, *target;
-  int64_t E;
-  int skew;                                          // soft start: workgroup b waits (b & 3) * skew / 4 microseconds (0: off)
-};
-
-template <int RT, int DW>
-__global__ __launch_bounds__(256, 1) void k7_gru_heads(const P7 p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = Geo<RT>::R;
-  const Lane l = lane_of();
-  const int64_t tile = blockIdx.x, row0 = tile * R;
-  char* act = smem;
-  float* red = reinterpret_cast<float*>(smem + 2 * Geo<RT>::ACT_BYTES);
-  char* al = act + l.n * PITCH + 16 * l.h;
-  char* gl = al + Geo<RT>::ACT_BYTES;               // second tile: where every lane parks its own gate values (no barriers)
-
-  soft_start(p.skew);
-  FU_T(4, 0);
-  f16v x[RT][3];
-  h8 wf[DW][3];
-  Bias bias;
-  const h8* wp = w_base(p.h.w, KS384, l);
-  w_preload<DW>(wf, wp);
-  bias_load(bias, p.h.b, l);
-  float* lnp = reinterpret_cast<float*>(smem + 2 * Geo<RT>::ACT_BYTES + Geo<RT>::RED_BYTES);      // [gamma | beta] x 2, f32
-  for (int i = l.tid; i < D; i += 256) {
-    lnp[i] = p.ln_g[0][i]; lnp[D + i] = p.ln_b[0][i]; lnp[2 * D + i] = p.ln_g[1][i]; lnp[3 * D + i] = p.ln_b[1][i];
-  }
-  gather_rows<RT>(act, p.y, p.rows, row0, p.E, l.tid, reinterpret_cast<int32_t*>(red));
-  float* ip = img_ptr<RT>(const_cast<float*>(p.img), tile, l);
-  {
-    Img<RT> im;
-    img_load<RT>(im, ip);       // lands under the first GEMM
-    __syncthreads();
-    FU_T(4, 1);
-    acc_init<RT>(x, bias);
-    gemm_lds<RT, KS384, DW, PITCH>(x, wf, wp, al);
-    FU_T(4, 2);
-    round_f16<RT>(x);
-    img_add<RT>(x, im);
-  }
-  // From here on the f32 state is in registers only between the last GEMM of a gated residual and the next LayerNorm: it is
-  // written back to its (lane-private) image slot after each LayerNorm and re-read, one row tile at a time, for the residual add.
-  // Holding it across the three GEMMs (144 + 144 accumulator registers > the 256-entry accumulation file) made the compiler spill
-  // ~120 registers, and every scratch reload is an exposed memory round trip with one wave per SIMD.
-#pragma unroll
-  for (int G = 0; G < 2; ++G) {
-    layernorm_tile_lds<RT>(x, red, lnp + 2 * D * G, l);
-    FU_T(4, 3 + 5 * G);
-    wp = w_base(p.gate[G].w, KS384, l);
-    w_preload<DW>(wf, wp);
-    bias_load(bias, p.gate[G].b, l);
-    img_store<RT>(x, ip);
-    to_lds<RT, 0>(x, al, l);
-    __syncthreads();
-    FU_T(4, 4 + 5 * G);
-    f16v acc[RT][3];
-    // gate = sigmoid(Linear(x))
-    acc_init<RT>(acc, bias);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp, al);
-    FU_T(4, 5 + 5 * G);
-    wp = w_base(p.res0[G].w, KS384, l);
-    w_preload<DW>(wf, wp);
-    bias_load(bias, p.res0[G].b, l);
-    to_lds<RT, 2>(acc, gl, l);
-    // res = Linear(relu(Linear(x)))
-    acc_init<RT>(acc, bias);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp, al);
-    FU_T(4, 6 + 5 * G);
-    wp = w_base(p.res2[G].w, KS384, l);
-    w_preload<DW>(wf, wp);
-    bias_load(bias, p.res2[G].b, l);
-    __syncthreads();
-    to_lds<RT, 1>(acc, al, l);
-    __syncthreads();
-    acc_init<RT>(acc, bias);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp, al);
-    FU_T(4, 7 + 5 * G);
-    // x = x(image) + gate * res   (half * half -> half, blocks.py:28-29)
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      f4 m[3][4];
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m[t][j] = *reinterpret_cast<const f4*>(ip + r * IMG_RT_STRIDE + (t * 4 + j) * 256);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const h8 gt = *reinterpret_cast<const h8*>(gl + r * 32 * PITCH + ((3 * l.w + t) * 2 + c) * 32);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int k = 8 * c + i;
-            const _Float16 rv = (_Float16)acc[r][t][k];
-            x[r][t][k] = m[t][k >> 2][k & 3] + (float)(_Float16)(gt[i] * rv);
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  FU_T(4, 13);
-  // ---- hidden state out (feature order) and the heads
-  // d and w (two Linear(384, 2) on relu(net), net.py:92) as ONE MFMA chain per wave over its own 96 features: the B fragment of
-  // k-step (3w + t) * 2 + c is exactly what to_lds would write for this lane -- relu(x[r][t][8c .. 8c + 7]) in f16 -- so it is
-  // built in registers; the A fragment carries the four head rows (rows 4..31 zero) in the same P order.  18 MFMAs instead of
-  // ~1 000 VALU instructions (relu, two conversions and four FMAs per value); f16 operands, f32 accumulate as before.
-  f16v hacc[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hacc[r][k] = 0.f;
-  {
-    const int m = l.n;                              // A row = output row of the 32-row MFMA tile: d0, d1, w0, w1, then zeros
-    const _Float16* wrow = m == 0 ? p.d_w : m == 1 ? p.d_w + D : m == 2 ? p.w_w : p.w_w + D;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int base = 96 * l.w + 32 * t + 16 * c + 4 * l.h;      // features base + {0..3} and base + 8 + {0..3}
-        h8 af = (h8)(_Float16)0;
-        if (m < 4) {
-          const h4 lo = *reinterpret_cast<const h4*>(wrow + base), hi = *reinterpret_cast<const h4*>(wrow + base + 8);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { af[i] = lo[i]; af[4 + i] = hi[i]; }
-        }
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          h8 bfr;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { const float v = x[r][t][8 * c + i]; bfr[i] = (_Float16)(v > 0.f ? v : 0.f); }
-          hacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfr, hacc[r], 0, 0, 0);
-        }
-      }
-  }
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int f = 96 * l.w + 32 * t + 8 * j + 4 * l.h;
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const int64_t g = row0 + r * 32 + l.n;
-        f4 o4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o4[q] = x[r][t][4 * j + q];
-        if (g < p.E) *reinterpret_cast<f4*>(p.net_out + g * D + f) = o4;
-      }
-    }
-  __syncthreads();                                  // (the LayerNorm partials in `red` are dead)
-  // D[row m][col n]: lane (n, h) holds rows (j & 3) + 8 (j >> 2) + 4 h in register j -> the four head sums of tile row n sit
-  // in registers 0..3 of the lanes with h == 0, both K halves already added
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-    if (l.h == 0) *reinterpret_cast<f4*>(red + ((r * 32 + l.n) * 4 + l.w) * 4) = (f4){hacc[r][0], hacc[r][1], hacc[r][2], hacc[r][3]};
-  __syncthreads();
-  if (l.tid < R) {
-    const int64_t g = row0 + l.tid;
-    if (g < p.E) {
-      f4 s = *reinterpret_cast<const f4*>(red + (l.tid * 4 + 0) * 4);
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const f4 q = *reinterpret_cast<const f4*>(red + (l.tid * 4 + w) * 4);
-#pragma unroll
-        for (int o = 0; o < 4; ++o) s[o] += q[o];
-      }
-      const float d0 = (float)(_Float16)(s[0] + (float)p.d_b[0]), d1 = (float)(_Float16)(s[1] + (float)p.d_b[1]);
-      const _Float16 h0 = (_Float16)(s[2] + (float)p.w_b[0]), h1 = (_Float16)(s[3] + (float)p.w_b[1]);
-      p.delta[2 * g + 0] = d0;
-      p.delta[2 * g + 1] = d1;
-      p.weight[2 * g + 0] = (float)(_Float16)sigm((float)h0);
-      p.weight[2 * g + 1] = (float)(_Float16)sigm((float)h1);
-      if (p.target) {
-        p.target[2 * g + 0] = p.coords[(g * 2 + 0) * p.pp + p.pp / 2] + d0;
-        p.target[2 * g + 1] = p.coords[(g * 2 + 1) * p.pp + p.pp / 2] + d1;
-      }
-    }
-  }
-  FU_T(4, 14);
-}
-
-
 // ------------------------------------------------------------------------------------------------ weight packing
 // W [384, ldw] f16 row-major (torch Linear layout), K columns used (zero beyond k_valid) -> fragment image.
 // chained = 0: k-slot (s, h, i) holds input column 16 s + 8 h + i (inputs in feature order: corr);
@@ -767,7 +576,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
     a.d_w = (const _Float16*)p->d_w; a.d_b = (const _Float16*)p->d_b; a.w_w = (const _Float16*)p->w_w; a.w_b = (const _Float16*)p->w_b;
     a.y = y; a.rows = plan + PL.pu; a.img = img; a.coords = coords; a.pp = P * P;
     a.net_out = net_out; a.delta = delta; a.weight = weight; a.target = target; a.E = E; a.skew = skew;
-    FU(launch<k7_gru_heads<RT, FU_DW7>>(tiles, Geo<RT>::LDS_BYTES + Geo<RT>::ACT_BYTES + 4 * D * 4, a, st));
+    FU(dpvo_fu::launch_k7(tiles, a, stream));          // (update_fused_k7.hip: 96-row tiles, one workgroup per CU)
   }
 #undef FU
   return DPVO_OK;
@@ -777,6 +586,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
 #ifdef FU_TRACE
 extern "C" int dpvo_debug_fu_trace_buffer(void* buf) {      // trace builds only (make TRACE=1): device buffer of 8*1024*4*16 u64, or NULL
   unsigned long long* p = (unsigned long long*)buf;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fu_trace), &p, sizeof(p));
+  const int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fu_trace), &p, sizeof(p));
+  return rc ? rc : dpvo_fu::k7_set_trace(p);
 }
 #endif

@@ -7,7 +7,7 @@
 
 #ifdef FU_TRACE
 // per-workgroup timeline (100 MHz wall clock) for tools/fu_trace.py: [kernel id 8][block 1024][wave 4][stamp 16]
-__device__ unsigned long long* g_fu_trace = nullptr;
+static __device__ unsigned long long* g_fu_trace = nullptr;      // (one per translation unit: the setters below fill each)
 #define FU_T(k, i)                                                                                                       \
   do {                                                                                                                   \
     if (g_fu_trace && (threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                      \
@@ -17,8 +17,31 @@ __device__ unsigned long long* g_fu_trace = nullptr;
 #define FU_T(k, i) do {} while (0)
 #endif
 
+// ---- shared between the translation units of the update operator (update_fused.hip, update_fused_k7.hip): external linkage, hidden
+namespace dpvo_fu {
+struct Lin { const void* w; const _Float16* b; };     // packed image + f16 bias
+struct P7 {
+  Lin h;
+  Lin gate[2], res0[2], res2[2];
+  const float *ln_g[2], *ln_b[2];
+  const _Float16 *d_w, *d_b, *w_w, *w_b;            // heads: [2,384], [2] f16, feature order
+  const _Float16* y; const int32_t* rows;           // y[pu]
+  const float* img;
+  const float* coords; int pp;                      // optional: target = coords[..., P/2, P/2] + delta
+  float *net_out, *delta, *weight, *target;
+  int64_t E;
+  int skew;                                          // soft start: workgroup b waits (b & 3) * skew / 4 microseconds (0: off)
+};
+// K7 lives in its own translation unit: it parks 144 state registers in AGPRs and therefore needs its MFMAs in the VGPR form
+// (-amdgpu-mfma-vgpr-form is a per-compilation switch; K1 spills under it).  tiles x 256 threads, dynamic LDS set inside.
+__attribute__((visibility("hidden"))) int launch_k7(int64_t tiles, const P7& p, void* stream);
+__attribute__((visibility("hidden"))) int k7_set_trace(unsigned long long* buf);      // trace builds only
+}  // namespace dpvo_fu
+
 namespace {
 namespace fu {
+using ::dpvo_fu::Lin;
+using ::dpvo_fu::P7;
 
 // Soft start (dpvo_update_fused_start_skew): the workgroups of a launch begin in four groups, skew / 4 microseconds apart,
 // instead of all 256 CUs entering the same phase in the same microsecond.  A candidate of the autotune only: it costs a few
@@ -417,8 +440,6 @@ __device__ __forceinline__ void scatter_rows(const char* act, _Float16* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ parameter blocks
-struct Lin { const void* w; const _Float16* b; };     // packed image + f16 bias
-
 // The kernel is a non-type template parameter, so every kernel instantiation owns its flag word: bit d = the dynamic-LDS
 // attribute has been set on device d (relaxed atomics: setting it twice is harmless, it only must not be skipped).
 template <auto KERN, typename P>

@@ -138,22 +138,44 @@ def our_outputs_at_ba_time(c, ours, e_inac_before):
     return out
 
 
-def attribute(cap, c, ours, e_inac_before=0, reruns=3):
+def exact_ba(c, target=None, weight=None):
+    """the captured call solved by the f64 CPU oracle (oracle/dpvo_oracle.c: cuda_ba restated, ba_cuda.cu:232-582) -> poses [N,7] as a
+    tensor: what both f32 implementations approximate"""
+    import oracle
+    n = c["t1"]
+    cpu = lambda t: t.detach().double().cpu().numpy()
+    tg = c["target"] if target is None else target
+    wg = c["weight"] if weight is None else weight
+    P = c["patches"].shape[-1]
+    poses, _patches, _info, _rt = oracle.ba(cpu(c["poses"]).reshape(-1, 7), cpu(c["patches"]).reshape(-1, 3, P, P), cpu(c["intrinsics"]).reshape(-1, 4),
+                                           cpu(tg).reshape(-1, 2), cpu(wg).reshape(-1, 2), float(c["lmbda"].reshape(-1)[0]),
+                                           c["ii"].cpu().numpy(), c["jj"].cpu().numpy(), c["kk"].cpu().numpy(), c["t0"], n,
+                                           iterations=c["iterations"], dtype=np.float64)
+    return torch.from_numpy(poses)
+
+
+def attribute(cap, c, ours, e_inac_before=0, reruns=3, pose_max=0.0, lim0=float("inf")):
     """One captured BA call of the reference, taken apart:
-      yard     -- the reference against ITSELF: the same call re-run `reruns` times on the same inputs (float atomics in
-                  ba_cuda.cu:335-373 are its only source of difference); what conditioning makes of summation-order noise, on this box
-      ba_dist  -- OUR bundle adjustment (dpvo_amd.fastba.BA through the C ABI) on the reference's inputs against the reference's result
-      attr_dist-- the reference's OWN bundle adjustment on OUR update operator's targets / weights against OUR poses of this frame:
-                  small means the whole pose difference of the frame is what the reference's solver makes of the (separately asserted)
-                  differences of the update operator's outputs -- i.e. conditioning, not an implementation"""
+      yard      -- the reference against ITSELF: the same call re-run `reruns` times on the same inputs (float atomics in
+                   ba_cuda.cu:335-373 are its only source of difference): the one-step reference-vs-reference spread on this box
+      ba_dist   -- OUR bundle adjustment (dpvo_amd.fastba.BA through the C ABI) on the reference's inputs against the reference's result
+      attr_dist -- the reference's OWN bundle adjustment on OUR update operator's targets / weights against OUR poses of this frame:
+                   small means the whole pose difference of the frame is what the reference's solver makes of the (separately asserted)
+                   differences of the update operator's outputs -- i.e. conditioning, not an implementation
+    and, only on frames where one of the distances exceeds the plain tolerance lim0 (the f64 solve is slow):
+      ref_exact / ours_exact -- the reference's result and ours (same inputs) against the f64 solution of the same two Gauss-Newton
+                   steps: how far each f32 implementation is from what both approximate.  Re-running the reference only samples the
+                   ORDER noise of its atomics; an implementation with a different summation tree differs from it by more than that
+                   wherever the step is ill-conditioned, and the honest question there is which of the two is closer to the exact step
+      attr_exact -- the f64 solve on OUR targets / weights against OUR poses of this frame"""
     from dpvo_amd import fastba as our_fastba
     n = c["t1"]
     out = {"yard": 0.0, "eff_impl": bool(c["eff_impl"]), "E_ba": int(c["ii"].numel())}
     for _ in range(reruns):
         p, _pt = cap.rerun(c)
         out["yard"] = max(out["yard"], pose_dist(p, c["poses_after"], n))
-    p, pt = cap.rerun(c, ba=our_fastba.BA)
-    out["ba_dist"] = pose_dist(p, c["poses_after"], n)
+    p_ours, pt = cap.rerun(c, ba=our_fastba.BA)
+    out["ba_dist"] = pose_dist(p_ours, c["poses_after"], n)
     m = n * c["M"]
     da, db = pt.reshape(-1, 3, 3, 3)[:m, 2, 1, 1], c["patches_after"].reshape(-1, 3, 3, 3)[:m, 2, 1, 1]
     out["ba_depth_rel_p90"] = float(torch.quantile(((da - db).abs() / db.abs().clamp_min(1e-2))[::max(1, m // 4096)], 0.9)) if m else 0.0
@@ -161,6 +183,14 @@ def attribute(cap, c, ours, e_inac_before=0, reruns=3):
     if tw is not None and ours.n == n:
         p, _pt = cap.rerun(c, target=tw[0], weight=tw[1])
         out["attr_dist"] = pose_dist(p, ours.pg.poses_, n)
+    else:
+        tw = None
+    if max(out["ba_dist"], pose_max) > lim0 and int(c["ii"].numel()) <= 120000:
+        ex = exact_ba(c)
+        out["ref_exact"] = pose_dist(c["poses_after"].cpu(), ex, n)
+        out["ours_exact"] = pose_dist(p_ours.cpu(), ex, n)
+        if tw is not None and pose_max > lim0:
+            out["attr_exact"] = pose_dist(exact_ba(c, tw[0], tw[1]), ours.pg.poses_.cpu(), n)
     return out
 
 
@@ -259,7 +289,8 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
             #  dropped behind it the poses have moved down a slot and the edges were renumbered: the BA-on-the-same-inputs figures do
             #  not care, the attribution against our final poses is not available for that frame)
             with torch.no_grad():
-                d.update(attribute(cap, cap.calls[-1], ours, e_inac_before=e_inac_before))
+                d.update(attribute(cap, cap.calls[-1], ours, e_inac_before=e_inac_before, pose_max=d.get("pose_max", 0.0),
+                                   lim0=1e-3 * max(1.0, d.get("extent", 0.0))))
             cap.calls.clear()
         recs.append(d)
         if log is not None:
@@ -288,8 +319,9 @@ def summarise(recs):
                    pose_max_first28=max((r["pose_max"] for r in ok if r["t"] < 28), default=None),
                    pose_max_first24=max((r["pose_max"] for r in ok if r["t"] < 24), default=None),
                    pose_max_first16=max((r["pose_max"] for r in ok if r["t"] < 16), default=None),
-                   above_1e3=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}"), r.get("yard"), r.get("ba_dist"),
-                               r.get("attr_dist")] for r in ok if r["pose_max"] > 1e-3 * max(1.0, r["extent"])],
+                   above_1e3=[{k: (float(f"{r[k]:.3g}") if isinstance(r.get(k), float) else r.get(k)) for k in
+                               ("t", "pose_max", "extent", "yard", "ba_dist", "attr_dist", "ref_exact", "ours_exact", "attr_exact", "eff_impl")}
+                              for r in ok if max(r["pose_max"], r.get("ba_dist", 0.0)) > 1e-3 * max(1.0, r["extent"])],
                    pose_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}")] for r in ok[::4]])
     at = [r for r in ok if "ba_dist" in r]
     if at:
