@@ -205,6 +205,21 @@ def loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed, warm=70, ti
         return {"frames_per_sec": None, "error": repr(e)[:300]}
 
 
+def launcher_command(gpus, argv, port=None, environ=None):
+    """(command, environment) with which `python bench.py --gpus N` re-executes itself: N ranks of ONE node under torch.distributed.run,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve), dmabuf IPC for RCCL.  Every rank then places itself from
+    LOCAL_RANK alone (multiseq.place_rank: device LOCAL_RANK over "nccl" when the node shows >= N devices, a disjoint slice of the host
+    cores) -- no HIP_VISIBLE_DEVICES games: all devices stay visible to every rank, which is what RCCL's xGMI peer access wants.
+    A function of its arguments (tests/test_multiseq.py builds the 8-GPU command without a GPU)."""
+    if port is None:
+        import socket
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ if environ is None else environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,12 +237,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) on this node
-        import socket
         import subprocess
-        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd, env = launcher_command(args.gpus, sys.argv[1:])
         sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))

@@ -121,3 +121,29 @@ def test_nccl_init_failure_is_loud_not_a_gloo_fallback():
     msg = q.get(timeout=120)
     p.join(60)
     assert "could not be initialised" in msg and "Not falling back to gloo" in msg, msg
+
+
+def test_bench_launcher_and_placement_for_eight_gpus():
+    """VERDICT r4 #6 (no 8-GPU node to run on): what `python bench.py --gpus 8` WOULD execute, built without a GPU -- the
+    torch.distributed.run command line the driver's contract names, and the placement every one of the 8 ranks derives from its
+    LOCAL_RANK on a node that shows 8 devices and 256 host cores: backend "nccl" (= RCCL), 8 distinct devices,
+    8 disjoint contiguous slices of 32 cores."""
+    import sys
+    import bench
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd, env = bench.launcher_command(8, argv, port=29517, environ={"PATH": "/usr/bin"})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == argv, "the ranks must see the launcher's own arguments"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["MASTER_ADDR"] == "127.0.0.1" and env["PATH"] == "/usr/bin"
+    assert "HIP_VISIBLE_DEVICES" not in env and "ROCR_VISIBLE_DEVICES" not in env, "every rank keeps all 8 devices visible (xGMI peers)"
+    placed = [multiseq.place_rank(r, 8, 8, allowed=range(256)) for r in range(8)]
+    assert [b for b, _, _ in placed] == ["nccl"] * 8
+    assert sorted(d for _, d, _ in placed) == list(range(8))
+    cores = [c for _, _, c in placed]
+    assert all(len(c) == 32 and c == list(range(c[0], c[0] + 32)) for c in cores)
+    assert len(set().union(*map(set, cores))) == 256
+    # ... and on the 1-GPU boxes of this pool the same command degrades loudly-labelled: gloo, shared device (smoke mode)
+    assert [multiseq.place_rank(r, 8, 1, allowed=range(16))[:2] for r in range(8)] == [("gloo", 0)] * 8
