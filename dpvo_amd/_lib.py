@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPVO_HIP_LIB") or os.path.join(_HERE, "libdpvo_hip.so")      # (override: development builds)
 
 F16, F32 = 0, 1
-ABI_VERSION = 5         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
+ABI_VERSION = 6         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
 
 # every symbol include/dpvo_hip.h declares (tests/test_capi.py checks the .so exports all of them)
 SYMBOLS = [
@@ -27,7 +27,7 @@ SYMBOLS = [
     "dpvo_softagg",
     "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_default_tiling",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
-    "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_retract", "dpvo_gba_solve_workspace_bytes", "dpvo_gba_solve",
+    "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_relinearize", "dpvo_gba_retract", "dpvo_gba_solve_workspace_bytes", "dpvo_gba_solve",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
     "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state", "dpvo_frame_state_part", "dpvo_keyframe_step", "dpvo_frame_update", "dpvo_debug_stamp",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_encoders_forward_hold", "dpvo_pool4_nhwc",

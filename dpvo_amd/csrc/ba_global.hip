@@ -155,14 +155,38 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
     if (jx >= 0 && jx < N) tgt_list[tgt_off[jx] + atomicAdd(&tgt_cnt[jx], 1)] = g;
   }
   __syncthreads();
-  for (int p = t; p < N; p += 1024) {                              // (the claims above land in any order: sort every short list)
-    int32_t* L = tgt_list + tgt_off[p];
-    const int n = tgt_off[p + 1] - tgt_off[p];
-    for (int a = 1; a < n; ++a) {
-      const int v = L[a];
-      int b = a - 1;
-      while (b >= 0 && L[b] > v) { L[b + 1] = L[b]; --b; }
-      L[b + 1] = v;
+  // The claims above land in any order: every list is put in ascending pair order.  A WAVE per list (round 4: a thread per list ran
+  // an insertion sort, O(n^2) dependent memory steps for the ~30-100 pairs that target a pose -- 90 of the kernel's 93 us at N = 100,
+  // profiles/r05_lc_timeline.txt): the pair indices are distinct, so an entry's place is the number of smaller entries; lane l counts
+  // it for entries l, l + 64, ... against the whole list (read through the cache), then the wave writes the list back in place.
+  {
+    const int lane = t & 63, wv = t >> 6;
+    for (int p = wv; p < N; p += 16) {
+      int32_t* L = tgt_list + tgt_off[p];
+      const int n = tgt_off[p + 1] - tgt_off[p];
+      constexpr int kMaxPer = 8;                                   // lists up to 512 entries in registers; longer ones: the serial sort
+      if (n <= 64 * kMaxPer) {
+        int v[kMaxPer], r[kMaxPer];
+#pragma unroll
+        for (int a = 0; a < kMaxPer; ++a) { v[a] = lane + 64 * a < n ? L[lane + 64 * a] : 0x7fffffff; r[a] = 0; }
+        for (int b = 0; b < n; ++b) {
+          const int x = L[b];                                      // (uniform address: one broadcast load)
+#pragma unroll
+          for (int a = 0; a < kMaxPer; ++a) r[a] += x < v[a];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // every lane has read the whole list before anyone overwrites it
+#pragma unroll
+        for (int a = 0; a < kMaxPer; ++a)
+          if (lane + 64 * a < n) L[r[a]] = v[a];
+      } else if (lane == 0) {
+        for (int a = 1; a < n; ++a) {
+          const int v = L[a];
+          int b = a - 1;
+          while (b >= 0 && L[b] > v) { L[b + 1] = L[b]; --b; }
+          L[b + 1] = v;
+        }
+      }
     }
   }
 }
@@ -429,11 +453,11 @@ extern "C" size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n
 
 // Linearise: fills S [6N,6N] (B - E Q E^T, WITHOUT the damping) and y [6N] (v - E Q u); both must be zeroed by the
 // caller.  Frames f0 .. f0+n_frames-1 are the source frames that own patches (n_frames*M Q/u slots).
-extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
-                                  const float* weight, float lmbda, const int64_t* ii, const int64_t* jj,
-                                  const int64_t* kk, const int32_t* plan, int64_t n_patches_h, int64_t n_pairs_h,
-                                  int64_t E, int P, int M, int f0, int n_frames, int t0, int t1, float* S, float* y,
-                                  void* ws, size_t ws_bytes, void* stream) {
+static int gba_linearize_impl(const float* poses, const float* patches, const float* intrinsics, const float* target,
+                              const float* weight, float lmbda, const int64_t* ii, const int64_t* jj,
+                              const int64_t* kk, const int32_t* plan, int64_t n_patches_h, int64_t n_pairs_h,
+                              int64_t E, int P, int M, int f0, int n_frames, int t0, int t1, float* S, float* y,
+                              void* ws, size_t ws_bytes, void* stream, bool reuse_index) {
   if (E <= 0 || P <= 0 || M <= 0 || t1 <= t0 || n_frames <= 0 || n_pairs_h <= 0 || n_patches_h <= 0) return DPVO_E_INVALID;
   if (!poses || !patches || !intrinsics || !target || !weight || !ii || !jj || !kk || !plan || !S || !y || !ws) return DPVO_E_INVALID;
   GbaWs L;
@@ -461,8 +485,10 @@ extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, cons
   const unsigned pair_grid = (unsigned)(n_pairs_h < 65535 ? n_pairs_h : 65535);
   hipLaunchKernelGGL(ba_pair_kernel, dim3(pair_grid), dim3(128), 0, st, poses, patches, intrinsics, target, weight, kk,
                      plan + PL.perm_p, plan + PL.pair_off, plan + PL.pair_ij, n_pairs, pairbuf, edgebuf, P);
-  hipLaunchKernelGGL(gba_index_kernel, dim3(1), dim3(1024), 0, st, plan + PL.pair_ij, n_pairs, f0, n_frames, t0, N, run_lo,
-                     tgt_off, tgt_cnt, tgt_list);
+  // (the index structures depend on the plan and the frame ranges only: a later Gauss-Newton iteration of the same call reuses them)
+  if (!reuse_index)
+    hipLaunchKernelGGL(gba_index_kernel, dim3(1), dim3(1024), 0, st, plan + PL.pair_ij, n_pairs, f0, n_frames, t0, N, run_lo,
+                       tgt_off, tgt_cnt, tgt_list);
   hipLaunchKernelGGL(gba_scatter_kernel, dim3(pair_grid), dim3(128), 0, st, kk, plan + PL.perm_p, plan + PL.pair_off, n_pairs,
                      edgebuf, Ecol, M);
   hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
@@ -471,6 +497,24 @@ extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, cons
                      pairbuf, Q, U, Ecol, Eself, M, f0, n_frames, t0, N, S, y);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
+}
+
+extern "C" int dpvo_gba_linearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
+                                  const float* weight, float lmbda, const int64_t* ii, const int64_t* jj,
+                                  const int64_t* kk, const int32_t* plan, int64_t n_patches_h, int64_t n_pairs_h,
+                                  int64_t E, int P, int M, int f0, int n_frames, int t0, int t1, float* S, float* y,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  return gba_linearize_impl(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, plan, n_patches_h, n_pairs_h, E, P, M, f0,
+                            n_frames, t0, t1, S, y, ws, ws_bytes, stream, false);
+}
+
+extern "C" int dpvo_gba_relinearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
+                                    const float* weight, float lmbda, const int64_t* ii, const int64_t* jj,
+                                    const int64_t* kk, const int32_t* plan, int64_t n_patches_h, int64_t n_pairs_h,
+                                    int64_t E, int P, int M, int f0, int n_frames, int t0, int t1, float* S, float* y,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  return gba_linearize_impl(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, plan, n_patches_h, n_pairs_h, E, P, M, f0,
+                            n_frames, t0, t1, S, y, ws, ws_bytes, stream, true);
 }
 
 extern "C" int dpvo_gba_retract(float* poses, float* patches, const int32_t* plan, int64_t n_patches_h, int64_t n_pairs_h,

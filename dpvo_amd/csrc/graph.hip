@@ -37,12 +37,35 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ ii, const int64_t* 
 // by_hi: a group is a run of equal high parts (patch), else of equal whole keys (frame pair).
 //   PATCH: ku[e] = group, kx[g] = patch id, off[g] = first position, ix/jx[e] = previous / next edge of the patch
 //   PAIR : pu[e] = group, pair_ij[g] = (i, j), off[g]
+// Round 5: part (a) used to re-scan the sorted keys -- E / 2048 loads per thread on average, E / 1024 in the last workgroup: fine for
+// the tracker's 47 k active edges (18 us), quadratic for the global BA's 330 k active + inactive ones (2 x 95 us per global-BA frame,
+// profiles/r05_lc_timeline.txt).  group_count_kernel leaves the number of group starts of every 1024-position block; a workgroup
+// now adds up the counts of the blocks before it (<= E / 1024 values).  Same ranks, same outputs.
+template <typename K, bool PATCH>
+__global__ __launch_bounds__(1024) void group_count_kernel(const K* __restrict__ keys, int32_t* __restrict__ blk_count, int64_t E, int shift) {
+  __shared__ int32_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t p = (int64_t)blockIdx.x * 1024 + t;
+  auto gkey = [&](int64_t q) -> K { return PATCH ? (K)(keys[q] >> shift) : keys[q]; };
+  const bool start = p < E && (p == 0 || gkey(p) != gkey(p - 1));
+  const unsigned long long bal = __ballot(start);
+  if (lane == 0) wsum[wv] = __popcll(bal);
+  __syncthreads();
+  if (t == 0) {
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c += wsum[i];
+    blk_count[blockIdx.x] = c;
+  }
+}
+
 template <typename K, bool PATCH>
 __global__ __launch_bounds__(1024) void group_kernel(const K* __restrict__ keys, const int32_t* __restrict__ perm,
                                                      int32_t* __restrict__ gu, int32_t* __restrict__ gx,
                                                      int32_t* __restrict__ off, int32_t* __restrict__ ix,
                                                      int32_t* __restrict__ jx, int32_t* __restrict__ count,
-                                                     int32_t* __restrict__ zero2, int64_t E, int shift) {
+                                                     int32_t* __restrict__ zero2, int64_t E, int shift,
+                                                     const int32_t* __restrict__ blk_count) {
   __shared__ int32_t wsum[16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   auto gkey = [&](int64_t p) -> K { return PATCH ? (K)(keys[p] >> shift) : keys[p]; };
@@ -50,7 +73,7 @@ __global__ __launch_bounds__(1024) void group_kernel(const K* __restrict__ keys,
   // (a) group starts before this workgroup's first position
   const int64_t first = (int64_t)blockIdx.x * 1024;
   int32_t c = 0;
-  for (int64_t p = t; p < first; p += 1024) c += is_start(p);
+  for (int b = t; b < (int)blockIdx.x; b += 1024) c += blk_count[b];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if (lane == 0) wsum[wv] = c;
@@ -371,6 +394,7 @@ int build_plan(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t 
   K* keys_b = (K*)(w + L.keys_b);
   K* keys_out = (K*)(w + L.keys_out);
   int32_t* vals_in = (int32_t*)(w + L.vals_in);
+  int32_t* blk_count = (int32_t*)(w + L.win);      // (the window path's tile histograms: unused here, >= 24 KB per 1024 edges)
   hipLaunchKernelGGL(make_keys_kernel<K>, dim3(grid_for(E)), dim3(256), 0, st, ii, jj, kk, (which & 1) ? keys_a : (K*)nullptr,
                      (which & 2) ? keys_b : (K*)nullptr, vals_in, E, shift, plan + P.flow);
   if (which & 1) {      // sort by (kk, jj, edge)
@@ -378,18 +402,20 @@ int build_plan(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t 
     hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_a, keys_out, vals_in, plan + P.perm_k, (size_t)E, 0,
                                              (unsigned)bits_a, st);
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((group_count_kernel<K, true>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const K*)keys_out, blk_count, E, shift);
     hipLaunchKernelGGL((group_kernel<K, true>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const K*)keys_out, plan + P.perm_k, plan + P.ku,
                        plan + P.kx, plan + P.patch_off, plan + P.ix, plan + P.jx, plan + P.counts + 0, plan + P.counts + 2, E,
-                       shift);
+                       shift, blk_count);
   }
   if (which & 2) {      // sort by (ii, jj, edge)
     size_t tb = L.temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_b, keys_out, vals_in, plan + P.perm_p, (size_t)E, 0,
                                              (unsigned)bits_b, st);
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((group_count_kernel<K, false>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const K*)keys_out, blk_count, E, shift);
     hipLaunchKernelGGL((group_kernel<K, false>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const K*)keys_out, plan + P.perm_p, plan + P.pu,
                        plan + P.pair_ij, plan + P.pair_off, (int32_t*)nullptr, (int32_t*)nullptr, plan + P.counts + 1,
-                       (int32_t*)nullptr, E, shift);
+                       (int32_t*)nullptr, E, shift, blk_count);
   }
   return 0;
 }
@@ -575,8 +601,11 @@ extern "C" int dpvo_neighbors(const int64_t* kk, const int64_t* jj, int64_t* ix,
   size_t tb = L.temp_bytes;
   hipError_t e = rocprim::radix_sort_pairs((void*)(w + L.temp), tb, keys_a, keys_out, vals_in, perm, (size_t)E, 0, 64, st);
   if (e != hipSuccess) return (int)e;
+  int32_t* blk_count = (int32_t*)(w + L.win);
+  hipLaunchKernelGGL((group_count_kernel<uint64_t, true>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const uint64_t*)keys_out, blk_count, E,
+                     kKeyShift);
   hipLaunchKernelGGL((group_kernel<uint64_t, true>), dim3((unsigned)cdiv64(E, 1024)), dim3(1024), 0, st, (const uint64_t*)keys_out, perm, ku, kx, off,
-                     ix32, jx32, off + E + 1 /*count scratch*/, (int32_t*)nullptr, E, kKeyShift);
+                     ix32, jx32, off + E + 1 /*count scratch*/, (int32_t*)nullptr, E, kKeyShift, blk_count);
   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(E)), dim3(256), 0, st, ix32, jx32, ix, jx, E);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;

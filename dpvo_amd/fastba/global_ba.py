@@ -61,9 +61,10 @@ def global_BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0,
     if _PROFILE is not None:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-    for _ in range(iterations):
+    for it in range(iterations):
         sy[:n6 * n6 + n6].zero_()
-        L.check(L.lib().dpvo_gba_linearize(
+        # (iterations after the first reuse the index structures the first one left in `ws`: dpvo_gba_relinearize)
+        L.check((L.lib().dpvo_gba_linearize if it == 0 else L.lib().dpvo_gba_relinearize)(
             L.ptr(poses), L.ptr(patches), L.ptr(intrinsics), L.ptr(target), L.ptr(weight), L.f32(lm), L.ptr(ii), L.ptr(jj),
             L.ptr(kk), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(E), L.i32(P), L.i32(M),
             L.i32(f0), L.i32(n_frames), L.i32(t0), L.i32(t1), L.ptr(S), L.ptr(y), L.ptr(ws), ctypes.c_size_t(ws.numel()),

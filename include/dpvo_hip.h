@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version: bumped on ANY change of a signature, a struct layout or the exported set (round 3 changed all three without a
  * bump: ADVICE r3).  The Python binding refuses a library whose version differs from the one it was written against. */
-#define DPVO_ABI_VERSION 5
+#define DPVO_ABI_VERSION 6
 int dpvo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -487,6 +487,14 @@ int dpvo_gba_linearize(const float* poses, const float* patches, const float* in
                        const float* weight, float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk,
                        const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E, int P, int M, int f0,
                        int n_frames, int t0, int t1, float* S, float* y, void* ws, size_t ws_bytes, void* stream);
+/* The second and later Gauss-Newton iterations of ONE global BA (ba_cuda.cu:538-550 loops `iterations` times over the same edge
+ * lists): identical to dpvo_gba_linearize, but the index structures that depend only on (plan, f0, n_frames, t0, t1) -- left in `ws` by
+ * the dpvo_gba_linearize call of the first iteration -- are reused instead of rebuilt.  Same arguments, same `ws`, nothing else may
+ * have written `ws` in between except dpvo_gba_retract. */
+int dpvo_gba_relinearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
+                         const float* weight, float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk,
+                         const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E, int P, int M, int f0,
+                         int n_frames, int t0, int t1, float* S, float* y, void* ws, size_t ws_bytes, void* stream);
 int dpvo_gba_retract(float* poses, float* patches, const int32_t* plan, int64_t n_patches, int64_t n_pairs, int64_t E,
                      int P, int M, int f0, int n_frames, int t0, int t1, const float* dX, void* ws, size_t ws_bytes,
                      void* stream);
