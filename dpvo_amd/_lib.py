@@ -34,12 +34,11 @@ SYMBOLS = [
 ]
 
 
-# libdpvo_hip_cmp.so (include/dpvo_hip_cmp.h): the two COMPARATOR implementations of the update operator -- test and measurement
-# partners of the product's seven-launch operator, never loaded by the tracker (cmp_lib() below)
+# libdpvo_hip_cmp.so (include/dpvo_hip_cmp.h): the COMPARATOR implementation of the update operator (launch by launch, update.hip) -- test and measurement
+# partner of the product's seven-launch operator, never loaded by the tracker (cmp_lib() below)
 CMP_LIB_PATH = os.environ.get("DPVO_HIP_CMP_LIB") or os.path.join(_HERE, "libdpvo_hip_cmp.so")
 CMP_SYMBOLS = ["dpvo_linear", "dpvo_layernorm", "dpvo_gather_add", "dpvo_heads", "dpvo_heads_target",
-               "dpvo_update_workspace_bytes", "dpvo_update_forward", "dpvo_update_pm_workspace_bytes", "dpvo_update_forward_pm",
-               "dpvo_update_pm2_workspace_bytes", "dpvo_update_forward_pm2"]
+               "dpvo_update_workspace_bytes", "dpvo_update_forward"]
 
 
 class DPVOHipError(RuntimeError):
@@ -138,7 +137,7 @@ def cmp_lib():
         for s in CMP_SYMBOLS:
             if not hasattr(C, s):
                 raise DPVOHipError(f"libdpvo_hip_cmp.so does not export {s}")
-        for s in ("dpvo_update_workspace_bytes", "dpvo_update_pm_workspace_bytes", "dpvo_update_pm2_workspace_bytes"):
+        for s in ("dpvo_update_workspace_bytes",):
             getattr(C, s).restype = ctypes.c_size_t
         _cmp = C
     return _cmp

@@ -518,7 +518,7 @@ class DPVO:
         # LOOP_CLOSURE (BASELINE config 5): the one-call path serves every frame whose update() takes the LOCAL BA branch of
         # dpvo.py:351-354 -- no long-range edge active (reported by the previous keyframe step) and none appended for this frame
         return (_FRAME_CALL and self.is_initialized and self._lr_active == 0 and self._hip_enc is not None and self.P == 3
-                and self._gmap_cl.dtype == torch.float16 and net_mod.FUSED_DEFAULT and not net_mod.PM_DEFAULT
+                and self._gmap_cl.dtype == torch.float16 and net_mod.FUSED_DEFAULT
                 and n - self.cfg.KEYFRAME_INDEX >= 1 and self.cfg.OPTIMIZATION_WINDOW <= 20)
 
     def _frame_update_buffers(self):

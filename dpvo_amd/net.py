@@ -1,7 +1,7 @@
 """VONet / Update / Patchifier with the reference's module tree and state-dict keys (dpvo/net.py:27-184,
 dpvo/blocks.py:15-48), so `dpvo.pth` loads unchanged, and `Update.forward` executed by the seven HIP kernels of
-dpvo_amd/csrc/update_fused.hip instead of ~60 torch / torch_scatter launches.  (`fused=False` / `fused="pm"` / `composite=False`
-run the comparator implementations of libdpvo_hip_cmp.so instead: tests and measurements only.)
+dpvo_amd/csrc/update_fused.hip instead of ~60 torch / torch_scatter launches.  (`fused=False` / `composite=False`
+run the launch-by-launch comparator implementation of libdpvo_hip_cmp.so instead: tests and measurements only.)
 
 The nn.Module parameters are the single source of truth; `Update.pack()` derives the f16 operand images the
 kernels consume (what autocast's per-call weight casts produce in the reference, dpvo/dpvo.py:332).
@@ -27,10 +27,9 @@ PROFILE = None
 
 EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 # Update.forward runs the seven row-tile kernels of update_fused.hip -- always the same path, whatever the box (round 2's
-# run-time autotune between five candidates is gone: a tracker's output must not depend on a timing).  The comparators
-# (launch-by-launch update.hip, patch-major) are reached explicitly: fused=False / fused="pm" or the two environment switches.
+# run-time autotune between five candidates is gone: a tracker's output must not depend on a timing).  The comparator
+# (launch-by-launch update.hip) is reached explicitly: fused=False or DPVO_UPDATE_FUSED=0.
 FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
-PM_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_PM", "0")))      # patch-major (4 launches): opt-in, see DESIGN.md 3.4
 
 
 # ------------------------------------------------------------------------------------------ kernels' Python face
@@ -282,7 +281,7 @@ class Update(nn.Module):
         inp2 = inp2.contiguous()
 
         if net_rows is not None:
-            seven = composite and net2.dtype == torch.float32 and (fused is True or fused == "pm2" or (fused is None and FUSED_DEFAULT)) and not PM_DEFAULT
+            seven = composite and net2.dtype == torch.float32 and (fused is True or (fused is None and FUSED_DEFAULT))
             if not seven:
                 rows, n_kept, src = net_rows
                 tmp = workspace.get(E * DIM * 4, dev, "net_gather")[:E * DIM * 4].view(torch.float32).view(E, DIM)
@@ -316,39 +315,6 @@ class Update(nn.Module):
             maxg = max(plan.n_patches_host, plan.n_pairs_host)
             if fused is None:
                 fused = FUSED_DEFAULT
-            if fused == "pm2":
-                # four launches over 64-row tiles of whole patches packed by size (update_pm2.hip)
-                nbytes = L.cmp_lib().dpvo_update_pm2_workspace_bytes(L.i64(E), L.i64(maxg))
-                ws = workspace.get(nbytes, dev, "update_pm2")
-                st = workspace.get(4, dev, "update_pm2_status")
-                rows, n_kept = net_rows[:2] if net_rows is not None else (None, 0)
-                L.check(L.cmp_lib().dpvo_update_forward_pm2(
-                    ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(rows), L.i64(n_kept), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod),
-                    L.ptr(corr2), L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host),
-                    L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
-                    L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
-                    ctypes.c_size_t(ws.numel()), L.ptr(st), L.stream()), "dpvo_update_forward_pm2")
-                self.pm_status = st
-                return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
-            if fused == "pm" or (fused is True and PM_DEFAULT):
-                # four launches, edges in per-patch order (update_fused.hip, "patch-major"): needs an upper bound on the
-                # number of edges of one patch (DPVO passes 2 * PATCH_LIFETIME - 1; computed here, with a sync, otherwise)
-                ub = patch_edges_ub
-                if ub is None:
-                    ub = int(torch.bincount(kk.reshape(-1) - kk.min()).max().item())
-                if 0 < ub <= 96 and 2 * ((E + 95) // 96) + 48 <= 2048:
-                    nbytes = L.cmp_lib().dpvo_update_pm_workspace_bytes(L.i64(E), L.i64(maxg))
-                    ws = workspace.get(nbytes, dev, "update_pm")
-                    st = workspace.get(4, dev, "update_pm_status")
-                    L.check(L.cmp_lib().dpvo_update_forward_pm(
-                        ctypes.byref(P["_fparams"]), L.ptr(net2), L.ptr(inp2), L.ptr(inp_rows), L.i64(inp_mod), L.ptr(corr2),
-                        L.i64(corr2.stride(0)), L.ptr(plan.buf), L.i64(plan.n_patches_host), L.i64(plan.n_pairs_host), L.i64(ub),
-                        L.ptr(coords), L.i32(coords.shape[-1] if coords is not None else 0), L.ptr(x), L.ptr(delta),
-                        L.ptr(weight), L.ptr(target_out if coords is not None else None), L.i64(E), L.ptr(ws),
-                        ctypes.c_size_t(ws.numel()), L.ptr(st), L.stream()), "dpvo_update_forward_pm")
-                    self.pm_status = st          # device byte tensor: int32 1 = a patch exceeded the bound (checked by the caller)
-                    return x.view(1, E, DIM), (delta.view(1, E, 2), weight.view(1, E, 2), None)
-                fused = True                     # (does not fit the patch-major limits: the seven-launch path)
             if fused:
                 # seven launches of row-tile-resident kernels (update_fused.hip)
                 P["_fparams"].tiling, P["_fparams"].start_skew = self.tiling, self.start_skew

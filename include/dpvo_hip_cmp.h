@@ -1,11 +1,12 @@
-/* dpvo_hip_cmp.h -- C ABI of libdpvo_hip_cmp.so: the COMPARATOR implementations of the update operator.
+/* dpvo_hip_cmp.h -- C ABI of libdpvo_hip_cmp.so: the COMPARATOR implementation of the update operator.
  *
- * Not part of the product (libdpvo_hip.so / dpvo_hip.h), never loaded by the tracker: two further, independently written
- * implementations of Update.forward (reference dpvo/net.py:74-92) that the parity tests and the measurement tools run beside
+ * Not part of the product (libdpvo_hip.so / dpvo_hip.h), never loaded by the tracker: a second, independently written
+ * implementation of Update.forward (reference dpvo/net.py:74-92) that the parity tests and the measurement tools run beside
  * the product's seven-launch operator (dpvo_update_forward_fused, update_fused.hip):
  *   - update.hip     the launch-by-launch composite of generic pieces (round 1: 23 launches, 780 us), whose pieces double as
- *                    stand-alone checks of a Linear / LayerNorm / gather-add / heads against torch;
- *   - update_pm.hip  the patch-major four-launch variant (711 us).
+ *                    stand-alone checks of a Linear / LayerNorm / gather-add / heads against torch.
+ * (Rounds 2-4 also carried two patch-major cuts, update_pm.hip / update_pm2.hip: 700 / 602 us against 561 for the seven launches;
+ * measured, recorded in DESIGN.md 3.4 and profiles/README.md, removed in round 5.)
  * The library links against libdpvo_hip.so (dpvo_softagg, dpvo_plan_layout).  Conventions as in dpvo_hip.h. */
 #ifndef DPVO_HIP_CMP_H
 #define DPVO_HIP_CMP_H
@@ -73,28 +74,6 @@ int dpvo_update_forward(const dpvo_update_params_t* params, const float* net, co
                         int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan, int64_t n_patches_ub,
                         int64_t n_pairs_ub, const float* coords, int P, float* net_out, float* delta, float* weight,
                         float* target, int64_t E, void* ws, size_t ws_bytes, void* stream);
-
-/* The same operator in FOUR launches, edges taken in the plan's per-patch order (perm_k): with tiles made of whole patches the
- * neighbour rows of c1 / c2 (fastba.neighbors) are the adjacent rows of the tile and agg_kk is a segmented softmax inside it, so
- * the corr MLP, norm, c1, c2, agg_kk and the f | g of agg_ij run in ONE kernel with the f32 state in registers; then the agg_ij
- * softmax-sum, then agg_ij.h + gru + heads.  patch_edges_ub: the caller's upper bound on the number of edges of one patch
- * (2 * PATCH_LIFETIME - 1 in DPVO); must be <= 96, and E <= ~46 000 * 2, else DPVO_E_UNSUPPORTED (use dpvo_update_forward_fused).
- * status (device int32, may be NULL): set to 1 if a patch exceeded the bound (outputs then unspecified, memory safe). */
-size_t dpvo_update_pm_workspace_bytes(int64_t E, int64_t max_groups);
-int dpvo_update_forward_pm(const dpvo_update_fused_params_t* params, const float* net, const void* inp, const int64_t* inp_rows,
-                           int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan, int64_t n_patches_ub,
-                           int64_t n_pairs_ub, int64_t patch_edges_ub, const float* coords, int P, float* net_out, float* delta,
-                           float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, int32_t* status, void* stream);
-
-/* Four launches over 64-row tiles of whole patches packed by size, f32 state in registers from the first layer to the last
- * (update_pm2.hip).  Contract of dpvo_update_forward_fused_rows; status (device int32, may be NULL) = 1 if the graph does not fit
- * the packing (a patch with more than 64 edges, more than 4096 patches). */
-size_t dpvo_update_pm2_workspace_bytes(int64_t E, int64_t max_groups);
-int dpvo_update_forward_pm2(const dpvo_update_fused_params_t* params, const float* net, const int64_t* net_rows, int64_t n_kept,
-                            const void* inp, const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr,
-                            const int32_t* plan, int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,
-                            float* delta, float* weight, float* target, int64_t E, void* ws, size_t ws_bytes, int32_t* status,
-                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -110,7 +110,7 @@ def test_layernorm_softagg_heads(dev):
     H.assert_close(w.cpu().numpy(), rw.numpy(), 2e-3, 2e-3, "head w")
 
 
-@pytest.mark.parametrize("fused", ["pm2", "pm", "seven", False])
+@pytest.mark.parametrize("fused", ["seven", False])
 @pytest.mark.parametrize("first_call", [True, False])
 def test_update_forward_vs_oracle(oracle, dev, first_call, fused):
     from oracle import update_ref
@@ -203,7 +203,7 @@ def test_composite_entry_equals_launch_by_launch(dev, E_frames):
     assert torch.equal(res[1][3], coords[0, :, :, 1, 1] + res[1][1][0])
 
 
-@pytest.mark.parametrize("flavour", ["pm2", "pm", "seven"])
+@pytest.mark.parametrize("flavour", ["seven"])
 @pytest.mark.parametrize("E_frames", [14, 40])
 def test_fused_equals_launch_by_launch_to_rounding(dev, E_frames, flavour):
     """the row-tile-resident kernels (update_fused.hip) against the launch-by-launch kernels (update.hip): same rounding
@@ -285,12 +285,12 @@ def test_fused_tilings_are_bit_identical(dev, E_frames):
 _FULL_ORACLE = {}
 
 
-@pytest.mark.parametrize("path", ["default", "pm2", "pm", "launch_by_launch"])
+@pytest.mark.parametrize("path", ["default", "launch_by_launch"])
 def test_update_full_size_vs_oracle(oracle, dev, path):
     """E = 45 312 (BASELINE config 2): ONE full Update.forward against oracle/update_ref.py on every edge (f64 math with the
-    autocast rounding points; ~20 s of CPU, computed once for the three cases).  "default" is exactly what DPVO.update() and
+    autocast rounding points; ~20 s of CPU, computed once for the two cases).  "default" is exactly what DPVO.update() and
     bench.py run: no `fused` argument, the seven-launch kernels with the default tiling, called through the composite entry
-    with the imap table + row ids; "pm" / "launch_by_launch" are the two comparators.  Same stated tolerances as the small cases."""
+    with the imap table + row ids; "launch_by_launch" is the comparator.  Same stated tolerances as the small cases."""
     from oracle import update_ref
     from dpvo_amd import synthetic as S
     torch.manual_seed(1234)
@@ -312,11 +312,8 @@ def test_update_full_size_vs_oracle(oracle, dev, path):
     upd = upd.to(dev)
     args = (net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
     if path == "default":
-        assert N.FUSED_DEFAULT and not N.PM_DEFAULT and upd.tiling == -1 and upd.start_skew == 0
+        assert N.FUSED_DEFAULT and upd.tiling == -1 and upd.start_skew == 0
         out, (d, w, _) = upd(*args)
-    elif path in ("pm", "pm2"):
-        out, (d, w, _) = upd(*args, fused=path, patch_edges_ub=25)
-        assert int(upd.pm_status.view(torch.int32)[0].item()) == 0
     else:
         out, (d, w, _) = upd(*args, fused=False)
     # the MEASURED distance to the oracle on all 45 312 edges (printed with -s, committed in profiles/rNN_*_ref_parity.txt), then the

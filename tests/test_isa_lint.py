@@ -34,7 +34,7 @@ def test_library_is_free_of_the_faulting_form(name):
     lib = os.path.join(ROOT, "dpvo_amd", name)
     assert os.path.exists(lib), "build the library first (__graft_entry__.build())"
     n_pk, hits = isa_lint.lint(lib)
-    assert n_pk > 1000          # packed ops are in use (update operators), so the check is not vacuous
+    assert n_pk > (1000 if name == "libdpvo_hip.so" else 100)          # packed ops are in use (update operators), so the check is not vacuous
     assert hits == []
 
 

@@ -7,8 +7,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["DPVO_HIP_LIB"] = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_trace.so")
-if os.environ.get("MODE", "pm") == "pm2":
-    os.environ["DPVO_HIP_CMP_LIB"] = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_cmp_trace.so")
 sys.path.insert(0, ROOT)
 import ctypes          # noqa: E402
 
@@ -29,11 +27,6 @@ NAMES = {
                        "to_lds", "GEMM f", "f rows out", "GEMM g", "g rows out"]),
     3: ("K5 h + fg", ["gather issued", "gather landed", "-", "-", "GEMM h", "round + img add/store", "to_lds", "GEMM f",
                       "f rows out", "GEMM g", "g rows out"]),
-    5: ("KA (patch-major)", ["corr GEMM 896", "c2 + LN", "c5 + net/inp + LN", "c1, c2 (4 GEMMs)", "f, g of agg_kk", "softmax-sum",
-                             "h + expand", "f, g of agg_ij + rows out"]),
-    6: ("KB (patch-major)", ["y rows + GEMM h + img", "LN + gated residual 0", "LN + gated residual 1", "net out + heads"]),
-    7: ("KB gated residual 0, fine", ["LayerNorm", "W req + image store", "to_lds + barrier", "GEMM gate", "sigmoid + park", "GEMM res0",
-                                     "barrier + relu to_lds + barrier", "GEMM res2"]),
     4: ("K7 h + gru + heads", ["gather landed", "GEMM h", "img add + LN0", "W req + to_lds", "GEMM gate0", "park gate + GEMM res0",
                                "to_lds + GEMM res2", "gate*res + LN1", "W req + to_lds", "GEMM gate1", "park + GEMM res0",
                                "to_lds + GEMM res2", "gate*res", "net out + heads"]),
@@ -55,11 +48,8 @@ def main():
     imap = torch.randn(3456, 384, generator=g).half().to(dev)
     corr = torch.zeros(E, 896, dtype=torch.float16, device=dev); corr[:, :882] = torch.randn(E, 882, generator=g).half().to(dev)
     net = torch.randn(1, E, 384, generator=g).to(dev)
-    mode = os.environ.get("MODE", "pm")
-    N.PM_DEFAULT = False
-    run = lambda: upd(net, imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True,
-                      fused=(mode if mode in ("pm", "pm2") else True), patch_edges_ub=25)
-    setter = L.cmp_lib().dpvo_debug_pm2_trace_buffer if mode == "pm2" else L.lib().dpvo_debug_fu_trace_buffer
+    run = lambda: upd(net, imap[None], corr[None], None, ii, jj, kk, plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True, fused=True)
+    setter = L.lib().dpvo_debug_fu_trace_buffer
     for _ in range(3):
         run()
     buf = torch.zeros(8 * 1024 * 4 * 16, dtype=torch.int64, device=dev)
@@ -69,21 +59,9 @@ def main():
     torch.cuda.synchronize()
     setter(ctypes.c_void_p(0))
     t = buf.cpu().numpy().reshape(8, 1024, 4, 16).astype(np.int64)
-    kb = t[6, :256, 0]
-    ok = (kb[:, 13] > kb[:, 12]) & (kb[:, 4] > kb[:, 0])
-    if ok.any():
-        mhz = (kb[ok, 13] - kb[ok, 12]) / ((kb[ok, 4] - kb[ok, 0]) / 100.0)
-        print(f"shader clock during KB (s_memtime ticks per us of wall clock): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
-    t[6, :, :, 12:] = 0
     nb = (E + 95) // 96
-    if mode == "pm2":
-        NAMES[5] = ("KA2 (64-row tiles of whole patches)", ["corr GEMM 896", "c2 + LN", "c5 + net/inp + LN", "c1, c2 (4 GEMMs)", "f, g of agg_kk",
-                                                             "softmax-sum", "h + expand + img", "f, g of agg_ij + rows out"])
-        NAMES[6] = ("KB2", ["y rows + GEMM h + img", "LN + gated residual 0", "LN + gated residual 1", "net out + heads"])
-        NAMES.pop(7, None)
     for k, (name, phases) in NAMES.items():
-        if k >= 5:
-            nb = 256 if mode != "pm2" else 700         # (pm: the first 256 tiles; pm2: ~730 tiles, the trace holds 1024)
+        nb = min(nb, 1024)
         a = t[k, :nb]                                  # [block, wave, stamp]
         used = [i for i in range(16) if (a[:, 0, i] != 0).any()]
         if not used:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Update operator alone at the size it runs at in steady state (E = 45 312 after removal, 47 712 while update() runs):
-fused (update_fused.hip) vs launch-by-launch (update.hip), HIP-event time, TFLOP/s against the 2.5 PFLOP/s dense f16 peak,
+fused (update_fused.hip, WHICH=fused) vs launch-by-launch (update.hip, WHICH=unfused), HIP-event time, TFLOP/s against the 2.5 PFLOP/s dense f16 peak,
 and the difference of the two results.  Dev tool; run under `rocprofv3 --kernel-trace --stats` for the per-kernel table."""
 import os
 import sys
@@ -53,16 +53,14 @@ def main():
         kw = dict(plan=plan, inp_rows=kk, inp_mod=3456, corr_is_padded=True)
         flops = 2 * E * (896 * 384 + 16 * 384 * 384)
         out = {}
-        for name, fz in (("pm2", "pm2"), ("pm", "pm"), ("fused", True), ("unfused", False)):
+        for name, fz in (("fused", True), ("unfused", False)):
             if which not in ("both", name):
                 continue
-            N.PM_DEFAULT = False
-            kw["patch_edges_ub"] = 25
             ms = timeit(lambda: upd(net, imap[None], corr[None], None, ii, jj, kk, fused=fz, **kw), reps=reps)
             out[name] = upd(net, imap[None], corr[None], None, ii, jj, kk, fused=fz, **kw)
             print(f"E={E} {name:8s} {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s (reference FLOPs)  "
                   f"{flops / ms / 1e9 / 2500:.3f} of dense f16 peak")
-        for nm in ("pm2", "pm", "fused"):
+        for nm in ("fused",):
             if nm not in out or "unfused" not in out:
                 continue
             a, b = out[nm], out["unfused"]
