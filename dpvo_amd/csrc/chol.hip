@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int NB = 64;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void chol_load_kernel(const float* __restrict__ S, const float* __restrict__ y, int n,
                                                         float* __restrict__ Lw, int np) {
@@ -55,48 +56,67 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, 
   const int bi = k + 1 + blockIdx.x;
   const float* Akk = Lw + ((int64_t)k * NB) * ld + k * NB;
   float* Bik = Lw + ((int64_t)bi * NB) * ld + k * NB;
-  float a[NB], b[NB];
+  // rows as float PAIRS: the trailing updates are v_pk_fma_f32 (two columns per instruction; the 4 032 scalar FMAs of a panel were
+  // 8 of its 18 us, tools/chol_bench.py under rocprofv3)
+  f2 a[NB / 2], b[NB / 2];
+#define A_(c) a[(c) >> 1][(c) & 1]
+#define B_(c) b[(c) >> 1][(c) & 1]
   {
     const f4* src = reinterpret_cast<const f4*>(Akk + (int64_t)t * ld);
     const f4* srb = reinterpret_cast<const f4*>(Bik + (int64_t)t * ld);
 #pragma unroll
     for (int q = 0; q < NB / 4; ++q) {
-      const f4 v = src[q]; a[4 * q] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
-      const f4 u = srb[q]; b[4 * q] = u[0]; b[4 * q + 1] = u[1]; b[4 * q + 2] = u[2]; b[4 * q + 3] = u[3];
+      const f4 v = src[q]; a[2 * q] = (f2){v[0], v[1]}; a[2 * q + 1] = (f2){v[2], v[3]};
+      const f4 u = srb[q]; b[2 * q] = (f2){u[0], u[1]}; b[2 * q + 1] = (f2){u[2], u[3]};
     }
   }
-  // column j of L is published in LDS as it is made (Lc[j][i] = L_ij): the other lanes read it back as 16-byte broadcasts,
-  // four multipliers per LDS instruction instead of one v_readlane each; the solve below reads the same columns again.
+  // Column j of L is published in LDS as it is made (Lc[j][i] = L_ij); the other lanes read it back as 16-byte broadcasts, four
+  // multipliers per LDS instruction.  Round 5: the LDS round trip is OFF the dependent chain.  Rounds 3-4 wrote column j, waited,
+  // read it back and only then updated the trailing columns -- two exposed LDS latencies per column, 250 ns x 64 columns = 16 of the
+  // kernel's 19 us.  Now step j applies column j to the NEXT TWO columns through v_readlane (register to register), and the bulk
+  // update with column j - 1 (columns >= j + 2), whose broadcast reads were requested at the top of the step and land under the
+  // sqrt / rcp chain.  Every column still receives the updates of all earlier columns before it becomes the pivot column:
+  // from j - 1 and j - 2 through the readlane path, from everything older through the bulk path at least one step earlier.
   __shared__ __attribute__((aligned(16))) float Lc[NB][NB];
   __shared__ float invs[NB];
+  float lprev = 0.f;
 #pragma clang loop unroll(full)
   for (int j = 0; j < NB; ++j) {
-    // (the hardware square root and reciprocal, 1 ulp each: the IEEE sequences are 40 instructions per column, a quarter of the kernel)
-    const float d = __builtin_amdgcn_sqrtf(lane_bcast(a[j], j));
+    f4 v[NB / 4];
+    const int q0 = (j + 2) >> 2;
+    if (j > 0) {
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q) if (q >= q0) v[q] = *reinterpret_cast<const f4*>(&Lc[j - 1][4 * q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (the hardware square root and reciprocal, 1 ulp each: the IEEE sequences are 40 instructions per column)
+    const float d = __builtin_amdgcn_sqrtf(lane_bcast(A_(j), j));
     const float inv = __builtin_amdgcn_rcpf(d);
-    const float l = (t == j) ? d : a[j] * inv;       // lanes above the diagonal: don't-care
-    a[j] = l;
+    const float l = (t == j) ? d : A_(j) * inv;      // lanes above the diagonal: don't-care
+    A_(j) = l;
     Lc[j][t] = l;
-    if (t == j) invs[j] = inv;
+    invs[j] = inv;                                   // (the same value from every lane: no divergent store)
+    if (j + 1 < NB) { const int c = j + 1 < NB ? j + 1 : 0; A_(c) -= l * lane_bcast(l, c); asm volatile("" : "+v"(a[c >> 1])); }
+    if (j + 2 < NB) { const int c = j + 2 < NB ? j + 2 : 0; A_(c) -= l * lane_bcast(l, c); asm volatile("" : "+v"(a[c >> 1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (j > 0) {
+      const f2 lp = {lprev, lprev};
+#pragma unroll
+      for (int p2 = 0; p2 < NB / 2; ++p2) {
+        const int c = 2 * p2;                          // columns c, c + 1; column j + 2 may be the odd one of its pair
+        if (c >= j + 2) {
+          a[p2] -= lp * (f2){v[p2 >> 1][2 * (p2 & 1)], v[p2 >> 1][2 * (p2 & 1) + 1]};
+          asm volatile("" : "+v"(a[p2]));            // (pins the update here: LLVM otherwise sinks it to step c and keeps 2 016 loaded values alive)
+        } else if (c + 1 >= j + 2) {
+          a[p2][1] -= lprev * v[p2 >> 1][2 * (p2 & 1) + 1];
+          asm volatile("" : "+v"(a[p2]));
+        }
+      }
+    }
+    lprev = l;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      const int q0 = (j + 1) >> 2;
-      f4 v[NB / 4];
-#pragma unroll
-      for (int q = 0; q < NB / 4; ++q) if (q >= q0) v[q] = *reinterpret_cast<const f4*>(&Lc[j][4 * q]);
-#pragma unroll
-      for (int q = 0; q < NB / 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = 4 * q + e;
-          if (q >= q0 && c > j) {
-            a[c] -= l * v[q][e];
-            asm volatile("" : "+v"(a[c]));           // (pins the update here: LLVM otherwise sinks it to step c and keeps 2 016 loaded values alive)
-          }
-        }
-    }
   }
   if (blockIdx.x == 0) {
     Di[k * NB + t] = invs[t];
@@ -105,31 +125,49 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, 
     for (int q = 0; q < NB / 4; ++q) {
       f4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (4 * q + e <= t) ? a[4 * q + e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = (4 * q + e <= t) ? A_(4 * q + e) : 0.f;
       dst[q] = v;
     }
   }
+  // X = A_ik L_kk^-T, row r of the block per lane: x_c = b_c / L_cc, b_c' -= x_c L_c'c.  The multipliers of step c + 1 (row c + 1 of
+  // Lc: the same for every lane) are requested before step c's arithmetic.
+  {
+    f4 vv[2][NB / 4];
+    float iv[2];
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) vv[0][q] = *reinterpret_cast<const f4*>(&Lc[0][4 * q]);
+    iv[0] = invs[0];
 #pragma clang loop unroll(full)
-  for (int c = 0; c < NB; ++c) {
-    const float x = b[c] * invs[c];
-    b[c] = x;
-    {
-      const int q0 = (c + 1) >> 2;
-      f4 v[NB / 4];
+    for (int c = 0; c < NB; ++c) {
+      if (c + 1 < NB) {
+        const int q1 = (c + 2) >> 2;
 #pragma unroll
-      for (int q = 0; q < NB / 4; ++q) if (q >= q0) v[q] = *reinterpret_cast<const f4*>(&Lc[c][4 * q]);
+        for (int q = 0; q < NB / 4; ++q) if (q >= q1) vv[(c + 1) & 1][q] = *reinterpret_cast<const f4*>(&Lc[c + 1 < NB ? c + 1 : 0][4 * q]);
+        iv[(c + 1) & 1] = invs[c + 1 < NB ? c + 1 : 0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float x = B_(c) * iv[c & 1];
+      B_(c) = x;
+      const f2 x2 = {x, x};
 #pragma unroll
-      for (int q = 0; q < NB / 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c2 = 4 * q + e;
-          if (q >= q0 && c2 > c) { b[c2] -= x * v[q][e]; asm volatile("" : "+v"(b[c2])); }
+      for (int p2 = 0; p2 < NB / 2; ++p2) {
+        const int c2 = 2 * p2;
+        if (c2 > c) {
+          b[p2] -= x2 * (f2){vv[c & 1][p2 >> 1][2 * (p2 & 1)], vv[c & 1][p2 >> 1][2 * (p2 & 1) + 1]};
+          asm volatile("" : "+v"(b[p2]));
+        } else if (c2 + 1 > c) {
+          b[p2][1] -= x * vv[c & 1][p2 >> 1][2 * (p2 & 1) + 1];
+          asm volatile("" : "+v"(b[p2]));
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   f4* dst = reinterpret_cast<f4*>(Bik + (int64_t)t * ld);
 #pragma unroll
-  for (int q = 0; q < NB / 4; ++q) { f4 v = {b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]}; dst[q] = v; }
+  for (int q = 0; q < NB / 4; ++q) { f4 v = {b[2 * q][0], b[2 * q][1], b[2 * q + 1][0], b[2 * q + 1][1]}; dst[q] = v; }
+#undef A_
+#undef B_
 }
 
 __global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ Lw, int ld, int k, int r) {
