@@ -62,10 +62,19 @@ MFMA_PEAK_TFLOPS = 2500.0                                       # dense f16 MFMA
 UPDATE_FLOP_EDGE = 2 * (882 * 384 + 16 * 384 * 384 + 2 * 384 * 2)    # Update.forward per edge: 5.40 MFLOP
 
 
+def corr_source_sha256():
+    """fingerprint of the correlation kernel's source: corr.hip + corr_dev.h (the kernel's device code lives in the header since round 5)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("corr.hip", "corr_dev.h"):
+        h.update(open(os.path.join(ROOT, "dpvo_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(config="default"):
     """HBM-side bytes per corr_pyramid_kernel launch from the newest committed PMC pass (tools/pmc_corr.sh, two separate
     rocprofv3 --pmc runs of this same command; corrected as MI355X_MICROARCH.md prescribes) -- but only if that pass measured
-    THIS kernel: the file carries the SHA-256 of dpvo_amd/csrc/corr.hip it was taken with, and a file whose fingerprint does not
+    THIS kernel: the file carries the SHA-256 of dpvo_amd/csrc/corr.hip + corr_dev.h it was taken with, and a file whose fingerprint does not
     match the source in the tree (or has none) is refused.  Returns (bytes or None, reason)."""
     import glob
     import hashlib
@@ -74,7 +83,7 @@ def pmc_traffic(config="default"):
         return None, "no PMC pass committed"
     try:
         rec = json.load(open(files[-1]))
-        now = hashlib.sha256(open(os.path.join(ROOT, "dpvo_amd", "csrc", "corr.hip"), "rb").read()).hexdigest()
+        now = corr_source_sha256()
         if rec.get("corr_hip_sha256") != now:
             return None, f"{os.path.basename(files[-1])} was measured on a different corr.hip (stale): refused"
         return float(rec["traffic_bytes_per_launch"]), os.path.basename(files[-1])

@@ -12,9 +12,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   (cd $root && DPVO_BENCH_SYNC_EVERY_FRAME=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python bench.py --steps 8 --warmup 45 --no-cpu-baseline --config $cfg > $out/$c.log 2>&1)
 done
 cd $root
-python - <<'PY'
+PYTHONPATH=$root python - <<'PY'
 import csv, glob, hashlib, json, os
-res = {"config": os.environ.get("CONFIG", "default"), "corr_hip_sha256": hashlib.sha256(open("dpvo_amd/csrc/corr.hip", "rb").read()).hexdigest()}   # bench.py ignores the file once the kernel source changes
+import bench
+res = {"config": os.environ.get("CONFIG", "default"), "corr_hip_sha256": bench.corr_source_sha256()}   # bench.py ignores the file once the kernel source changes
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.environ["PMC_OUT"] + f"/{c}/**/*counter_collection.csv", recursive=True)[0]
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "corr_pyramid_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
