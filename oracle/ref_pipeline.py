@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- the reference's OWN tracker (`dpvo.dpvo.DPVO`, dpvo/dpvo.py:20-473, with its own net.py / patchgraph.py /
 projective_ops.py / blocks.py / lietorch Python and its own native kernels cuda_corr / cuda_ba compiled for gfx950) running on the
-MI355X: the trajectory-level checker of tests/test_gpu_ref_pipeline.py and the same-box `ref_baseline` of bench.py.
+MI355X: the trajectory-level checker of tests/test_zz_ref_pipeline.py and the same-box `ref_baseline` of bench.py.
 
 Where the pieces come from (oracle/build_ref.py, run where /root/reference exists; everything lands in the git-ignored oracle/_ref/,
 which travels to the GPU box with the tree):

@@ -1,6 +1,6 @@
 """Lock-step runner: dpvo_amd's tracker and the REFERENCE's own tracker (oracle/ref_pipeline.py: its Python + its native kernels,
 compiled for gfx950) on the same frames, weights and random draws; per-frame comparison of the state both leave behind.
-Shared by tests/test_gpu_ref_pipeline.py and tools/ref_parity.py (which commits the measured distances to profiles/)."""
+Shared by tests/test_zz_ref_pipeline.py and tools/ref_parity.py (which commits the measured distances to profiles/)."""
 import os
 import sys
 

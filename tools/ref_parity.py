@@ -2,7 +2,7 @@
 """Trajectory-level parity report: dpvo_amd's tracker against the REFERENCE's own tracker (its Python + its native kernels compiled
 for gfx950, oracle/ref_pipeline.py) on the MI355X, at the configuration bench.py times (480x640, 96 patches, default.yaml, one C-ABI
 call per frame, overlapped + held encoders, deferred result record).  Prints one JSON object per scenario; the committed copy is
-profiles/rNN_ref_parity_pipeline.txt.  tests/test_gpu_ref_pipeline.py asserts the same quantities.
+profiles/rNN_ref_parity_pipeline.txt.  tests/test_zz_ref_pipeline.py asserts the same quantities.
 
     python tools/ref_parity.py [--frames 70] [--scenarios A,A2,B,C,D]
 """
