@@ -4,7 +4,11 @@
 // corr.hip): tools/corr_variants.sh links it, beside the product objects, into dpvo_amd/libdpvo_hip_corrvar.so, and
 // tools/corr_bench.py calls dpvo_corr_pyramid_variant through ctypes when CORR_VARIANT is set.  Never part of libdpvo_hip.so.
 //   variant 0: the product's arithmetic (must reproduce the product kernel's checksum);  1: level 0 only;  2: level 1 only;
-//   4: level 1 reads one fixed cache-hot window (the most a level-1 tile shared through LDS could deliver);  5: both levels do.
+//   4: level 1 reads one fixed cache-hot window (the most a level-1 tile shared through LDS could deliver);  5: both levels do;
+//   6: the per-edge FIXED work made free -- ring indices computed instead of loaded, the nine templates taken from patch 0 (cache-hot),
+//      coordinates still loaded: the most that several edges of one patch per workgroup sharing the index / template round trips
+//       could save;  7: as 6, and the output row is not written (the most a correlation fused into the update
+//      operator's first kernel could save on THIS side of the fusion).
 #include "../../dpvo_amd/csrc/corr_dev.h"
 
 template <int VARIANT>
@@ -18,7 +22,9 @@ __global__ __launch_bounds__(64, 3) void corr_pyramid_variant_kernel(
   __shared__ float meta_f[32];
   const int lane = threadIdx.x;
   for (int64_t e = blockIdx.x; e < E; e += gridDim.x) {
-    const int64_t u = (int)us[e] % N1, v = (int)vs[e] % N2;
+    int64_t u, v;
+    if constexpr (VARIANT == 6 || VARIANT == 7) { u = 0; v = (int)(e / 1326) % N2; }      // (1 326 = E / 36: same frames, no dependent loads)
+    else { u = (int)us[e] % N1; v = (int)vs[e] % N2; }
     h8 a[4];
     {
       const int m = lane & 15, kg = lane >> 4;
@@ -51,12 +57,16 @@ __global__ __launch_bounds__(64, 3) void corr_pyramid_variant_kernel(
     }
     const uint32_t* src = reinterpret_cast<const uint32_t*>(orow);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
+    if constexpr (VARIANT == 7) {
+      if (src[lane] == 0x7fff7fffu) dst[lane] = 1;       // (keeps the blend alive without the row store)
+    } else {
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const int q = lane + 64 * s;
-      if (q < CORR_NOUT) dst[q] = src[q];
+      for (int s = 0; s < 7; ++s) {
+        const int q = lane + 64 * s;
+        if (q < CORR_NOUT) dst[q] = src[q];
+      }
+      for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
     }
-    for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
     __syncthreads();
   }
 }
@@ -76,6 +86,8 @@ extern "C" int dpvo_corr_pyramid_variant(const void* gmap, const void* fmap0, co
     case 2: CV(2); break;
     case 4: CV(4); break;
     case 5: CV(5); break;
+    case 6: CV(6); break;
+    case 7: CV(7); break;
     default: return DPVO_E_UNSUPPORTED;
   }
 #undef CV
