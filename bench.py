@@ -17,7 +17,8 @@ N*K / max-over-ranks seconds; scaling is "weak".  Launched either by torch.distr
 environment) or plainly as `python bench.py --gpus N`, which re-executes itself under torch.distributed.run with N ranks
 on 127.0.0.1.  If the box shows fewer than N devices the ranks share them round-robin over gloo (a smoke mode for the
 launch path and the host-side cost, flagged in `config.parallelism`; not a scaling measurement).
-`per_rank` carries, for every rank, its seconds and the host CPU time it spent per frame (time.process_time).
+`per_rank` carries, for every rank, its seconds, frames/sec, the host CPU time it spent per frame (time.process_time), its device index
+and the host cores it pinned itself to.
 
 The JSON line also carries
   roofline     -- the correlation kernel (corr_pyramid_kernel), mean launch duration from HIP events on the launch stream
@@ -384,7 +385,8 @@ def main():
     lc_leg = None
     if world == 1 and args.drop_every == 0 and args.config == "default" and not os.environ.get("DPVO_BENCH_NO_LC_LEG"):
         lc_leg = loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed=1234 + seed_off)
-    res = multiseq.gather_results(args.steps, local, extra=1e6 * (cpu1 - cpu0) / args.steps, dist=dist,
+    res = multiseq.gather_results(args.steps, local, extra=[1e6 * (cpu1 - cpu0) / args.steps, dev_index,
+                                                           pinned[0] if pinned else -1, pinned[-1] if pinned else -1], dist=dist,
                                   device=device if backend == "nccl" else "cpu")
     elapsed = res["seconds"]                          # max over ranks
 
@@ -446,7 +448,9 @@ def main():
                                                                 f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
             "frame_period_ms": period,
             "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg, "with_loop_closure": lc_leg,
-            "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "host_cpu_us_per_frame": round(r[2], 1)}
+            "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "frames_per_sec": round(r[0] / r[1], 1),
+                          "host_cpu_us_per_frame": round(r[2], 1), "device": int(r[3]),
+                          "pinned_to": (f"{int(r[4])}-{int(r[5])}" if r[4] >= 0 else None)}
                          for i, r in enumerate(res["per_rank"])],
             "placement": {"backend": backend if world > 1 else None, "devices_visible": n_dev, "host_cores_allowed": len(allowed) if allowed else None,
                           "rank0_pinned_to": (f"{pinned[0]}-{pinned[-1]} ({len(pinned)} cores)" if pinned else None), "cores_per_rank": len(cpus)},

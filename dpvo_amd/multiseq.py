@@ -43,9 +43,11 @@ class Clock:
 
 
 def gather_results(frames, seconds, extra=0.0, dist=None, device="cpu"):
-    """all_gather of (frames, seconds, extra) per rank -> whole-job record.
+    """all_gather of (frames, seconds, extra...) per rank -> whole-job record (`extra`: one number or a short sequence of numbers that
+    travels with the rank's record, e.g. host CPU time per frame, device index, first / last pinned core).
     fps = sum(frames) / max(seconds): the job is done when the slowest rank is done."""
-    rec = torch.tensor([float(frames), float(seconds), float(extra)], dtype=torch.float64, device=device)
+    extras = [float(extra)] if not isinstance(extra, (list, tuple)) else [float(x) for x in extra]
+    rec = torch.tensor([float(frames), float(seconds)] + extras, dtype=torch.float64, device=device)
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
         dist.all_gather(out, rec)

@@ -81,6 +81,15 @@ def test_bench_self_spawns_two_real_trackers():
     secs = [r["seconds"] for r in rec["per_rank"]]
     assert abs(rec["value"] - 2 * 12 / max(secs)) / rec["value"] < 1e-2, rec     # whole-job frames/sec = N*K / max over ranks
     assert all(r["host_cpu_us_per_frame"] > 0 for r in rec["per_rank"]), rec
+    # what DESIGN.md section 6 says an accepted multi-GPU line carries per rank: device, frames/sec, the pinned core slice (disjoint)
+    import torch
+    n_dev = torch.cuda.device_count()
+    assert all(0 <= r["device"] < n_dev and r["frames_per_sec"] > 0 for r in rec["per_rank"]), rec
+    assert rec["placement"]["backend"] == ("nccl" if n_dev >= 2 else "gloo"), rec
+    pins = [r["pinned_to"] for r in rec["per_rank"]]
+    if all(pins):
+        spans = sorted(tuple(int(x) for x in p_.split("-")) for p_ in pins)
+        assert spans[0][1] < spans[1][0], ("the ranks' core slices overlap", pins)
 
 
 def test_rank_placement_logic():
