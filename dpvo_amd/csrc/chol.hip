@@ -13,8 +13,9 @@
 //   chol_panel_kernel    one wave per row block below the diagonal block (the border row included): every wave factorises the
 //                        64 x 64 diagonal block by itself, in registers (cheaper than a launch + a round trip through memory),
 //                        then solves its own block against it: X = A_ik L_kk^-T.  L_kk is kept in Dg[k].
-//   chol_update_kernel   one workgroup per 64 x 64 tile (i >= j > k) of the trailing matrix: A_ij -= L_ik L_jk^T, K = 64 as
-//                        32 steps of the 32x32x2 f32 MFMA per wave, operands straight from L2 into the fragment registers.
+//   chol_step_kernel     (panels k >= 1) one workgroup per 64 x 64 tile (i >= j >= k) of the trailing matrix of panel k - 1:
+//                        A_ij -= L_i,k-1 L_j,k-1^T, K = 64 as 32 steps of the 32x32x2 f32 MFMA per wave, operands straight from L2
+//                        into the fragment registers; the workgroups of the first tile column go on with panel k (look-ahead).
 //   chol_back_kernel     per block column from the last: x_k = L_kk^-T y_k (one wave, in registers), then every workgroup takes one
 //                        block j < k: y_j -= L_kj^T x_k.
 #include "common.h"
@@ -51,25 +52,13 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {          // lan
 // barrier: 64 fully unrolled steps); the entries above the diagonal go along as don't-cares.  The
 // same wave then solves its own block against the factor: lane r keeps row r of A_ik, x_c = b_c / L_cc, b_c' -= x_c L_c'c.
 // (A 256-thread version with the block in LDS and two barriers per column took 80 us per panel; this one takes ~20.)
-__global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, float* __restrict__ Dg, float* __restrict__ Di, int ld, int k) {
-  const int t = threadIdx.x;
-  const int bi = k + 1 + blockIdx.x;
-  const float* Akk = Lw + ((int64_t)k * NB) * ld + k * NB;
-  float* Bik = Lw + ((int64_t)bi * NB) * ld + k * NB;
-  // rows as float PAIRS: the trailing updates are v_pk_fma_f32 (two columns per instruction; the 4 032 scalar FMAs of a panel were
-  // 8 of its 18 us, tools/chol_bench.py under rocprofv3)
-  f2 a[NB / 2], b[NB / 2];
+// The panel step on rows that are already in registers: lane t holds row t of the diagonal block in `a` and row t of its own block
+// in `b` (float pairs).  Shared by chol_panel_kernel (rows loaded from the work matrix) and chol_step_kernel (rows taken from the LDS
+// tiles its own trailing update has just produced).  Lc: [NB][NB] floats of LDS, invs: [NB].
 #define A_(c) a[(c) >> 1][(c) & 1]
 #define B_(c) b[(c) >> 1][(c) & 1]
-  {
-    const f4* src = reinterpret_cast<const f4*>(Akk + (int64_t)t * ld);
-    const f4* srb = reinterpret_cast<const f4*>(Bik + (int64_t)t * ld);
-#pragma unroll
-    for (int q = 0; q < NB / 4; ++q) {
-      const f4 v = src[q]; a[2 * q] = (f2){v[0], v[1]}; a[2 * q + 1] = (f2){v[2], v[3]};
-      const f4 u = srb[q]; b[2 * q] = (f2){u[0], u[1]}; b[2 * q + 1] = (f2){u[2], u[3]};
-    }
-  }
+__device__ __forceinline__ void panel_body(f2 (&a)[NB / 2], f2 (&b)[NB / 2], float (*Lc)[NB], float* invs, const int t, const bool write_diag,
+                                           float* __restrict__ Dg, float* __restrict__ Di, float* __restrict__ Bik, const int ld, const int k) {
   // Column j of L is published in LDS as it is made (Lc[j][i] = L_ij); the other lanes read it back as 16-byte broadcasts, four
   // multipliers per LDS instruction.  Round 5: the LDS round trip is OFF the dependent chain.  Rounds 3-4 wrote column j, waited,
   // read it back and only then updated the trailing columns -- two exposed LDS latencies per column, 250 ns x 64 columns = 16 of the
@@ -77,8 +66,6 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, 
   // update with column j - 1 (columns >= j + 2), whose broadcast reads were requested at the top of the step and land under the
   // sqrt / rcp chain.  Every column still receives the updates of all earlier columns before it becomes the pivot column:
   // from j - 1 and j - 2 through the readlane path, from everything older through the bulk path at least one step earlier.
-  __shared__ __attribute__((aligned(16))) float Lc[NB][NB];
-  __shared__ float invs[NB];
   float lprev = 0.f;
 #pragma clang loop unroll(full)
   for (int j = 0; j < NB; ++j) {
@@ -118,7 +105,7 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (blockIdx.x == 0) {
+  if (write_diag) {
     Di[k * NB + t] = invs[t];
     f4* dst = reinterpret_cast<f4*>(Dg + (int64_t)k * NB * NB + t * NB);
 #pragma unroll
@@ -170,23 +157,31 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, 
 #undef B_
 }
 
-__global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ Lw, int ld, int k, int r) {
-  // tile enumeration: lower triangle of the r trailing blocks (rows first), then the border row (block r) against blocks 0..r-1
-  const int b = blockIdx.x;
-  const int ntri = r * (r + 1) / 2;
-  int i, j;
-  if (b < ntri) {
-    i = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
-    while (i * (i + 1) / 2 > b) --i;
-    while ((i + 1) * (i + 2) / 2 <= b) ++i;
-    j = b - i * (i + 1) / 2;
-  } else {
-    i = r; j = b - ntri;
+__global__ __launch_bounds__(64) void chol_panel_kernel(float* __restrict__ Lw, float* __restrict__ Dg, float* __restrict__ Di, int ld, int k) {
+  const int t = threadIdx.x;
+  const int bi = k + 1 + blockIdx.x;
+  const float* Akk = Lw + ((int64_t)k * NB) * ld + k * NB;
+  float* Bik = Lw + ((int64_t)bi * NB) * ld + k * NB;
+  // rows as float PAIRS: the trailing updates are v_pk_fma_f32 (two columns per instruction; the 4 032 scalar FMAs of a panel were
+  // 8 of its 18 us, tools/chol_bench.py under rocprofv3)
+  f2 a[NB / 2], b[NB / 2];
+  {
+    const f4* src = reinterpret_cast<const f4*>(Akk + (int64_t)t * ld);
+    const f4* srb = reinterpret_cast<const f4*>(Bik + (int64_t)t * ld);
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+      const f4 v = src[q]; a[2 * q] = (f2){v[0], v[1]}; a[2 * q + 1] = (f2){v[2], v[3]};
+      const f4 u = srb[q]; b[2 * q] = (f2){u[0], u[1]}; b[2 * q + 1] = (f2){u[2], u[3]};
+    }
   }
-  const int bi = k + 1 + i, bj = k + 1 + j;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int qi = w >> 1, qj = w & 1;
-  if (bi == bj && qi < qj) return;                          // upper quadrant of a diagonal tile: never read
+  __shared__ __attribute__((aligned(16))) float Lc[NB][NB];
+  __shared__ float invs[NB];
+  panel_body(a, b, Lc, invs, t, blockIdx.x == 0, Dg, Di, Bik, ld, k);
+}
+
+// tile (bi, bj) of the trailing matrix minus L_{bi,k} L_{bj,k}^T, one 32 x 32 quadrant (qi, qj) per wave: acc[4 g + rr] <-> row
+// 8 g + 4 kh + rr, column m of the quadrant (m = lane & 31, kh = lane >> 5)
+__device__ __forceinline__ f16v tile_update(const float* __restrict__ Lw, int ld, int k, int bi, int bj, int qi, int qj, int lane) {
   const int m = lane & 31, kh = lane >> 5;
   // fragments: lane (m, kh) holds elements [32 kh, 32 kh + 32) of row m of its quadrant's 32 x 64 operand; MFMA step s
   // consumes element s of every lane (k = s from the lanes with kh = 0, k = 32 + s from the others) -- the same permutation of
@@ -196,8 +191,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ Lw
   f4 a[8], bb[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { a[q] = pa[q]; bb[q] = pb[q]; }
-  // C fragment: acc[4 g + rr] <-> row 8 g + 4 kh + rr, column m
-  float* C = Lw + ((int64_t)bi * NB + 32 * qi) * ld + bj * NB + 32 * qj + m;
+  const float* C = Lw + ((int64_t)bi * NB + 32 * qi) * ld + bj * NB + 32 * qj + m;
   f16v acc;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -207,10 +201,80 @@ __global__ __launch_bounds__(256) void chol_update_kernel(float* __restrict__ Lw
   for (int q = 0; q < 8; ++q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[q][e], bb[q][e], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ void tile_enum(int b, int r, int& i, int& j) {
+  // tile enumeration: lower triangle of the r trailing blocks (rows first), then the border row (block r) against blocks 0..r-1
+  const int ntri = r * (r + 1) / 2;
+  if (b < ntri) {
+    i = (int)((sqrtf(8.f * (float)b + 1.f) - 1.f) * 0.5f);
+    while (i * (i + 1) / 2 > b) --i;
+    while ((i + 1) * (i + 2) / 2 <= b) ++i;
+    j = b - i * (i + 1) / 2;
+  } else {
+    i = r; j = b - ntri;
+  }
+}
+
+// Look-ahead (round 5): ONE launch per panel instead of two.  The trailing update with panel k - 1 and the factorisation of panel k
+// used to be two dependent launches (chol_update_kernel: one workgroup per 64 x 64 tile, A_ij -= L_ik L_jk^T as 32 steps of the
+// 32x32x2 f32 MFMA per wave, then chol_panel_kernel); here the workgroups of the update's first tile column (tiles (i, 0), i >= 1:
+// exactly the blocks panel k needs) update their own tile AND, redundantly, the diagonal tile into LDS instead of memory, and their
+// wave 0 goes straight on with the panel step on those rows (panel_body); every other workgroup is the plain update.  Panel k is
+// factored while the rest of update k - 1 is still running.  Same operands, same order of operations per entry as the two-launch
+// path: bit-identical.  Measured against it on one box (profiles/r05_d_chol_lookahead.txt): n = 294 / 630 / 1 194 / 2 394 / 4 794:
+// 123 / 250 / 489 / 1 099 / 2 972 -> 122 / 247 / 478 / 1 055 / 2 821 us -- 1-5 %: back-to-back launches of one stream already
+// overlap most of a launch boundary, and the step kernel carries the panel path's 206 registers and 51 KB of LDS on every workgroup.
+constexpr int TP = NB + 4;           // LDS tile pitch in floats: 16-byte aligned rows, a lane's own row conflict free for ds_read_b128
+__global__ __launch_bounds__(256) void chol_step_kernel(float* __restrict__ Lw, float* __restrict__ Dg, float* __restrict__ Di, int ld, int k, int r) {
+  // update with panel kp = k - 1 over its r trailing blocks; panel k = first trailing block column
+  const int kp = k - 1;
+  int i, j;
+  tile_enum(blockIdx.x, r, i, j);
+  const int bi = kp + 1 + i, bj = kp + 1 + j;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qi = w >> 1, qj = w & 1;
+  const int m = lane & 31, kh = lane >> 5;
+  if (j != 0) {
+    if (bi == bj && qi < qj) return;
+    const f16v acc = tile_update(Lw, ld, kp, bi, bj, qi, qj, lane);
+    float* C = Lw + ((int64_t)bi * NB + 32 * qi) * ld + bj * NB + 32 * qj + m;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) C[(int64_t)(8 * g + 4 * kh + rr) * ld] = acc[4 * g + rr];
+      for (int rr = 0; rr < 4; ++rr) C[(int64_t)(8 * g + 4 * kh + rr) * ld] = acc[4 * g + rr];
+    return;
+  }
+  if (i == 0) return;                                       // the diagonal tile itself: every column workgroup forms it for itself
+  __shared__ __attribute__((aligned(16))) float T0[NB][TP];          // diagonal tile (k, k) after the update
+  __shared__ __attribute__((aligned(16))) float T1[NB][TP];          // own tile (bi, k) after the update
+  __shared__ __attribute__((aligned(16))) float Lc[NB][NB];
+  __shared__ float invs[NB];
+  {
+    const f16v acc = tile_update(Lw, ld, kp, bi, k, qi, qj, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) T1[32 * qi + 8 * g + 4 * kh + rr][32 * qj + m] = acc[4 * g + rr];
+  }
+  if (qi >= qj) {
+    const f16v acc = tile_update(Lw, ld, kp, k, k, qi, qj, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) T0[32 * qi + 8 * g + 4 * kh + rr][32 * qj + m] = acc[4 * g + rr];
+  }
+  __syncthreads();
+  if (w != 0) return;
+  const int t = lane;
+  f2 a[NB / 2], b[NB / 2];
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) {
+    const f4 v = *reinterpret_cast<const f4*>(&T0[t][4 * q]); a[2 * q] = (f2){v[0], v[1]}; a[2 * q + 1] = (f2){v[2], v[3]};
+    const f4 u = *reinterpret_cast<const f4*>(&T1[t][4 * q]); b[2 * q] = (f2){u[0], u[1]}; b[2 * q + 1] = (f2){u[2], u[3]};
+  }
+  panel_body(a, b, Lc, invs, t, i == 1, Dg, Di, Lw + ((int64_t)bi * NB) * ld + k * NB, ld, k);
 }
 
 __global__ __launch_bounds__(256) void chol_back_kernel(const float* __restrict__ Lw, const float* __restrict__ Dg, const float* __restrict__ Di, int ld, float* __restrict__ yv,
@@ -265,10 +329,11 @@ extern "C" int dpvo_gba_solve(const float* S, const float* y, int n, float* dX, 
   const int64_t total = (int64_t)(np + NB) * np;
   const int lg = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(chol_load_kernel, dim3(lg), dim3(256), 0, stream, S, y, n, Lw, np);
-  for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(nb - k), dim3(64), 0, stream, Lw, Dg, Di, np, k);
-    const int r = nb - k - 1;
-    if (r > 0) hipLaunchKernelGGL(chol_update_kernel, dim3(r * (r + 1) / 2 + r), dim3(256), 0, stream, Lw, np, k, r);
+  // panel 0 by itself, then ONE launch per panel: the trailing update with panel k - 1 and, in its first tile column, panel k
+  hipLaunchKernelGGL(chol_panel_kernel, dim3(nb), dim3(64), 0, stream, Lw, Dg, Di, np, 0);
+  for (int k = 1; k < nb; ++k) {
+    const int r = nb - k;                                   // trailing blocks of panel k - 1
+    hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2 + r), dim3(256), 0, stream, Lw, Dg, Di, np, k, r);
   }
   float* yv = Lw + (int64_t)np * np;
   for (int k = nb - 1; k >= 0; --k)
