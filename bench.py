@@ -480,6 +480,18 @@ def main():
                            "corr_ms_minmax": [round(min(corr_ms), 4), round(max(corr_ms), 4)]}
         if world == 1 and not os.environ.get("DPVO_BENCH_NO_BOX"):     # (skipped under rocprofv3: the probe is a child process)
             out["box"] = box_clock()
+        # The slow kind of box (one call in ~10 on this pool; profiles/r05_b_*_slow_box.txt, r04: "650-667 on a throttled one"): the
+        # kernels that run ONE wave per SIMD or one workgroup in all (K1 / K7 of the update operator, the BA solve, the Cholesky
+        # panels) take 1.6-2.1x as long while the 12-waves-per-CU correlation kernel is unaffected, and the sustained-MFMA clock probe
+        # above does not see it.  What does: the ratio of the two stages' times, measured in THIS run (1.8-1.9 on the usual boxes).
+        if roof is not None and roof_u is not None and roof.get("avg_launch_ms"):
+            ratio = round(roof_u["avg_ms"] / roof["avg_launch_ms"], 2)
+            if not isinstance(out.get("box"), dict):
+                out["box"] = {}
+            out["box"]["update_over_corr"] = ratio
+            if ratio > 2.3 and args.config == "default":
+                out["box"]["slow_box"] = ("update operator / correlation = %.2f (1.8-1.9 on the pool's usual boxes): this box runs the "
+                                          "one-wave-per-SIMD kernels 1.6-2x slower, frames/sec here is ~0.7x of the usual" % ratio)
         if world == 1 and not args.no_ref_baseline and args.config == "default":
             out["ref_baseline"] = ref_baseline(device, ht, wd, cfg, frames, intr, 1234 + seed_off)
             if out["ref_baseline"].get("frames_per_sec"):
