@@ -159,3 +159,15 @@ def test_plan_layout_flow_region():
     for E in (0, 1, 2, 3, 5, 96, 1023, 45312, 47712):
         lay = L.plan_layout(E)
         assert lay.flow % 4 == 0 and lay.flow >= lay.counts + 4 and lay.total_ints == lay.flow + 4 + 2 * 256, E
+
+
+def test_committed_pmc_pass_belongs_to_the_committed_correlation_kernel():
+    """bench.py's roofline.traffic comes from the newest profiles/rNN_corr_pmc.json only if the SHA-256 recorded in it equals the
+    fingerprint of dpvo_amd/csrc/corr.hip + corr_dev.h in the tree; otherwise the line falls back to the streaming figure and says so.
+    A commit that changes the kernel without a fresh tools/pmc_corr.sh pass must be visible HERE, not only in the driver's bench line."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    traffic, source = bench.pmc_traffic("default")
+    assert traffic is not None, f"stale PMC pass: {source} (run tools/pmc_corr.sh on a GPU box and commit profiles/rNN_corr_pmc.json)"
+    assert 1.0e9 < traffic < 2.6e9 and source.endswith("_corr_pmc.json"), (traffic, source)
