@@ -43,8 +43,8 @@ inline void gba_layout(int64_t E, int64_t n_pairs, int64_t n_frames, int M, int6
   L->tgt_list = o; o += al(g * 4);
   L->Q = o; o += al(f * M * 4);
   L->u = o; o += al(f * M * 4);
-  L->Ecol = o; o += al(g * M * 6 * 4);
   L->Eself = o; o += al(f * M * 6 * 4);
+  L->Ecol = o; o += al(g * M * 6 * 4);          // (last: the only one of the four that is written in full, so it is not cleared)
   L->total = o;
 }
 
@@ -476,7 +476,10 @@ static int gba_linearize_impl(const float* poses, const float* patches, const fl
   const int N = t1 - t0;
   const int32_t* n_patches = plan + PL.counts + 0;
   const int32_t* n_pairs = plan + PL.counts + 1;
-  hipError_t e = hipMemsetAsync(w + L.Q, 0, L.total - L.Q, st);     // Q, u, Ecol, Eself
+  // Q, u, Eself: patch slots without an edge must read as zero.  Ecol is NOT cleared (round 5: it was 8-13 MB per call at the bound on
+  // the pair count, 24 us of every linearisation): gba_scatter_kernel writes all 6 M entries of every existing pair, and every reader
+  // (row kernel, retraction) reaches it through an existing pair's index
+  hipError_t e = hipMemsetAsync(w + L.Q, 0, L.Ecol - L.Q, st);
   if (e != hipSuccess) return (int)e;
   int32_t* run_lo = (int32_t*)(w + L.run_lo);
   int32_t* tgt_off = (int32_t*)(w + L.tgt_off);
