@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPVO_HIP_LIB") or os.path.join(_HERE, "libdpvo_hip.so")      # (override: development builds)
 
 F16, F32 = 0, 1
-ABI_VERSION = 6         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
+ABI_VERSION = 7         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
 
 # every symbol include/dpvo_hip.h declares (tests/test_capi.py checks the .so exports all of them)
 SYMBOLS = [
@@ -23,6 +23,7 @@ SYMBOLS = [
     "dpvo_reproject", "dpvo_flow_mag", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud", "dpvo_point_cloud_motionmag",
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window", "dpvo_plan_build_window_flow",
+    "dpvo_plan_wide_workspace_bytes", "dpvo_plan_build_wide",
     "dpvo_neighbors_workspace_bytes", "dpvo_neighbors",
     "dpvo_softagg",
     "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_default_tiling",
@@ -111,7 +112,7 @@ def lib():
         for s in SYMBOLS:
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
-        for s in ("dpvo_plan_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
+        for s in ("dpvo_plan_workspace_bytes", "dpvo_plan_wide_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
                   "dpvo_gba_workspace_bytes", "dpvo_gba_solve_workspace_bytes", "dpvo_encoders_workspace_bytes",
                   "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
             getattr(L, s).restype = ctypes.c_size_t

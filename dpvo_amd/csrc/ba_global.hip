@@ -108,6 +108,13 @@ __global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32
   }
 }
 
+// Q, u, Eself = 0 in front of a linearisation (hipMemsetAsync of these ~0.3 MB is a 23 us fill on this runtime,
+// profiles/r05_e_lc_timeline.txt; a plain store kernel is a launch)
+__global__ __launch_bounds__(256) void gba_zero_kernel(f4* __restrict__ p, int64_t n4) {
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) p[i] = z;
+}
+
 __device__ __forceinline__ int lower_bound_i(const int32_t* pair_ij, int ng, int f) {
   int lo = 0, hi = ng;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (pair_ij[2 * mid] < f) lo = mid + 1; else hi = mid; }
@@ -401,15 +408,18 @@ __global__ __launch_bounds__(128) void gba_retr_kernel(float* __restrict__ poses
                                                        const int32_t* __restrict__ n_patches, const float* __restrict__ Q,
                                                        const float* __restrict__ U, const float* __restrict__ Ecol,
                                                        const float* __restrict__ Eself, const float* __restrict__ dX,
+                                                       const int32_t* __restrict__ run_lo,
                                                        int M, int f0, int n_frames, int t0, int N, int P) {
-  const int ng = *n_pairs, np = *n_patches;
+  const int np = *n_patches;
   const int PP = P * P;
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   for (int k = gt; k < np; k += gridDim.x * blockDim.x) {
     const int patch = kx[k];
     const int f = patch / M, fr = f - f0, slot = patch % M;
     if (fr < 0 || fr >= n_frames) continue;
-    const int ga = lower_bound_i(pair_ij, ng, f), gb = lower_bound_i(pair_ij, ng, f + 1);
+    // the frame's pair run: run_lo[fr] = first pair of source frame f0 + fr (gba_index_kernel: the same lower bounds this kernel
+    // used to search for itself, two dependent 12-step binary searches per patch)
+    const int ga = run_lo[fr], gb = run_lo[fr + 1];
     float s = 0.f;
     const int ix = f - t0;
     if (ix >= 0 && ix < N) {
@@ -479,8 +489,11 @@ static int gba_linearize_impl(const float* poses, const float* patches, const fl
   // Q, u, Eself: patch slots without an edge must read as zero.  Ecol is NOT cleared (round 5: it was 8-13 MB per call at the bound on
   // the pair count, 24 us of every linearisation): gba_scatter_kernel writes all 6 M entries of every existing pair, and every reader
   // (row kernel, retraction) reaches it through an existing pair's index
-  hipError_t e = hipMemsetAsync(w + L.Q, 0, L.Ecol - L.Q, st);
-  if (e != hipSuccess) return (int)e;
+  {
+    const int64_t n4 = (int64_t)((L.Ecol - L.Q) / 16);          // (every region is 256-byte aligned: gba_layout)
+    const int64_t zg = (n4 + 255) / 256;
+    hipLaunchKernelGGL(gba_zero_kernel, dim3((unsigned)(zg < 1 ? 1 : (zg > 2048 ? 2048 : zg))), dim3(256), 0, st, (f4*)(w + L.Q), n4);
+  }
   int32_t* run_lo = (int32_t*)(w + L.run_lo);
   int32_t* tgt_off = (int32_t*)(w + L.tgt_off);
   int32_t* tgt_cnt = (int32_t*)(w + L.tgt_cnt);
@@ -536,7 +549,7 @@ extern "C" int dpvo_gba_retract(float* poses, float* patches, const int32_t* pla
   hipLaunchKernelGGL(gba_retr_kernel, dim3((unsigned)((work + 127) / 128)), dim3(128), 0, (hipStream_t)stream, poses,
                      patches, plan + PL.pair_ij, plan + PL.counts + 1, plan + PL.kx, plan + PL.counts + 0,
                      (const float*)(w + L.Q), (const float*)(w + L.u), (const float*)(w + L.Ecol),
-                     (const float*)(w + L.Eself), dX, M, f0, n_frames, t0, N, P);
+                     (const float*)(w + L.Eself), dX, (const int32_t*)(w + L.run_lo), M, f0, n_frames, t0, N, P);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

@@ -18,6 +18,7 @@
 //                        into the fragment registers; the workgroups of the first tile column go on with panel k (look-ahead).
 //   chol_back_kernel     per block column from the last: x_k = L_kk^-T y_k (one wave, in registers), then every workgroup takes one
 //                        block j < k: y_j -= L_kj^T x_k.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -310,6 +311,77 @@ __global__ __launch_bounds__(256) void chol_back_kernel(const float* __restrict_
   }
 }
 
+// The whole back substitution as ONE launch of one workgroup (round 5), for systems of up to kBackAllMax block columns -- the bench leg's
+// global BA has 10-11 (profiles/r05_e_lc_timeline.txt: 11 chol_back_kernel launches x 7 us per solve, each a dependent launch whose
+// work is a 64-step chain in one wave and a few 64 x 64 products).  8 waves: per block column k, wave 0 solves x_k = L_kk^-T y_k exactly
+// as chol_back_kernel does, then the two 256-thread groups take the blocks j < k (j = group, group + 2, ...): y_j -= L_kj^T x_k with the same
+// four 16-row partial sums in the same order -- bit-identical to the launch-per-column path (tests/test_gpu_chol.py compares the two).
+// y lives in LDS for the whole solve; the operands of ALL of a column's blocks are requested before the first is consumed (one
+// memory round trip per column), and the next column's diagonal factor is fetched under the products.
+constexpr int kBackAllMax = 12, kBackGroups = 2, kBackPer = kBackAllMax / kBackGroups;
+__global__ __launch_bounds__(256 * kBackGroups) void chol_back_all_kernel(const float* __restrict__ Lw, const float* __restrict__ Dg,
+                                                                          const float* __restrict__ Di, int ld, const float* __restrict__ yv,
+                                                                          float* __restrict__ x_out, int n, int nb) {
+  constexpr int NT = 256 * kBackGroups, PER = NB * NB / NT;
+  __shared__ float A[NB][NB + 1];
+  __shared__ float xs[NB];
+  __shared__ float part[kBackGroups][4][NB];
+  __shared__ float ys[kBackAllMax * NB];
+  const int t = threadIdx.x, g = t >> 8, tt = t & 255, q = tt >> 6, c = tt & 63;
+  for (int i = t; i < nb * NB; i += NT) ys[i] = yv[i];
+  float an[PER];                                                 // the diagonal factor of the column about to be solved
+#pragma unroll
+  for (int u = 0; u < PER; ++u) an[u] = Dg[(int64_t)(nb - 1) * NB * NB + t + NT * u];
+  for (int k = nb - 1; k >= 0; --k) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int idx = t + NT * u; A[idx >> 6][idx & 63] = an[u]; }
+    __syncthreads();
+    if (k > 0) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) an[u] = Dg[(int64_t)(k - 1) * NB * NB + t + NT * u];
+    }
+    // operands of this column's products (they do not depend on x_k): up to kBackPer blocks per group, 16 rows each
+    float lv[kBackPer][16];
+#pragma unroll
+    for (int b = 0; b < kBackPer; ++b) {
+      const int j = g + kBackGroups * b;
+      if (j < k) {
+        const float* Lkj = Lw + ((int64_t)k * NB + 16 * q) * ld + j * NB + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { lv[b][r] = *Lkj; Lkj += ld; }
+      }
+    }
+    if (t < NB) {
+      float yl = ys[k * NB + t], x = 0.f;
+      const float il = Di[k * NB + t];
+#pragma unroll
+      for (int cc = NB - 1; cc >= 0; --cc) {
+        const float xc = lane_bcast(yl, cc) * lane_bcast(il, cc);
+        if (t < cc) yl -= A[cc][t] * xc;
+        if (t == cc) x = xc;
+      }
+      xs[t] = x;
+      if (k * NB + t < n) x_out[k * NB + t] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kBackPer; ++b) {
+      const int j = g + kBackGroups * b;
+      if (kBackGroups * b < k) {                                  // (uniform over the workgroup: the barriers below are taken by everyone)
+        if (j < k) {
+          float s = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += lv[b][r] * xs[16 * q + r];
+          part[g][q][c] = s;
+        }
+        __syncthreads();
+        if (j < k && tt < NB) ys[j * NB + tt] -= (part[g][0][tt] + part[g][1][tt]) + (part[g][2][tt] + part[g][3][tt]);
+        __syncthreads();
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t dpvo_gba_solve_workspace_bytes(int n) {
@@ -336,8 +408,14 @@ extern "C" int dpvo_gba_solve(const float* S, const float* y, int n, float* dX, 
     hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2 + r), dim3(256), 0, stream, Lw, Dg, Di, np, k, r);
   }
   float* yv = Lw + (int64_t)np * np;
-  for (int k = nb - 1; k >= 0; --k)
-    hipLaunchKernelGGL(chol_back_kernel, dim3(k > 0 ? k : 1), dim3(256), 0, stream, Lw, Dg, Di, np, yv, dX, n, k);
+  // back substitution: one launch of one workgroup for small systems, else one launch per block column (DPVO_CHOL_BACK_STEPS=1 forces
+  // the latter: the comparison partner of tests/test_gpu_chol.py and tools/chol_bench.py)
+  const char* force_steps = getenv("DPVO_CHOL_BACK_STEPS");
+  if (nb <= kBackAllMax && !(force_steps && force_steps[0] == '1'))
+    hipLaunchKernelGGL(chol_back_all_kernel, dim3(1), dim3(256 * kBackGroups), 0, stream, Lw, Dg, Di, np, yv, dX, n, nb);
+  else
+    for (int k = nb - 1; k >= 0; --k)
+      hipLaunchKernelGGL(chol_back_kernel, dim3(k > 0 ? k : 1), dim3(256), 0, stream, Lw, Dg, Di, np, yv, dX, n, k);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

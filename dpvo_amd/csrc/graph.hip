@@ -355,6 +355,229 @@ __global__ void win_segsort_kernel(WinArgs W) {
   if (rank == 0) { W.kx[g] = (int32_t)(key >> W.shift); W.patch_off[g] = s; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide plan build (dpvo_plan_build_wide, round 5): the same two orderings when the ids are bounded by the tracker's frame count only
+// (LOOP_CLOSURE: long-range edges among the active ones; the global BA's plan of all active + inactive edges) -- too many bins for
+// per-tile histograms in LDS, so the bins live in memory: one bin per patch id and one per (i, j) frame pair.  Histogram (integer
+// atomics: order-independent), two-level scan over the bins, placement by counting DOWN the same counters (any order inside a bin),
+// then every element ranks itself inside its bin's segment by (jj, edge) resp. by edge -- which is what makes the result the stable
+// sort's, independent of the order the atomics landed in.  6 launches; the two rocPRIM radix sorts it replaces are 16 launches at
+// E = 50 k and 48 at E = 300 k (170 / 450 us of every global-BA frame, profiles/r05_e_lc_timeline.txt).  Consecutive edges usually
+// share a bin (an append lists the 96 patches of a frame against one target, or one patch against 13 targets), so a run of equal
+// bins inside a wave issues ONE atomic for the whole run.
+// ---------------------------------------------------------------------------------------------------
+constexpr int64_t kWideMaxBins = (int64_t)1 << 22;
+
+struct WideArgs {
+  const int64_t *ii, *jj, *kk; int64_t E;
+  int nf, np;                           // promised: ii, jj in [0, nf), kk in [0, np)
+  int nbA, nbB, chunksA, chunksB;       // bins of the two orderings (np, nf * nf) and their 1024-bin chunks
+  int32_t* tot;                         // [nbA + nbB] per-bin counts (zeroed; counted down to zero again by the scatter), then the flag
+  int32_t* flag;                        // ids outside the promise were seen (-> counts[3])
+  int32_t* csum;                        // [chunksA + chunksB][2]: edges / non-empty bins of every chunk
+  int32_t *startA, *startB;             // [nbA + 1], [nbB + 1]: segment starts
+  int32_t *gidA, *gidB;                 // number of non-empty bins before a bin = its group index
+  uint32_t* tmpA_j; int32_t *tmpA_e, *tmpB_e;      // bin order before the ranking
+  int32_t *perm_k, *perm_p, *ku, *kx, *patch_off, *ix, *jx, *pu, *pair_off, *pair_ij, *counts, *flow;
+};
+
+__device__ __forceinline__ void wide_bins(const WideArgs& W, int64_t e, int& ba, int& bb, bool& bad) {
+  const int64_t k = W.kk[e], i = W.ii[e], j = W.jj[e];
+  bad = k < 0 || k >= W.np || i < 0 || i >= W.nf || j < 0 || j >= W.nf;
+  ba = (int)(k < 0 ? 0 : (k >= W.np ? W.np - 1 : k));
+  const int ic = (int)(i < 0 ? 0 : (i >= W.nf ? W.nf - 1 : i)), jc = (int)(j < 0 ? 0 : (j >= W.nf ? W.nf - 1 : j));
+  bb = ic * W.nf + jc;
+}
+
+// Runs of equal bins among the valid lanes of a wave (the valid lanes are a prefix of the wave): head = first lane of its run,
+// hl = the head lane of this lane's run, cnt = length of the run (meaningful in the head lane).  Every lane of the wave calls this.
+__device__ __forceinline__ void wave_runs(int bin, bool valid, int lane, bool& head, int& hl, int& cnt) {
+  const int prev = __shfl_up(bin, 1);
+  head = valid && (lane == 0 || prev != bin);
+  const unsigned long long heads = __ballot(head), vmask = __ballot(valid);
+  const unsigned long long upto = (2ull << lane) - 1;              // bits 0 .. lane (lane 63: all ones)
+  const unsigned long long below = heads & upto, above = heads & ~upto;
+  hl = below ? 63 - __clzll((long long)below) : 0;
+  const int nvalid = __popcll(vmask);
+  const int next = above ? __ffsll((long long)above) - 1 : nvalid;
+  cnt = next - lane;
+}
+
+__global__ __launch_bounds__(256) void wide_hist_kernel(WideArgs W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = e < W.E;
+  int ba = 0, bb = 0; bool bad = false;
+  if (valid) wide_bins(W, e, ba, bb, bad);
+  if (bad) *W.flag = 1;
+  bool head; int hl, cnt;
+  wave_runs(ba, valid, lane, head, hl, cnt);
+  if (head) atomicAdd(&W.tot[ba], cnt);
+  wave_runs(bb, valid, lane, head, hl, cnt);
+  if (head) atomicAdd(&W.tot[W.nbA + bb], cnt);
+}
+
+// edges and non-empty bins of every 1024-bin chunk (blockIdx.x < chunksA: by-patch bins, else pair bins)
+__global__ __launch_bounds__(1024) void wide_chunk_kernel(WideArgs W) {
+  __shared__ int32_t wsum[16], wocc[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int part = (int)blockIdx.x >= W.chunksA;
+  const int c = part ? (int)blockIdx.x - W.chunksA : (int)blockIdx.x;
+  const int nb = part ? W.nbB : W.nbA, b0 = part ? W.nbA : 0;
+  const int b = c * 1024 + t;
+  int32_t v = b < nb ? W.tot[b0 + b] : 0, o = v != 0;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) { v += __shfl_xor(v, s); o += __shfl_xor(o, s); }
+  if (lane == 0) { wsum[wv] = v; wocc[wv] = o; }
+  __syncthreads();
+  if (t == 0) {
+    int32_t a = 0, q = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a += wsum[k]; q += wocc[k]; }
+    W.csum[2 * blockIdx.x] = a; W.csum[2 * blockIdx.x + 1] = q;
+  }
+}
+
+// segment start and group index of every bin; the last bin of each ordering also writes the group count and the closing offset
+__global__ __launch_bounds__(1024) void wide_scan_kernel(WideArgs W) {
+  __shared__ int32_t wsum[16], wocc[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int part = (int)blockIdx.x >= W.chunksA;
+  const int c = part ? (int)blockIdx.x - W.chunksA : (int)blockIdx.x;
+  const int nb = part ? W.nbB : W.nbA, b0 = part ? W.nbA : 0;
+  if (blockIdx.x == 0 && t < 4) W.flow[t] = t < 2 ? -1 : 0;        // (no flow-test list from this builder)
+  // chunks of this ordering before this one
+  const int32_t* cs = W.csum + 2 * (part ? W.chunksA : 0);
+  int32_t pre = 0, preo = 0;
+  for (int q = t; q < c; q += 1024) { pre += cs[2 * q]; preo += cs[2 * q + 1]; }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) { pre += __shfl_xor(pre, s); preo += __shfl_xor(preo, s); }
+  if (lane == 0) { wsum[wv] = pre; wocc[wv] = preo; }
+  __syncthreads();
+  int32_t carry = 0, carryo = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { carry += wsum[k]; carryo += wocc[k]; }
+  __syncthreads();
+  const int b = c * 1024 + t;
+  const int32_t tot = b < nb ? W.tot[b0 + b] : 0;
+  int32_t x = tot, xo = tot != 0;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const int32_t y = __shfl_up(x, s), yo = __shfl_up(xo, s);
+    if (lane >= s) { x += y; xo += yo; }
+  }
+  if (lane == 63) { wsum[wv] = x; wocc[wv] = xo; }
+  __syncthreads();
+  int32_t wbase = 0, obase = 0;
+  for (int k = 0; k < wv; ++k) { wbase += wsum[k]; obase += wocc[k]; }
+  int32_t* start = part ? W.startB : W.startA;
+  if (b < nb) {
+    start[b] = carry + wbase + x - tot;
+    (part ? W.gidB : W.gidA)[b] = carryo + obase + xo - (tot != 0);
+  }
+  if (b == nb - 1) {
+    const int32_t ng = carryo + obase + xo, E = carry + wbase + x;
+    start[nb] = E;
+    (part ? W.pair_off : W.patch_off)[ng] = E;
+    W.counts[part] = ng;
+    if (part) { W.counts[2] = 0; W.counts[3] = *W.flag; }
+  }
+}
+
+__global__ __launch_bounds__(256) void wide_scatter_kernel(WideArgs W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = e < W.E;
+  int ba = 0, bb = 0; bool bad = false;
+  if (valid) wide_bins(W, e, ba, bb, bad);
+  bool head; int hl, cnt;
+  wave_runs(ba, valid, lane, head, hl, cnt);
+  int base = head ? atomicSub(&W.tot[ba], cnt) - cnt : 0;           // the run's slots inside the bin's segment: [base, base + cnt)
+  base = __shfl(base, hl);
+  if (valid) {
+    const int pa = W.startA[ba] + base + (lane - hl);
+    W.tmpA_j[pa] = (uint32_t)W.jj[e];
+    W.tmpA_e[pa] = (int32_t)e;
+  }
+  wave_runs(bb, valid, lane, head, hl, cnt);
+  base = head ? atomicSub(&W.tot[W.nbA + bb], cnt) - cnt : 0;
+  base = __shfl(base, hl);
+  if (valid) W.tmpB_e[W.startB[bb] + base + (lane - hl)] = (int32_t)e;
+}
+
+// thread p < E: position p of the by-patch order; thread E + p: position p of the by-pair order.  Every element ranks itself
+// inside its bin's segment ((jj, edge) resp. edge: a total order, so the ranks are a permutation of the segment) and writes the
+// group structures of its ordering; the first of a segment also writes the group's entry.
+__global__ __launch_bounds__(256) void wide_rank_kernel(WideArgs W) {
+  const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gt < W.E) {
+    const int32_t e = W.tmpA_e[gt];
+    const uint32_t key = W.tmpA_j[gt];
+    const int64_t kraw = W.kk[e];
+    const int k = (int)(kraw < 0 ? 0 : (kraw >= W.np ? W.np - 1 : kraw));
+    const int s = W.startA[k], t = W.startA[k + 1];
+    int rank = 0;
+    uint32_t pk = 0, nk = 0xffffffffu; int32_t pe = -1, ne = -1;          // closest element below / above in (jj, edge) order
+    for (int q = s; q < t; ++q) {
+      const uint32_t kq = W.tmpA_j[q];
+      const int32_t eq = W.tmpA_e[q];
+      const bool below = (kq < key) || (kq == key && eq < e);
+      const bool above = (kq > key) || (kq == key && eq > e);
+      rank += below;
+      if (below && (pe < 0 || kq > pk || (kq == pk && eq > pe))) { pk = kq; pe = eq; }
+      if (above && (ne < 0 || kq < nk || (kq == nk && eq < ne))) { nk = kq; ne = eq; }
+    }
+    int64_t pos = (int64_t)s + rank;
+    if (pos >= W.E) pos = W.E - 1;
+    W.perm_k[pos] = e;
+    W.ix[e] = pe; W.jx[e] = ne;
+    const int g = W.gidA[k];
+    W.ku[e] = g;
+    if (rank == 0) { W.kx[g] = (int32_t)kraw; W.patch_off[g] = s; }
+  } else if (gt < 2 * W.E) {
+    const int32_t e = W.tmpB_e[gt - W.E];
+    int ba, bb; bool bad;
+    wide_bins(W, e, ba, bb, bad);
+    const int s = W.startB[bb], t = W.startB[bb + 1];
+    int rank = 0;
+    for (int q = s; q < t; ++q) rank += W.tmpB_e[q] < e;
+    int64_t pos = (int64_t)s + rank;
+    if (pos >= W.E) pos = W.E - 1;
+    W.perm_p[pos] = e;
+    const int g = W.gidB[bb];
+    W.pu[e] = g;
+    if (rank == 0) {
+      W.pair_off[g] = s;
+      W.pair_ij[2 * g] = (int32_t)W.ii[e];
+      W.pair_ij[2 * g + 1] = (int32_t)W.jj[e];
+    }
+  }
+}
+
+struct WideWs { size_t tot, csum, startA, startB, gidA, gidB, tmpA_j, tmpA_e, tmpB_e, total; int nbA, nbB, chunksA, chunksB; };
+
+// 0 = ok, else the id ranges are outside what the wide build takes (the caller then uses the radix build)
+int wide_layout(int64_t E, int64_t n_frames, int64_t n_patch_ids, WideWs* L) {
+  if (E < 0 || E >= ((int64_t)1 << 30) || n_frames <= 0 || n_patch_ids <= 0 || n_frames > 2048 || n_patch_ids > kWideMaxBins ||
+      n_frames * n_frames > kWideMaxBins)
+    return 1;
+  const size_t n = (size_t)(E > 0 ? E : 1);
+  L->nbA = (int)n_patch_ids; L->nbB = (int)(n_frames * n_frames);
+  L->chunksA = (L->nbA + 1023) / 1024; L->chunksB = (L->nbB + 1023) / 1024;
+  size_t o = 0;
+  L->tot = o; o += align256(((size_t)L->nbA + L->nbB + 1) * 4);
+  L->csum = o; o += align256((size_t)(L->chunksA + L->chunksB) * 2 * 4);
+  L->startA = o; o += align256(((size_t)L->nbA + 1) * 4);
+  L->startB = o; o += align256(((size_t)L->nbB + 1) * 4);
+  L->gidA = o; o += align256((size_t)L->nbA * 4);
+  L->gidB = o; o += align256((size_t)L->nbB * 4);
+  L->tmpA_j = o; o += align256(n * 4);
+  L->tmpA_e = o; o += align256(n * 4);
+  L->tmpB_e = o; o += align256(n * 4);
+  L->total = o;
+  return 0;
+}
+
 // (sized for the 64-bit generic path; the 32-bit path uses a prefix of every buffer)
 int ws_layout(int64_t E, WsLayout* L) {
   size_t sort_bytes = 0, sort_bytes32 = 0;
@@ -561,6 +784,52 @@ extern "C" int dpvo_plan_build_window_job(const int64_t* ii, const int64_t* jj, 
   hipLaunchKernelGGL(win_scan_kernel, dim3(chunks_a + chunks_b), dim3(1024), 0, st, W, tiles, chunks_a);
   hipLaunchKernelGGL(win_scatter_kernel, dim3(tiles), dim3(1024), 0, st, W);
   hipLaunchKernelGGL(win_segsort_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, W);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" size_t dpvo_plan_wide_workspace_bytes(int64_t E, int64_t n_frames, int64_t n_patch_ids) {
+  WideWs L;
+  if (wide_layout(E, n_frames, n_patch_ids, &L) != 0) return 0;
+  return L.total;
+}
+
+extern "C" int dpvo_plan_build_wide(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
+                                    size_t ws_bytes, int64_t n_frames, int64_t n_patch_ids, void* stream) {
+  if (E < 0 || !plan || n_frames <= 0 || n_patch_ids <= 0) return DPVO_E_INVALID;
+  WideWs L;
+  if (wide_layout(E, n_frames, n_patch_ids, &L) != 0) return DPVO_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dpvo_plan_layout_t P;
+  dpvo_plan_layout(E, &P);
+  if (E == 0) {
+    hipError_t e = hipMemsetAsync(plan + P.counts, 0, 4 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(plan + P.flow, 0xff, 4 * sizeof(int32_t), st);       // (qi = qj = -1: no flow-test list)
+    return e == hipSuccess ? DPVO_OK : (int)e;
+  }
+  if (!ii || !jj || !kk || !ws) return DPVO_E_INVALID;
+  if (ws_bytes < L.total) return DPVO_E_WORKSPACE;
+  char* w = (char*)ws;
+  WideArgs W;
+  W.ii = ii; W.jj = jj; W.kk = kk; W.E = E;
+  W.nf = (int)n_frames; W.np = (int)n_patch_ids;
+  W.nbA = L.nbA; W.nbB = L.nbB; W.chunksA = L.chunksA; W.chunksB = L.chunksB;
+  W.tot = (int32_t*)(w + L.tot); W.flag = W.tot + (size_t)L.nbA + L.nbB;
+  W.csum = (int32_t*)(w + L.csum);
+  W.startA = (int32_t*)(w + L.startA); W.startB = (int32_t*)(w + L.startB);
+  W.gidA = (int32_t*)(w + L.gidA); W.gidB = (int32_t*)(w + L.gidB);
+  W.tmpA_j = (uint32_t*)(w + L.tmpA_j); W.tmpA_e = (int32_t*)(w + L.tmpA_e); W.tmpB_e = (int32_t*)(w + L.tmpB_e);
+  W.perm_k = plan + P.perm_k; W.perm_p = plan + P.perm_p;
+  W.ku = plan + P.ku; W.kx = plan + P.kx; W.patch_off = plan + P.patch_off; W.ix = plan + P.ix; W.jx = plan + P.jx;
+  W.pu = plan + P.pu; W.pair_off = plan + P.pair_off; W.pair_ij = plan + P.pair_ij; W.counts = plan + P.counts;
+  W.flow = plan + P.flow;
+  const int64_t nz = (int64_t)L.nbA + L.nbB + 1;
+  hipLaunchKernelGGL(win_zero_kernel, dim3((unsigned)cdiv64(nz, 1024)), dim3(1024), 0, st, W.tot, (int)nz);
+  hipLaunchKernelGGL(wide_hist_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, W);
+  hipLaunchKernelGGL(wide_chunk_kernel, dim3((unsigned)(L.chunksA + L.chunksB)), dim3(1024), 0, st, W);
+  hipLaunchKernelGGL(wide_scan_kernel, dim3((unsigned)(L.chunksA + L.chunksB)), dim3(1024), 0, st, W);
+  hipLaunchKernelGGL(wide_scatter_kernel, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, st, W);
+  hipLaunchKernelGGL(wide_rank_kernel, dim3((unsigned)cdiv64(2 * E, 256)), dim3(256), 0, st, W);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

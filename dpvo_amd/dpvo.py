@@ -31,6 +31,7 @@ _CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0"))
 # the frame start then just waits longer for the overlapped encoders, and the staging buffer of the keep list stays busy until
 # the update operator has run, which costs the host its lead (measured: 814 -> 809 frames/sec, +0.6 ms of host CPU per frame).
 _DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '0')))
+_GBA_CAT = bool(int(__import__('os').environ.get('DPVO_GBA_CAT', '0')))      # 1: the global BA's edge lists as five torch.cat (measurements)
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 # The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
 # DPVO_PLAN_ASYNC=1 its four small kernels + memsets are built on a third stream beside the correlation kernel instead of in
@@ -97,6 +98,7 @@ class DPVO:
         # whose weights are random (bench.py --drop-every, the bookkeeping tests): the flow magnitude means nothing there.
         self.keyframe_override = None
         self._loop_pairs_total = 0  # edges ever appended from outside the tracker's own bookkeeping (bounds the pair count of the global plan)
+        self._iota = None           # 0, 1, 2, ... on the device (identity gather of __run_global_BA)
         self._bound_watch = []      # plans built with host-side bounds whose exact counts are on their way back (_watch_plan_bounds)
         self._lr_active = 0         # long-range (loop-closure) edges in the active list: > 0 => update() owes a global BA (dpvo.py:348)
         self._enc_done_ev = None    # the side stream's "encoders done" events (two, alternating)
@@ -787,11 +789,23 @@ class DPVO:
     def __run_global_BA(self):
         """ Global bundle adjustment
          Includes both active and inactive edges """
-        full_target = torch.cat((self.pg.target_inac, self.pg.target), dim=1)
-        full_weight = torch.cat((self.pg.weight_inac, self.pg.weight), dim=1)
-        full_ii = torch.cat((self.pg.ii_inac, self.pg.ii))
-        full_jj = torch.cat((self.pg.jj_inac, self.pg.jj))
-        full_kk = torch.cat((self.pg.kk_inac, self.pg.kk))
+        # full_* = torch.cat((inactive, active)) of dpvo.py:315-319 without the five copies of the inactive store: the active edges are
+        # copied behind the inactive ones in the inactive store's own buffers (free space there; one launch), the lists are views
+        es, inac = self.pg.edges, self.pg.edges_inac
+        if _GBA_CAT:
+            full_target = torch.cat((self.pg.target_inac, self.pg.target), dim=1)
+            full_weight = torch.cat((self.pg.weight_inac, self.pg.weight), dim=1)
+            full_ii = torch.cat((self.pg.ii_inac, self.pg.ii))
+            full_jj = torch.cat((self.pg.jj_inac, self.pg.jj))
+            full_kk = torch.cat((self.pg.kk_inac, self.pg.kk))
+        else:
+            Ea, Ei = es.E, inac.E
+            inac.reserve(Ea)
+            if self._iota is None or self._iota.numel() < Ea:
+                self._iota = torch.arange(max(2 * Ea, 1 << 16), dtype=torch.int64, device=self.device)
+            es.gather_into(self._iota[:Ea], inac.a, Ei, skip_net=True)
+            full_ii, full_jj, full_kk = (inac.a[k][:Ei + Ea] for k in ("ii", "jj", "kk"))
+            full_target, full_weight = inac.a["target"][None, :Ei + Ea], inac.a["weight"][None, :Ei + Ea]
 
         self.pg.normalize()
         t0 = int(self.pg.edges.host()["ii"].min()) if self.pg.edges.mirror else self.pg.ii.min().item()      # (the host mirror: no device wait)
@@ -806,7 +820,7 @@ class DPVO:
             ub_p = min(E_all, self.n * self.M)
             ub_g = min(E_all, self.n * (2 * self.cfg.PATCH_LIFETIME + 2) + self._loop_pairs_total + self.n)
             plan = GraphPlan(full_ii.contiguous(), full_jj.contiguous(), full_kk.contiguous(), n_patches_ub=ub_p, n_pairs_ub=ub_g,
-                             n_frames=self.N, n_patch_ids=self.N * self.M)
+                             n_frames=self.N, n_patch_ids=self.N * self.M, wide=(self.n + 1, (self.n + 1) * self.M))
             self._watch_plan_bounds(plan, "global BA plan (active + inactive edges)")
             if _CHECK_MIRROR:
                 c = plan.counts.cpu().tolist()
@@ -868,8 +882,10 @@ class DPVO:
                 # counting-sort plan build (falls back to the radix build by itself when the window is too wide for it)
                 flo = max(0, self.n - (self.cfg.REMOVAL_WINDOW + self.cfg.PATCH_LIFETIME + 3))
                 window = (flo, self.n - flo, flo * self.M, (self.n - flo) * self.M)
+            # (no window -- long-range edges active, or exact plans: the ids are still below the frame count: wide counting build)
             build = lambda: GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
-                                      n_frames=self.N, n_patch_ids=self.N * self.M, window=window)
+                                      n_frames=self.N, n_patch_ids=self.N * self.M, window=window,
+                                      wide=None if window is not None else (self.n + 1, (self.n + 1) * self.M))
             if edges_ready is None or ub_p is None:       # (an exact plan reads its counts back: nothing to overlap)
                 self.plan_sync()
                 self._plan = build()

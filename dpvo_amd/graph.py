@@ -4,17 +4,22 @@ torch::_unique in cuda_ba (dpvo/fastba/ba_cuda.cu:447-449) and torch.unique in S
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib as L
 from . import workspace
+
+_PLAN_WIDE = bool(int(os.environ.get("DPVO_PLAN_WIDE", "1")))      # 0: measurements against the radix build (tools/lc_profile.py)
 
 
 class GraphPlan:
     """All views are int32 device tensors into one buffer; `counts` = [n_patches, n_pairs, 0, 0] stays on the
     device (no synchronisation); `n_patches()` / `n_pairs()` synchronise and are for tests / host logic only."""
 
-    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None, n_frames=0, n_patch_ids=0, window=None, flow_pair=None):
+    def __init__(self, ii, jj, kk, n_patches_ub=None, n_pairs_ub=None, n_frames=0, n_patch_ids=0, window=None, flow_pair=None,
+                 wide=None):
         L.require_cuda(ii, jj, kk)
         assert ii.dtype == jj.dtype == kk.dtype == torch.long
         E = ii.numel()
@@ -27,7 +32,13 @@ class GraphPlan:
         ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
         self._keep = (ii, jj, kk)
         nbytes = L.lib().dpvo_plan_workspace_bytes(L.i64(E))
-        ws = workspace.get(nbytes, ii.device, "plan")
+        # wide = (n_frames, n_patch_ids): the caller guarantees ii, jj < n_frames and kk < n_patch_ids with n_frames of the order of the
+        # tracker's frame count (not BUFFER_SIZE) -> bins-in-memory counting build (dpvo_plan_build_wide: 6 launches instead of the
+        # radix build's 16-48); ranges it does not take fall back to the radix build
+        wide_bytes = 0
+        if wide is not None and window is None and E > 0 and _PLAN_WIDE:
+            wide_bytes = L.lib().dpvo_plan_wide_workspace_bytes(L.i64(E), L.i64(wide[0]), L.i64(wide[1]))
+        ws = workspace.get(max(nbytes, wide_bytes), ii.device, "plan")
         # window = (frame_lo, n_frames_win, patch_lo, n_patches_win): the caller guarantees that all frame / patch ids lie in
         # these windows -> counting-sort build (dpvo_plan_build_window); falls back when the windows are too large for it
         rc = -2
@@ -40,6 +51,13 @@ class GraphPlan:
                                                      L.i64(window[3]), L.i64(qi), L.i64(qj), L.stream())
             if rc != -2:
                 L.check(rc, "dpvo_plan_build_window")
+        self.wide = False
+        if rc == -2 and wide_bytes:
+            rc = L.lib().dpvo_plan_build_wide(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),
+                                              ctypes.c_size_t(ws.numel()), L.i64(wide[0]), L.i64(wide[1]), L.stream())
+            if rc != -2:
+                L.check(rc, "dpvo_plan_build_wide")
+                self.wide = True
         # n_frames / n_patch_ids: optional bounds on the index values (BUFFER_SIZE, BUFFER_SIZE * PATCHES_PER_FRAME): 32-bit keys
         if rc == -2:
             L.check(L.lib().dpvo_plan_build_ranged(L.ptr(ii), L.ptr(jj), L.ptr(kk), L.i64(E), L.ptr(self.buf), L.ptr(ws),

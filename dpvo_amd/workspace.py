@@ -20,6 +20,11 @@ def get(nbytes, device, tag="default"):
     key = (device.type, idx, stream if _PER_STREAM else 0, tag)
     buf = _bufs.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        # grown geometrically: the global BA's scratch (edge records, E blocks, the plan's sort buffers) grows with the inactive edge
+        # store by a few KB EVERY frame that runs it, and a buffer sized exactly is a fresh hipMalloc of 15-100 MB each time -- the
+        # caching allocator cannot serve a larger request from the block just released
+        grow = 0 if buf is None else buf.numel() + buf.numel() // 2
+        _bufs[key] = buf = None                 # (release first: the old block can then back the new request's neighbours)
+        buf = torch.empty(max(int(nbytes), grow, 1 << 20), dtype=torch.uint8, device=device)
         _bufs[key] = buf
     return buf

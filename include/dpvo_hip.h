@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version: bumped on ANY change of a signature, a struct layout or the exported set (round 3 changed all three without a
  * bump: ADVICE r3).  The Python binding refuses a library whose version differs from the one it was written against. */
-#define DPVO_ABI_VERSION 6
+#define DPVO_ABI_VERSION 7
 int dpvo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -187,6 +187,19 @@ int dpvo_plan_build_window(const int64_t* ii, const int64_t* jj, const int64_t* 
 int dpvo_plan_build_window_flow(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
                                 size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo, int64_t n_patches_win,
                                 int64_t qi, int64_t qj, void* stream);
+
+/* Same plan when the ids are bounded by the tracker's frame count only (every ii, jj in [0, n_frames), every kk in [0, n_patch_ids)):
+ * what DPVO.update builds while long-range loop-closure edges are active and what DPVO.__run_global_BA builds over all active +
+ * inactive edges (dpvo.py:312-326,345-354; the reference re-derives these groupings with torch.unique / fastba.neighbors per call).
+ * One bin per patch id and per (i, j) pair in memory, integer-atomic histogram, scan, placement, then every element ranks itself
+ * inside its bin by (jj, edge) resp. edge: the stable sorts' result bit for bit, 6 launches instead of the radix build's 16-48.
+ * Limits: n_frames <= 2048, n_patch_ids <= 2^22, E < 2^30, else DPVO_E_UNSUPPORTED (use dpvo_plan_build_ranged); the work is
+ * proportional to sum over bins of (bin size)^2, i.e. meant for graphs whose patches / frame pairs hold tens to hundreds of edges.
+ * Ids outside the promise are clamped (memory safe, plan contents then unspecified) and reported in counts[3] = 1.
+ * ws: dpvo_plan_wide_workspace_bytes(E, n_frames, n_patch_ids) bytes (0 = unsupported ranges). */
+size_t dpvo_plan_wide_workspace_bytes(int64_t E, int64_t n_frames, int64_t n_patch_ids);
+int dpvo_plan_build_wide(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int32_t* plan, void* ws,
+                         size_t ws_bytes, int64_t n_frames, int64_t n_patch_ids, void* stream);
 
 /* cuda_ba.neighbors(kk, jj) -- ba.cpp:59-97,187: int64 outputs for API parity (device resident). */
 size_t dpvo_neighbors_workspace_bytes(int64_t E);

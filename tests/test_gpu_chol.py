@@ -73,6 +73,20 @@ def test_solve_is_bit_repeatable(dev):
         assert torch.equal(a, _solve(S, y, dev))
 
 
+@pytest.mark.parametrize("n", [6, 65, 300, 630, 768])
+def test_one_launch_back_substitution_is_bit_identical(dev, n, monkeypatch):
+    """chol_back_all_kernel (one launch of one workgroup for up to 12 block columns: the bench leg's global BA) against the
+    launch-per-column back substitution it replaces there (DPVO_CHOL_BACK_STEPS=1): the same operations in the same order"""
+    S, y = _spd(n, seed=100 + n)
+    monkeypatch.delenv("DPVO_CHOL_BACK_STEPS", raising=False)
+    a = _solve(S, y, dev)
+    monkeypatch.setenv("DPVO_CHOL_BACK_STEPS", "1")
+    b = _solve(S, y, dev)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    monkeypatch.delenv("DPVO_CHOL_BACK_STEPS", raising=False)
+    assert torch.equal(a, _solve(S, y, dev))
+
+
 def test_not_positive_definite_gives_nan_not_a_hang(dev):
     S, y = _spd(130, seed=1)
     S[70, 70] = -50.0

@@ -79,7 +79,7 @@ def test_reproject_flow_points(oracle, dev):
     H.assert_close(co2[0].cpu().numpy()[(ok & front).numpy()], ref[(ok & front).numpy()], 5e-3, 1e-4, "cuda_ba.reproject")
 
 
-@pytest.mark.parametrize("ranged", [False, True, "window"])
+@pytest.mark.parametrize("ranged", [False, True, "window", "wide"])
 @pytest.mark.parametrize("case", ["replay40", "small", "shuffled", "single", "empty", "tiles"])
 def test_plan_bit_exact(oracle, dev, case, ranged):
     if case == "replay40":
@@ -110,9 +110,21 @@ def test_plan_bit_exact(oracle, dev, case, ranged):
         plo = int(kk.min()); npw = int(kk.max()) + 1 - plo
         assert nfw * nfw <= 2048 and npw <= 4096, "test graphs are meant to fit the window path"
         rng["window"] = (flo, nfw, plo, npw)
+    if ranged == "wide" and E:
+        # wide: ids bounded by the frame count only -> bins-in-memory counting build (dpvo_plan_build_wide), same plan bit for bit
+        rng["wide"] = (int(max(ii.max(), jj.max())) + 1, int(kk.max()) + 1)
     plan = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev), **rng)
     if ranged == "window" and E:
         assert plan.counts.cpu().tolist()[3] == 0
+    if ranged == "wide" and E:
+        assert plan.wide and plan.counts.cpu().tolist()[2:] == [0, 0]
+        radix = GraphPlan(ii.to(dev), jj.to(dev), kk.to(dev))
+        ng, npair = radix.n_patches(), radix.n_pairs()
+        assert plan.counts.cpu().tolist()[:2] == [ng, npair]
+        for name, cnt in (("perm_k", E), ("ku", E), ("kx", ng), ("patch_off", ng + 1), ("ix", E), ("jx", E), ("perm_p", E), ("pu", E),
+                          ("pair_off", npair + 1), ("pair_ij", 2 * npair)):
+            assert torch.equal(getattr(plan, name)[:cnt], getattr(radix, name)[:cnt]), name
+        assert plan.flow.cpu().tolist()[:4] == radix.flow.cpu().tolist()[:4] == [-1, -1, 0, 0]
     if E == 0:
         assert plan.n_patches() == 0 and plan.n_pairs() == 0
         return
@@ -165,6 +177,44 @@ def test_plan_window_reports_ids_outside_the_window(dev):
     for name in ("perm_k", "ku", "ix", "jx", "perm_p", "pu"):
         assert torch.equal(getattr(wide, name), getattr(good, name)), name
     assert wide.counts.cpu().tolist()[:2] == good.counts.cpu().tolist()[:2]
+
+
+def test_plan_wide_at_global_ba_size_and_outside_ids(dev):
+    """dpvo_plan_build_wide at the size of the global BA's plan (active + inactive edges of a 110-frame run with loop-closure edges,
+    duplicates included): every array equal to the radix build's; ids outside the promised ranges are clamped (no out-of-bounds
+    access) and flagged in counts[3]; ranges it does not take fall back to the radix build by themselves"""
+    ii, jj, kk = S.replay_graph(110)
+    g = torch.Generator().manual_seed(11)
+    # loop-closure edges: all patches of 40 old frames against recent frames, some of them twice (re-added in a later round)
+    src = torch.randint(0, 60, (40,), generator=g); dst = torch.randint(95, 110, (40,), generator=g)
+    lk = (src[:, None] * 96 + torch.arange(96)[None]).reshape(-1); lj = dst[:, None].expand(-1, 96).reshape(-1)
+    ii = torch.cat([ii, lk // 96, lk[:960] // 96]); jj = torch.cat([jj, lj, lj[:960]]); kk = torch.cat([kk, lk, lk[:960]])
+    p = torch.randperm(ii.numel(), generator=g)
+    ii, jj, kk = ii[p], jj[p], kk[p]
+    # ... with a stretch in append order (runs of equal bins inside a wave take the one-atomic-per-run path)
+    a, b, c = S.replay_graph(20)
+    ii = torch.cat([ii, a]); jj = torch.cat([jj, b]); kk = torch.cat([kk, c])
+    E = ii.numel()
+    d = lambda t: t.to(dev)
+    radix = GraphPlan(d(ii), d(jj), d(kk), n_frames=4096, n_patch_ids=4096 * 96)
+    wide = GraphPlan(d(ii), d(jj), d(kk), n_patches_ub=E, n_pairs_ub=E, wide=(111, 111 * 96))
+    assert wide.wide and not radix.wide
+    ng, npair = radix.n_patches(), radix.n_pairs()
+    assert wide.counts.cpu().tolist() == [ng, npair, 0, 0]
+    for name, cnt in (("perm_k", E), ("ku", E), ("kx", ng), ("patch_off", ng + 1), ("ix", E), ("jx", E), ("perm_p", E), ("pu", E),
+                      ("pair_off", npair + 1), ("pair_ij", 2 * npair)):
+        assert torch.equal(getattr(wide, name)[:cnt], getattr(radix, name)[:cnt]), name
+    again = GraphPlan(d(ii), d(jj), d(kk), n_patches_ub=E, n_pairs_ub=E, wide=(111, 111 * 96))
+    for name, cnt in (("perm_k", E), ("ix", E), ("jx", E), ("perm_p", E)):
+        assert torch.equal(getattr(again, name)[:cnt], getattr(wide, name)[:cnt]), "the wide build must not depend on atomic order"
+    bad = GraphPlan(d(ii), d(jj), d(kk), n_patches_ub=E, n_pairs_ub=E, wide=(100, 100 * 96))
+    torch.cuda.synchronize()
+    assert bad.wide and bad.counts.cpu().tolist()[3] == 1
+    assert int(bad.perm_k.min()) >= 0 and int(bad.perm_k.max()) < E and int(bad.perm_p.min()) >= 0 and int(bad.perm_p.max()) < E
+    far = GraphPlan(d(ii), d(jj), d(kk), wide=(4096, 4096 * 96))            # 4096^2 pair bins: -> dpvo_plan_build_ranged
+    assert not far.wide
+    for name in ("perm_k", "ku", "ix", "jx", "perm_p", "pu"):
+        assert torch.equal(getattr(far, name), getattr(radix, name)), name
 
 
 def test_plan_flow_list_and_flow_test_bits(dev):
