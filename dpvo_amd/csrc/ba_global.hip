@@ -176,10 +176,17 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
         int v[kMaxPer], r[kMaxPer];
 #pragma unroll
         for (int a = 0; a < kMaxPer; ++a) { v[a] = lane + 64 * a < n ? L[lane + 64 * a] : 0x7fffffff; r[a] = 0; }
-        for (int b = 0; b < n; ++b) {
-          const int x = L[b];                                      // (uniform address: one broadcast load)
+        // every entry against the whole list, handed from register to register (v_readlane with a running lane number).  As broadcast
+        // LOADS of L[b] this loop was a dependent memory round trip per entry -- most of the kernel's 68 us at N = 105
+        // (profiles/r05_e_lc_timeline.txt)
 #pragma unroll
-          for (int a = 0; a < kMaxPer; ++a) r[a] += x < v[a];
+        for (int a2 = 0; a2 < kMaxPer; ++a2) {
+          const int nn = n - 64 * a2 < 64 ? n - 64 * a2 : 64;
+          for (int l = 0; l < nn; ++l) {
+            const int x = __builtin_amdgcn_readlane(v[a2], l);
+#pragma unroll
+            for (int a = 0; a < kMaxPer; ++a) r[a] += x < v[a];
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();                           // every lane has read the whole list before anyone overwrites it
