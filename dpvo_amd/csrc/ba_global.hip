@@ -217,6 +217,9 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
 // alternative: the frame's blocks staged in LDS + the row in an LDS strip, 16 waves: slower (two barriers and a 64 KB copy per
 // source frame); the atomics version this replaces: 0.28 ms.)  `S` and `y` must be zero on entry.
 constexpr int kRowWaves = 16;
+#ifndef GBA_BV_REG
+#define GBA_BV_REG 1      // 0: the B / v part as one read-modify-write chain per pair (rounds 4-5; tools/gba_bv_ab.sh builds it for the comparison)
+#endif
 #ifdef GBA_TRACE
 // instrumentation build (tools/gba_trace.sh): wave 0 of the workgroup of the middle pose stamps the 100 MHz wall clock
 __device__ unsigned long long gba_trace_buf[96];
@@ -249,6 +252,85 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   const bool own = frj >= 0 && frj < n_frames;
   const int ja = own ? run_lo[frj] : 0, jb = own ? run_lo[frj + 1] : 0;
   // ---- B and v (ba_cuda.cu:335-349,363-368): pairs with source j, then pairs with target j, ascending pair index each
+#if GBA_BV_REG
+  // Round 5 (last session).  The two loops used to be one dependent chain per pair for EVERY wave of the row: the pair's target (loop 1)
+  // resp. the list entry, then the pair's source (loop 2) loaded one at a time just to find out whose column it is, and the diagonal
+  // block and y[p] read-modify-written in memory once per pair -- ~60 pairs x 2-3 round trips in front of the Schur terms.  Now the
+  // indices come 64 at a time into the lanes and are handed out with readlane; the diagonal block and y[p] accumulate in registers in
+  // the same order (S and y are zero on entry: 0 + a + b ... is what the read-modify-writes formed) and are written once; an
+  // off-diagonal block of loop 1 is a plain store of 0 - b (zero on entry, the pairs of a source frame have distinct targets), its
+  // mirror update in loop 2 stays a read-modify-write by the same wave, in program order; the self pair (j, j) of the frame's own edges
+  // updates the diagonal block from both loops, in the register.  Same operations per entry, same order.
+  {
+    const bool dwave = wave == (p % kRowCls);
+    const bool dl = dwave && lane < 36, yl = wave == 0 && lane < 6;
+    float dacc = 0.f, yacc = 0.f;
+    for (int g0 = ja; g0 < jb; g0 += 64) {
+      const int gl = g0 + lane;
+      const int jx_l = gl < jb ? pair_ij[2 * gl + 1] - t0 : -1;
+      const int cnt = jb - g0 < 64 ? jb - g0 : 64;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float dv[4], yv4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                              // (the loads of four pairs in flight; the sums below stay in pair order)
+          const float* pb = pairbuf + (int64_t)(g0 + i0 + u) * kPairStride;
+          const bool on = i0 + u < cnt;
+          dv[u] = (on && dl) ? pb[r36 * 16 + c36] : 0.f;
+          yv4[u] = (on && yl) ? pb[lane * 16 + 12] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u < cnt) {
+            const int jx = __builtin_amdgcn_readlane(jx_l, i0 + u);
+            if (dl) dacc += dv[u];
+            if (yl) yacc -= yv4[u];
+            if (jx >= 0 && jx < N && wave == (jx % kRowCls) && lane < 36) {
+              const float* pb = pairbuf + (int64_t)(g0 + i0 + u) * kPairStride;
+              const float b = pb[r36 * 16 + 6 + c36];
+              if (jx == p) dacc -= b;                              // a self pair (j, j): its "off-diagonal" block IS the diagonal one
+              else Srow[(int64_t)r36 * n6 + 6 * jx + c36] = 0.f - b;
+            }
+          }
+        }
+      }
+    }
+    for (int q0 = tl0; q0 < tl1; q0 += 64) {
+      const int ql_ = q0 + lane;
+      const int g_l = ql_ < tl1 ? tgt_list[ql_] : 0;
+      const int ix_l = ql_ < tl1 ? pair_ij[2 * g_l] - t0 : -1;
+      const int cnt = tl1 - q0 < 64 ? tl1 - q0 : 64;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float dv[4], yv4[4];
+        int gg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool on = i0 + u < cnt;
+          gg[u] = __builtin_amdgcn_readlane(g_l, on ? i0 + u : 0);
+          const float* pb = pairbuf + (int64_t)gg[u] * kPairStride;
+          dv[u] = (on && dl) ? pb[(6 + r36) * 16 + 6 + c36] : 0.f;
+          yv4[u] = (on && yl) ? pb[(6 + lane) * 16 + 12] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u < cnt) {
+            const int ix = __builtin_amdgcn_readlane(ix_l, i0 + u);
+            if (dl) dacc += dv[u];
+            if (yl) yacc += yv4[u];
+            if (ix >= 0 && ix < N && wave == (ix % kRowCls) && lane < 36) {
+              const float* pb = pairbuf + (int64_t)gg[u] * kPairStride;
+              const float b = pb[c36 * 16 + 6 + r36];                               // mirror of block (ix, p)
+              if (ix == p) dacc -= b;
+              else Srow[(int64_t)r36 * n6 + 6 * ix + c36] -= b;
+            }
+          }
+        }
+      }
+    }
+    // (blocks this row never touches stay zero; the diagonal block and y[p] always exist)
+    if (dl) Srow[(int64_t)r36 * n6 + 6 * p + c36] = dacc;
+    if (yl) y[6 * p + lane] = yacc;
+  }
+#else
   for (int g = ja; g < jb; ++g) {
     const float* pb = pairbuf + (int64_t)g * kPairStride;
     const int jx = pair_ij[2 * g + 1] - t0;
@@ -264,6 +346,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
     if (ix >= 0 && ix < N && wave == (ix % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * ix + c36] -= pb[c36 * 16 + 6 + r36];   // mirror of block (ix, p)
     if (wave == 0 && lane < 6) y[6 * p + lane] += pb[(6 + lane) * 16 + 12];
   }
+#endif
   // ---- Schur terms: every source frame f that has a block with pose p -- the sources of the target list, and j itself (its
   //      self block; a pair (j, j) of self edges is in the target list too) -- in ascending f
   GT(1);

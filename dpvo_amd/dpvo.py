@@ -31,6 +31,7 @@ _CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0"))
 # the frame start then just waits longer for the overlapped encoders, and the staging buffer of the keep list stays busy until
 # the update operator has run, which costs the host its lead (measured: 814 -> 809 frames/sec, +0.6 ms of host CPU per frame).
 _DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '0')))
+_COMPOSITE_LR = bool(int(__import__('os').environ.get('DPVO_COMPOSITE_LR', '1')))   # 0: frame state entry by entry while long-range edges are active (measurements)
 _GBA_CAT = bool(int(__import__('os').environ.get('DPVO_GBA_CAT', '0')))      # 1: the global BA's edge lists as five torch.cat (measurements)
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 # The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
@@ -417,10 +418,17 @@ class DPVO:
                                         i, j, beta=0.5, plan=self._plan, defer=True, host_buf=host)
         # while the GPU is still busy with this frame: the removal mask of the common case (keyframe kept), on the host
         es = self.pg.edges
-        to_remove = self._removal_mask(es.host())
+        h = es.host()
+        to_remove = self._removal_mask(h)
         staged = self._stage_removal(to_remove, True)
         forced = None if self.keyframe_override is None else bool(self.keyframe_override(self.counter))
-        return m_pending, to_remove, staged, forced
+        # ... and the number of long-range edges that removal leaves active (what _keyframe_finish used to count AFTER the removal,
+        # replaying the mirror's compaction -- three 50 k-entry gathers on the host -- between the flow test's read-back and the next
+        # frame's first launch, with the GPU idle)
+        lr_after = None
+        if self.cfg.LOOP_CLOSURE or self._lr_active > 0:
+            lr_after = int(np.count_nonzero((h["ii"] < self.n - self.cfg.REMOVAL_WINDOW) & ~to_remove))
+        return m_pending, to_remove, staged, forced, lr_after
 
     def flush(self):
         """apply a deferred keyframe decision (no-op otherwise)"""
@@ -440,7 +448,7 @@ class DPVO:
         else:
             self._keyframe_finish(*pending)
 
-    def _keyframe_finish(self, m_pending, to_remove, staged, forced=None):
+    def _keyframe_finish(self, m_pending, to_remove, staged, forced=None, lr_after=None):
         es = self.pg.edges
         m_ij, m_ji = m_pending()            # the one host read-back of the frame
         m = m_ij + m_ji
@@ -492,7 +500,7 @@ class DPVO:
             self.n -= 1
             self.m -= self.M
             self._plan = None
-            to_remove, staged = self._removal_mask(es.host()), None
+            to_remove, staged, lr_after = self._removal_mask(es.host()), None, None
 
         self.remove_factors(to_remove, store=True, staged=staged)
         if self.cfg.LOOP_CLOSURE or self._lr_active > 0:
@@ -500,7 +508,9 @@ class DPVO:
             # next frame counted (n + 1) they satisfy ii < n - REMOVAL_WINDOW - 1 of dpvo.py:348.  (Also without LOOP_CLOSURE once a
             # caller has appended old patches through append_factors(): the removal above has dropped them, the count returns to 0
             # and with it the window plan / the one-call path -- ADVICE r4: it used to stick)
-            self._lr_active = int(np.count_nonzero(es.host()["ii"] < self.n - self.cfg.REMOVAL_WINDOW))
+            self._lr_active = lr_after if lr_after is not None else int(np.count_nonzero(es.host()["ii"] < self.n - self.cfg.REMOVAL_WINDOW))
+            if _CHECK_MIRROR:
+                assert self._lr_active == int(np.count_nonzero(es.host()["ii"] < self.n - self.cfg.REMOVAL_WINDOW)), "long-range count diverged"
         if _CHECK_MIRROR:       # tests: the host mirror must track the device arrays exactly
             h = es.host()
             for k in ("ii", "jj", "kk"):
@@ -1121,8 +1131,11 @@ class DPVO:
             if self.cfg.LOOP_CLOSURE and self.is_initialized and (n + 1) - self.last_global_ba >= self.cfg.GLOBAL_OPT_FREQ:
                 self._loop_try = self.pg.edges_loop(n=n + 1)
             loop_found = self._loop_try is not None and self._loop_try[0].numel() > 0
-            composite = (self.is_initialized and not loop_found and self._lr_active == 0 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR'
-                         and n > 1 and 3 * self.M * self.P * self.P <= 4096)
+            # (also while long-range edges are active: the frame then takes the call-by-call path -- _frame_call_ok() is false -- but its
+            #  state stores and its own edges are still the one dpvo_frame_state call; only a frame that appends loop edges, which go in
+            #  FRONT of its own, issues the entries one by one)
+            composite = (self.is_initialized and not loop_found and (self._lr_active == 0 or _COMPOSITE_LR)
+                         and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' and n > 1 and 3 * self.M * self.P * self.P <= 4096)
             fac = None
             if n > 1 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':
                 a, b, c = ([1, 1, 1] + self.tlist[-3:])[-3:]          # (the last three time stamps, padded with 1 like the reference's [1]*3 + tlist)

@@ -16,8 +16,12 @@ VARIANTS = [
     ("radix plans (DPVO_PLAN_WIDE=0)", {"DPVO_PLAN_WIDE": "0"}),
     ("five torch.cat (DPVO_GBA_CAT=1)", {"DPVO_GBA_CAT": "1"}),
     ("back substitution per column (DPVO_CHOL_BACK_STEPS=1)", {"DPVO_CHOL_BACK_STEPS": "1"}),
-    ("all three switched back", {"DPVO_PLAN_WIDE": "0", "DPVO_GBA_CAT": "1", "DPVO_CHOL_BACK_STEPS": "1"}),
+    ("frame state entry by entry (DPVO_COMPOSITE_LR=0)", {"DPVO_COMPOSITE_LR": "0"}),
+    ("all four switched back", {"DPVO_PLAN_WIDE": "0", "DPVO_GBA_CAT": "1", "DPVO_CHOL_BACK_STEPS": "1", "DPVO_COMPOSITE_LR": "0"}),
 ]
+_BV0 = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_bv0.so")          # tools/gba_bv_ab.sh build: the row kernel's B / v part of rounds 4-5
+if os.path.exists(_BV0):
+    VARIANTS.insert(5, ("row kernel's B / v part as a read-modify-write chain (libdpvo_hip_bv0.so)", {"DPVO_HIP_LIB": _BV0}))
 CHILD = r"""
 import json, sys, torch
 sys.path.insert(0, %r)
@@ -47,12 +51,12 @@ def main():
         for name, env in VARIANTS:
             d = run(env)
             res[name].append(d.get("frames_per_sec"))
-            print(f"run {r}  {name:58s} {d.get('frames_per_sec')} frames/sec  global BAs {d.get('global_ba_runs')}  finite {d.get('finite')}"
+            print(f"run {r}  {name:86s} {d.get('frames_per_sec')} frames/sec  global BAs {d.get('global_ba_runs')}  finite {d.get('finite')}"
                   + (f"  ERROR {d.get('error')}" if d.get("error") else ""), flush=True)
     print()
     for name, _ in VARIANTS:
         v = [x for x in res[name] if x]
-        print(f"{name:58s} mean {sum(v) / max(len(v), 1):7.1f} frames/sec over {len(v)} runs  {v}")
+        print(f"{name:86s} mean {sum(v) / max(len(v), 1):7.1f} frames/sec over {len(v)} runs  {v}")
     for name, env in (VARIANTS[0], VARIANTS[-1]):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lc_profile.py")], env=dict(os.environ, LC_SYNC="1", **env),
                              capture_output=True, text=True, timeout=600)
