@@ -21,6 +21,7 @@ SYMBOLS = [
     "dpvo_abi_version",
     "dpvo_corr_forward", "dpvo_corr_pyramid_forward", "dpvo_patchify_forward", "dpvo_patchify_bilinear",
     "dpvo_reproject", "dpvo_flow_mag", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud", "dpvo_point_cloud_motionmag",
+    "dpvo_normalize_scratch_bytes", "dpvo_normalize",
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window", "dpvo_plan_build_window_flow",
     "dpvo_plan_wide_workspace_bytes", "dpvo_plan_build_wide",
@@ -112,7 +113,7 @@ def lib():
         for s in SYMBOLS:
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
-        for s in ("dpvo_plan_workspace_bytes", "dpvo_plan_wide_workspace_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
+        for s in ("dpvo_plan_workspace_bytes", "dpvo_plan_wide_workspace_bytes", "dpvo_normalize_scratch_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
                   "dpvo_gba_workspace_bytes", "dpvo_gba_solve_workspace_bytes", "dpvo_encoders_workspace_bytes",
                   "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
             getattr(L, s).restype = ctypes.c_size_t

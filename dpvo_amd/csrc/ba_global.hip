@@ -91,11 +91,25 @@ __global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32
   const int np = *n_patches;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < np; k += gridDim.x * blockDim.x) {
     float C = 0.f, u = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0};
-    for (int p = patch_off[k]; p < patch_off[k + 1]; ++p) {
-      const float* eb = edgebuf + (int64_t)perm_k[p] * kEdgeStride;
-      C += eb[0]; u += eb[1];
+    // four edges' records in flight (edge number, then its two 16-byte loads); the sums stay in list order.  One edge at a time this
+    // loop was two dependent round trips per edge, ~28 edges per patch at the global BA's size: 44 us of every linearisation
+    const int p0 = patch_off[k], p1 = patch_off[k + 1];
+    for (int pb_ = p0; pb_ < p1; pb_ += 4) {
+      int e4[4];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) Ei[a] += eb[2 + a];
+      for (int v = 0; v < 4; ++v) e4[v] = pb_ + v < p1 ? perm_k[pb_ + v] : 0;
+      f4 r0[4], r1[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f4* eb = reinterpret_cast<const f4*>(edgebuf + (int64_t)e4[v] * kEdgeStride);
+        r0[v] = eb[0]; r1[v] = eb[1];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (pb_ + v < p1) {
+          C += r0[v][0]; u += r0[v][1];
+          Ei[0] += r0[v][2]; Ei[1] += r0[v][3]; Ei[2] += r1[v][0]; Ei[3] += r1[v][1]; Ei[4] += r1[v][2]; Ei[5] += r1[v][3];
+        }
     }
     const int patch = kx[k];
     const int fr = patch / M - f0, slot = patch % M;
@@ -217,6 +231,9 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
 // alternative: the frame's blocks staged in LDS + the row in an LDS strip, 16 waves: slower (two barriers and a 64 KB copy per
 // source frame); the atomics version this replaces: 0.28 ms.)  `S` and `y` must be zero on entry.
 constexpr int kRowWaves = 16;
+#ifndef GBA_TILE96
+#define GBA_TILE96 1     // 0: the tile's operands 48 slots at a time whatever M (rounds 4-5)
+#endif
 #ifndef GBA_BV_REG
 #define GBA_BV_REG 1      // 0: the B / v part as one read-modify-write chain per pair (rounds 4-5; tools/gba_bv_ab.sh builds it for the comparison)
 #endif
@@ -359,25 +376,46 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   // the list's metadata -- pair, its source frame, that frame's pair run -- for 64 entries at a time in the lanes (three round trips per
   // 64 frames instead of three per frame), handed out with readlane
   int qbase = tl0 - 64, m_g = -1, m_f = 0x7fffffff, m_g0 = 0, m_g1 = 0;
-  while (q < tl1 || !self_done) {
-    GT(2 + it_); ++it_;
-    if (q < tl1 && q - qbase >= 64) {
-      qbase = q;
-      const int qi_ = q + lane;
-      m_g = qi_ < tl1 ? tgt_list[qi_] : -1;
-      m_f = m_g >= 0 ? pair_ij[2 * m_g] : 0x7fffffff;
-      const int mfr = m_f - f0;
-      const bool fin = m_g >= 0 && mfr >= 0 && mfr < n_frames;
-      m_g0 = fin ? run_lo[mfr] : 0; m_g1 = fin ? run_lo[mfr + 1] : 0;
+  // the next source frame with patches: the frame, its pair run and, if it comes from the list, its pair with p
+  auto advance = [&](int& f, int& ga_, int& g0, int& g1) -> bool {
+    while (q < tl1 || !self_done) {
+      if (q < tl1 && q - qbase >= 64) {
+        qbase = q;
+        const int qi_ = q + lane;
+        m_g = qi_ < tl1 ? tgt_list[qi_] : -1;
+        m_f = m_g >= 0 ? pair_ij[2 * m_g] : 0x7fffffff;
+        const int mfr = m_f - f0;
+        const bool fin = m_g >= 0 && mfr >= 0 && mfr < n_frames;
+        m_g0 = fin ? run_lo[mfr] : 0; m_g1 = fin ? run_lo[mfr + 1] : 0;
+      }
+      const int ql = __builtin_amdgcn_readfirstlane(q < tl1 ? q - qbase : 0);
+      const int gq = q < tl1 ? __builtin_amdgcn_readlane(m_g, ql) : -1;
+      const int fq = gq >= 0 ? __builtin_amdgcn_readlane(m_f, ql) : 0x7fffffff;
+      if (!self_done && j <= fq) { f = j; ga_ = (fq == j) ? gq : -1; self_done = true; if (fq == j) ++q; g0 = ja; g1 = jb; }
+      else { f = fq; ga_ = gq; ++q; g0 = __builtin_amdgcn_readlane(m_g0, ql); g1 = __builtin_amdgcn_readlane(m_g1, ql); }
+      const int fr_ = f - f0;
+      if (fr_ < 0 || fr_ >= n_frames) continue;
+      return true;
     }
-    int f, ga_, g0, g1;                                            // the next frame, its pair run and, if it comes from the list, its pair
-    const int ql = __builtin_amdgcn_readfirstlane(q < tl1 ? q - qbase : 0);
-    const int gq = q < tl1 ? __builtin_amdgcn_readlane(m_g, ql) : -1;
-    const int fq = gq >= 0 ? __builtin_amdgcn_readlane(m_f, ql) : 0x7fffffff;
-    if (!self_done && j <= fq) { f = j; ga_ = (fq == j) ? gq : -1; self_done = true; if (fq == j) ++q; g0 = ja; g1 = jb; }
-    else { f = fq; ga_ = gq; ++q; g0 = __builtin_amdgcn_readlane(m_g0, ql); g1 = __builtin_amdgcn_readlane(m_g1, ql); }
+    return false;
+  };
+  // the target poses of 64 of a frame's blocks (its pairs g0 .. g1, then its self block), one per lane, -1 beyond the last
+  auto fetch = [&](int f, int g0, int g1, int b0) -> int {
+    const int bl_ = b0 + lane, P_ = g1 - g0;
+    return bl_ <= P_ ? (bl_ < P_ ? pair_ij[2 * (g0 + bl_) + 1] : f) - t0 : -1;
+  };
+  // Round 5 (last session): the frame loop is software pipelined by one frame -- the NEXT frame is picked and the targets of its
+  // blocks are requested before this frame's tiles run, so that a frame no longer starts with a memory round trip of its own (the
+  // rows of the loop-closure targets walk ~100 source frames, profiles/README.md round 5).
+  int f = 0, ga_ = -1, g0 = 0, g1 = 0;
+  bool have = advance(f, ga_, g0, g1);
+  int pbl0 = have ? fetch(f, g0, g1, 0) : -1;
+  while (have) {
+    GT(2 + it_); ++it_;
+    int nf_ = 0, nga_ = -1, ng0_ = 0, ng1_ = 0;
+    const bool nhave = advance(nf_, nga_, ng0_, ng1_);
+    const int npbl0 = nhave ? fetch(nf_, ng0_, ng1_, 0) : -1;
     const int fr = f - f0;
-    if (fr < 0 || fr >= n_frames) continue;
     const int P = g1 - g0;
     const float* Qf = Q + (int64_t)fr * M;
     const float* Uf = U + (int64_t)fr * M;
@@ -400,18 +438,30 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
         const bool rl = rhs && li == 12;
         f4 acc = {0.f, 0.f, 0.f, 0.f};
         // the row's current values travel with the operands (the read-modify-write's read is not a round trip of its own)
+        // (the lane's up to four entries D[4 lk + r][li], r < nr, lie one row of S -- or one element of y -- apart: one pointer + a stride)
         float cur[4] = {0.f, 0.f, 0.f, 0.f};
-        float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 4 * lk + r;
-          if (i < 6) {
-            if (li < 6) { if (Eb0) dst[r] = Srow + (int64_t)i * n6 + 6 * pb0 + li; }
-            else if (li < 12) { if (Eb1) dst[r] = Srow + (int64_t)i * n6 + 6 * pb1 + (li - 6); }
-            else if (rl) dst[r] = y + 6 * p + i;
-          }
-          if (dst[r]) cur[r] = *dst[r];
+        const int nr = lk == 0 ? 4 : (lk == 1 ? 2 : 0);            // rows 4 lk + r < 6
+        float* d0 = nullptr;
+        if (nr) {
+          if (li < 6) { if (Eb0) d0 = Srow + (int64_t)(4 * lk) * n6 + 6 * pb0 + li; }
+          else if (li < 12) { if (Eb1) d0 = Srow + (int64_t)(4 * lk) * n6 + 6 * pb1 + (li - 6); }
+          else if (rl) d0 = y + 6 * p + 4 * lk;
         }
+        const int64_t dstride = li < 12 ? n6 : 1;
+#if GBA_TILE96
+        {
+          // (loaded by every lane, from somewhere readable when the lane has no entry: straight-line code, so that these loads and the
+          //  operands' below are issued back to back -- behind a branch each the compiler waited for them group by group)
+          const float* cs = d0 ? d0 : Srow;
+          const int64_t cst = d0 ? dstride : 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cur[r] = cs[(r < nr ? r : 0) * cst];
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (d0 && r < nr) cur[r] = d0[r * dstride];
+#endif
         // operands: the blocks are stored component-major ([6][M]), so a lane's operands of FOUR chain steps are one 16-byte load: in
         // step (u, c) the four k-lanes of the tile take the slots 16 u + 4 lk + c.  48 slots per trip: 9 loads in flight, then 12
         // MFMAs.  (Slot-major blocks meant 72 four-byte gathers per tile and wave; a CU's 16 waves push them through one texture
@@ -430,6 +480,29 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
         };
         const float* arow = Ea + (int64_t)(li < 6 ? li : 0) * M;
         const float* brow = Eb ? Eb + (int64_t)cj * M : (rl ? Uf : nullptr);
+#if GBA_TILE96
+        // M = 96 (default.yaml's PATCHES_PER_FRAME): all 18 operand loads of the tile in flight at once, then the 24 MFMAs in the same
+        // order -- one memory round trip per tile instead of one per 48 slots
+        if (M == 96) {
+          // (no zeroing of the lanes that carry no operand: row i of D depends on row i of A only and column j on column j of B only, and
+          //  the rows / columns such lanes feed are never stored -- they only need an address that can be read: row 0 of e_a, Q for B)
+          f4 a4[6], b4[6], q4[6];
+          const float* bs = brow ? brow : Qf;
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int s_ = 16 * u + 4 * lk;
+            a4[u] = *reinterpret_cast<const f4*>(arow + s_);
+            q4[u] = *reinterpret_cast<const f4*>(Qf + s_);
+            b4[u] = *reinterpret_cast<const f4*>(bs + s_);
+          }
+          __builtin_amdgcn_sched_barrier(0);                         // (all 18 + 4 loads in flight before the first MFMA: the scheduler otherwise
+                                                                     //  sinks two thirds of them between the MFMAs to save registers)
+#pragma unroll
+          for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][c], q4[u][c] * b4[u][c], acc, 0, 0, 0);
+        } else
+#endif
         for (int s0 = 0; s0 < M; s0 += 48) {
           f4 a4[3], b4[3], q4[3];
 #pragma unroll
@@ -447,13 +520,12 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)                                  // acc[r] = D[4 lk + r][li]
-          if (dst[r]) *dst[r] = cur[r] - acc[r];
+          if (d0 && r < nr) d0[r * dstride] = cur[r] - acc[r];
       };
       bool rhs_due = wave == 0;                                      // right-hand side: y[p] -= sum_slot Q u e_a, once per (f, which)
       for (int b0 = 0; b0 <= P; b0 += 64) {
         const int bl_ = b0 + lane;
-        int pbl = -1;
-        if (bl_ <= P) pbl = (bl_ < P ? pair_ij[2 * (g0 + bl_) + 1] : f) - t0;
+        const int pbl = b0 == 0 ? pbl0 : fetch(f, g0, g1, b0);
         unsigned long long todo = __ballot(bl_ <= P && pbl >= 0 && pbl < N && (pbl % kRowCls) == wave);
         while (todo) {
           const int bit0 = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
@@ -481,6 +553,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
       }
       if (rhs_due) tile(nullptr, 0, nullptr, 0, true);
     }
+    f = nf_; ga_ = nga_; g0 = ng0_; g1 = ng1_; pbl0 = npbl0; have = nhave;
   }
   GT(90);
 #ifdef GBA_TRACE
@@ -517,12 +590,31 @@ __global__ __launch_bounds__(128) void gba_retr_kernel(float* __restrict__ poses
 #pragma unroll
       for (int r = 0; r < 6; ++r) s += e[(int64_t)r * M] * dX[6 * ix + r];
     }
-    for (int g = ga; g < gb; ++g) {
-      const int jx = pair_ij[2 * g + 1] - t0;
-      if (jx < 0 || jx >= N) continue;
-      const float* e = Ecol + (int64_t)g * 6 * M + slot;
+    // four pairs in flight: their targets and E entries first, then the targets' steps; the products are added in pair order as before
+    // (pair by pair the loop was two dependent round trips for each of a frame's ~30-40 pairs)
+    for (int g0 = ga; g0 < gb; g0 += 4) {
+      int jx4[4];
+      float e4[4][6], d4[4][6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) s += e[(int64_t)r * M] * dX[6 * jx + r];
+      for (int v = 0; v < 4; ++v) {
+        const int g = g0 + v < gb ? g0 + v : ga;
+        jx4[v] = g0 + v < gb ? pair_ij[2 * g + 1] - t0 : -1;
+        const float* e = Ecol + (int64_t)g * 6 * M + slot;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) e4[v][r] = e[(int64_t)r * M];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const bool on = jx4[v] >= 0 && jx4[v] < N;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d4[v][r] = on ? dX[6 * jx4[v] + r] : 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (jx4[v] >= 0 && jx4[v] < N) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) s += e4[v][r] * d4[v][r];
+        }
     }
     const int64_t o = (int64_t)fr * M + slot;
     const float dZ = Q[o] * (U[o] - s);

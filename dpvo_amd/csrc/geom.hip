@@ -192,7 +192,74 @@ inline unsigned grid_for(int64_t n) {
   return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
 
+// PatchGraph.normalize (patchgraph.py:84-90) as two launches instead of eight torch kernels (a 43 us strided reduction among them,
+// profiles/r05_e_lc_timeline.txt): scale = mean of the depth channel of the first n frames' patches, depths /= scale, translations
+// *= scale, every pose multiplied from the right by the inverse of (the scaled) pose 0.
+//   normalize_sum_kernel    per-block partial sums of the depths in f64 (fixed order: bit-repeatable), and a copy of pose 0
+//   normalize_apply_kernel  every block adds the partials up in block order (the same scale everywhere), then takes its share
+// scratch: [0] = scale (f32), [1..7] = pose 0 as it was, then the partial sums as doubles from byte 64 on.
+constexpr int kNormBlocks = 256;
+__global__ __launch_bounds__(1024) void normalize_sum_kernel(const float* __restrict__ poses, const float* __restrict__ patches, int64_t total,
+                                                             int PP, float* __restrict__ scratch) {
+  __shared__ double red[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  double acc = 0.0;
+  for (int64_t q = (int64_t)blockIdx.x * 1024 + t; q < total; q += (int64_t)gridDim.x * 1024) {
+    const int64_t k = q / PP; const int a = (int)(q - k * PP);
+    acc += (double)patches[(k * 3 + 2) * PP + a];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double b = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b += red[i];
+    reinterpret_cast<double*>(scratch + 16)[blockIdx.x] = b;
+  }
+  if (blockIdx.x == 0 && t < 7) scratch[1 + t] = poses[t];
+}
+
+__global__ __launch_bounds__(1024) void normalize_apply_kernel(float* __restrict__ poses, float* __restrict__ patches, int n, int64_t total,
+                                                               int PP, int nblk_sum, float* __restrict__ scratch) {
+  const int t = threadIdx.x;
+  double sum = 0.0;
+  for (int b = 0; b < nblk_sum; ++b) sum += reinterpret_cast<const double*>(scratch + 16)[b];      // (uniform: every thread the same order)
+  const float s = (float)(sum / (double)total);
+  if (blockIdx.x == 0 && t == 0) scratch[0] = s;
+  for (int64_t q = (int64_t)blockIdx.x * 1024 + t; q < total; q += (int64_t)gridDim.x * 1024) {
+    const int64_t k = q / PP; const int a = (int)(q - k * PP);
+    float* d = patches + (k * 3 + 2) * PP + a;
+    *d = *d / s;
+  }
+  // poses_[:n] = SE3(poses_[:n] with t *= s) * SE3(poses_[0] with t *= s).inv()
+  Pose X0 = load_pose(scratch + 1);
+  X0.t.x *= s; X0.t.y *= s; X0.t.z *= s;
+  Pose I0 = se3_inv(X0);
+  I0.q = qnormalize(I0.q);                                         // (as a stored inverse read back by the product: se3.h:34 normalises on construction)
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + t; i < n; i += (int64_t)gridDim.x * 1024) {
+    Pose X = load_pose(poses + 7 * i);
+    X.t.x *= s; X.t.y *= s; X.t.z *= s;
+    store_pose(poses + 7 * i, se3_mul(X, I0));
+  }
+}
+
 }  // namespace
+
+extern "C" size_t dpvo_normalize_scratch_bytes(void) { return 64 + kNormBlocks * sizeof(double); }
+
+extern "C" int dpvo_normalize(float* poses, float* patches, int n, int M, int P, float* scratch, void* stream) {
+  if (n <= 0 || M <= 0 || P <= 0 || !poses || !patches || !scratch) return DPVO_E_INVALID;
+  const int PP = P * P;
+  const int64_t total = (int64_t)n * M * PP;
+  const int64_t g = cdiv64(total, 1024);
+  const int nb = (int)(g > kNormBlocks ? kNormBlocks : g);
+  hipLaunchKernelGGL(normalize_sum_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, poses, patches, total, PP, scratch);
+  hipLaunchKernelGGL(normalize_apply_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, poses, patches, n, total, PP, nb, scratch);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
 
 #define SE3_ENTRY(name, kernel, ...)                                                              \
   if (n < 0) return DPVO_E_INVALID;                                                               \

@@ -13,6 +13,8 @@ from . import projective_ops as pops
 from .lietorch import SE3
 from .utils import flatmeshgrid
 
+_NORMALIZE_FUSED = bool(int(__import__("os").environ.get("DPVO_NORMALIZE_FUSED", "1")))     # 0: PatchGraph.normalize as torch operations (measurements)
+
 
 class EdgeStore:
     """Preallocated per-edge arrays (ii, jj, kk int64; net f32 [.,D]; target, weight f32 [.,2]) with an element count.
@@ -347,6 +349,7 @@ class PatchGraph:
         self.intrinsics_ = torch.zeros(self.N, 4, dtype=torch.float, device=dev)
 
         self.points_ = torch.zeros(self.N * self.M, 3, dtype=torch.float, device=dev)
+        self._norm_scratch = None   # dpvo_normalize's scratch (scale, pose 0, partial sums)
         self.colors_ = torch.zeros(self.N, self.M, 3, dtype=torch.uint8, device=dev)
 
         self.index_ = torch.zeros(self.N, self.M, dtype=torch.long, device=dev)
@@ -431,6 +434,17 @@ class PatchGraph:
 
     def normalize(self):
         """normalize depth and poses (patchgraph.py:84-95)"""
+        if _NORMALIZE_FUSED and self.patches_.dtype == torch.float32 and self.patches_.is_contiguous() and self.poses_.is_contiguous():
+            # the mean, both rescalings and the re-anchoring on pose 0 as two launches (dpvo_normalize), the point cloud as a third
+            if self._norm_scratch is None:
+                self._norm_scratch = torch.zeros(L.lib().dpvo_normalize_scratch_bytes() // 4, dtype=torch.float32, device=self.poses_.device)
+            L.check(L.lib().dpvo_normalize(L.ptr(self.poses_), L.ptr(self.patches_), L.i32(self.n), L.i32(self.M), L.i32(self.patches_.shape[-1]),
+                                           L.ptr(self._norm_scratch), L.stream()), "dpvo_normalize")
+            s = self._norm_scratch[0]
+            for t, (t0, dP) in self.delta.items():
+                self.delta[t] = (t0, dP.scale(s))
+            pops.point_cloud(self.poses, self.patches[:, :self.m], self.intrinsics, self.ix[:self.m], out=self.points_)
+            return
         s = self.patches_[:self.n, :, 2].mean()
         self.patches_[:self.n, :, 2] /= s
         self.poses_[:self.n, :3] *= s

@@ -129,6 +129,14 @@ int dpvo_point_cloud_motionmag(const float* poses, const float* patches, const f
 int dpvo_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
                      float* points, int64_t m, int P, void* stream);
 
+/* PatchGraph.normalize (patchgraph.py:84-90; caller DPVO.__run_global_BA, dpvo.py:321): s = mean depth of the first n frames'
+ * patches (patches [.,M,3,P,P], channel 2, all P*P entries), depths /= s, translations *= s, poses[:n] = poses[:n] * poses[0]^-1.
+ * Two launches (the reference: a strided torch reduction + seven elementwise / lietorch launches); the mean is summed in f64 in
+ * a fixed order.  scratch: dpvo_normalize_scratch_bytes() bytes, 8-byte aligned; scratch[0] = s afterwards (for the caller's
+ * PatchGraph.delta rescaling, patchgraph.py:88-89).  The point cloud refresh of patchgraph.py:92-94 is dpvo_point_cloud. */
+size_t dpvo_normalize_scratch_bytes(void);
+int dpvo_normalize(float* poses, float* patches, int n, int M, int P, float* scratch, void* stream);
+
 /* lietorch_backends.{inv,mul,act4,expm,logm}(group_id=3, ...) -- lietorch.cpp:286-316, SE3 forward
  * only (lietorch_gpu.cu:21-30,47-56,73-82,101-110,225-236; se3.h, so3.h).  f32, n elements. */
 int dpvo_se3_inv(const float* X, float* Y, int64_t n, void* stream);

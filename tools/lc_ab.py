@@ -14,14 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [
     ("product", {}),
     ("radix plans (DPVO_PLAN_WIDE=0)", {"DPVO_PLAN_WIDE": "0"}),
-    ("five torch.cat (DPVO_GBA_CAT=1)", {"DPVO_GBA_CAT": "1"}),
-    ("back substitution per column (DPVO_CHOL_BACK_STEPS=1)", {"DPVO_CHOL_BACK_STEPS": "1"}),
+    ("PatchGraph.normalize as torch operations (DPVO_NORMALIZE_FUSED=0)", {"DPVO_NORMALIZE_FUSED": "0"}),
     ("frame state entry by entry (DPVO_COMPOSITE_LR=0)", {"DPVO_COMPOSITE_LR": "0"}),
-    ("all four switched back", {"DPVO_PLAN_WIDE": "0", "DPVO_GBA_CAT": "1", "DPVO_CHOL_BACK_STEPS": "1", "DPVO_COMPOSITE_LR": "0"}),
+    ("all switches back", {"DPVO_PLAN_WIDE": "0", "DPVO_GBA_CAT": "1", "DPVO_CHOL_BACK_STEPS": "1", "DPVO_COMPOSITE_LR": "0",
+                           "DPVO_NORMALIZE_FUSED": "0"}),
 ]
-_BV0 = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_bv0.so")          # tools/gba_bv_ab.sh build: the row kernel's B / v part of rounds 4-5
+if os.environ.get("LC_AB_ALL"):        # the two switches that measured within the noise (profiles/r05_f_lc_ab.txt)
+    VARIANTS[3:3] = [("five torch.cat (DPVO_GBA_CAT=1)", {"DPVO_GBA_CAT": "1"}),
+                     ("back substitution per column (DPVO_CHOL_BACK_STEPS=1)", {"DPVO_CHOL_BACK_STEPS": "1"})]
+_BV0 = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_bv0.so")          # tools/gba_bv_ab.sh build: the row kernel of rounds 4-5
 if os.path.exists(_BV0):
-    VARIANTS.insert(5, ("row kernel's B / v part as a read-modify-write chain (libdpvo_hip_bv0.so)", {"DPVO_HIP_LIB": _BV0}))
+    VARIANTS.insert(len(VARIANTS) - 1, ("row kernel of rounds 4-5 (libdpvo_hip_bv0.so)", {"DPVO_HIP_LIB": _BV0}))
+    VARIANTS[-1] = (VARIANTS[-1][0] + " + that row kernel", dict(VARIANTS[-1][1], DPVO_HIP_LIB=_BV0))
 CHILD = r"""
 import json, sys, torch
 sys.path.insert(0, %r)
