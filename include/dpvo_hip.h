@@ -502,7 +502,8 @@ int dpvo_pool4_nhwc(const void* in, void* out, int h, int w, int C, void* stream
  *     dpvo_gba_retract(dX) -> dZ = Q (u - E^T dX), depth and pose retraction in place.
  * f0 / n_frames: first source frame that owns a patch in kk and the number of frames up to the last one
  * (patch p belongs to frame p / M); M = patches per frame (PPF); plan from dpvo_plan_build(ii,jj,kk);
- * the same `ws` (dpvo_gba_workspace_bytes) must be passed to both calls of one iteration. */
+ * the same `ws` (dpvo_gba_workspace_bytes) must be passed to both calls of one iteration (dpvo_gba_retract reads Q, u, the E
+ * blocks and the pair run of every source frame that the linearisation left there, for the same f0 / n_frames / t0 / t1). */
 size_t dpvo_gba_workspace_bytes(int64_t E, int64_t n_pairs, int64_t n_frames, int M, int64_t n_free);   /* n_free = t1 - t0 */
 int dpvo_gba_linearize(const float* poses, const float* patches, const float* intrinsics, const float* target,
                        const float* weight, float lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk,
