@@ -219,9 +219,9 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
   }
 }
 
-// Block row p of S and y[p] (see the file header).  grid (N, split), 1024 threads = 16 waves: the 16 * split waves of a row
+// Block row p of S and y[p] (see the file header).  N * split workgroups (1-D launch, XCD-major numbering: top of the kernel), 1024 threads = 16 waves: the 16 * split waves of a row
 // each own the column blocks whose pose q has q % (16 * split) == their number; wave 0 of the first workgroup also owns y.
-// split = gridDim.y is chosen by the launcher so that every workgroup of the launch is resident at once (a 1 024-thread workgroup
+// split is chosen by the launcher so that every workgroup of the launch is resident at once (a 1 024-thread workgroup
 // of this kernel takes a CU): 4 for N <= 64, 2 for N <= 128, else 1.  (Round 4's first rule -- 4 up to 128, 2 up to 400 -- put 396
 // workgroups on 256 CUs at N = 99: a second round started 150 us in, tools/gba_trace.sh; linearise + Schur 1.02 -> 0.80 ms there.)
 // A wave finds ITS blocks of a source frame with one 64-wide fetch of the frame's targets and a ballot (it used to read the targets
@@ -231,6 +231,9 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
 // alternative: the frame's blocks staged in LDS + the row in an LDS strip, 16 waves: slower (two barriers and a 64 KB copy per
 // source frame); the atomics version this replaces: 0.28 ms.)  `S` and `y` must be zero on entry.
 constexpr int kRowWaves = 16;
+#ifndef GBA_XCD
+#define GBA_XCD 1        // 0: workgroup b = (pose, part) number b (rounds 4-5)
+#endif
 #ifndef GBA_TILE96
 #define GBA_TILE96 1     // 0: the tile's operands 48 slots at a time whatever M (rounds 4-5)
 #endif
@@ -242,7 +245,7 @@ constexpr int kRowWaves = 16;
 __device__ unsigned long long gba_trace_buf[96];
 __device__ unsigned long long gba_wg_buf[4096][3];     // start, end, source frames walked -- of every workgroup (pose x split)
 __device__ unsigned int gba_wave_buf[1024][16][2];     // per wave: ticks from the workgroup's start to the wave's end, blocks it owned
-#define GT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x == (int)gridDim.x / 2 && (i) < 96) gba_trace_buf[i] = wall_clock64(); } while (0)
+#define GT(i) do { if (threadIdx.x == 0 && part_ == 0 && p == N / 2 && (i) < 96) gba_trace_buf[i] = wall_clock64(); } while (0)
 #else
 #define GT(i) do {} while (0)
 #endif
@@ -251,16 +254,28 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
                                                       const int32_t* __restrict__ tgt_list, const float* __restrict__ pairbuf,
                                                       const float* __restrict__ Q, const float* __restrict__ U,
                                                       const float* __restrict__ Ecol, const float* __restrict__ Eself, int M,
-                                                      int f0, int n_frames, int t0, int N, float* __restrict__ S,
+                                                      int f0, int n_frames, int t0, int N, int split, float* __restrict__ S,
                                                       float* __restrict__ y) {
-  const int p = blockIdx.x, j = p + t0;
+  // Workgroup -> (pose, part).  The launch is 1-D; workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md), so the b-th
+  // workgroup of an XCD takes logical index xcd * chunk + b / 8: the parts of a row and the rows of neighbouring poses -- which read
+  // the blocks of the same ~40 source frames, 3-4 MB: an XCD's L2 -- share an XCD instead of being dealt out round robin over all
+  // eight (the E blocks, 13 MB at the bench leg's size, then come from the Infinity Cache at twice the latency).  Placement only:
+  // every entry is still written by the same wave in the same order.
+#if GBA_XCD
+  const int chunk_ = ((int)gridDim.x + 7) / 8;
+  const int lidx_ = ((int)blockIdx.x % 8) * chunk_ + (int)blockIdx.x / 8;
+#else
+  const int lidx_ = (int)blockIdx.x;
+#endif
+  if (lidx_ >= N * split) return;
+  const int p = lidx_ / split, part_ = lidx_ - p * split, j = p + t0;
   GT(0);
 #ifdef GBA_TRACE
-  const int wg_ = (int)blockIdx.x * (int)gridDim.y + (int)blockIdx.y;
+  const int wg_ = lidx_;
   if (threadIdx.x == 0 && wg_ < 4096) gba_wg_buf[wg_][0] = wall_clock64();
 #endif
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) + kRowWaves * (int)blockIdx.y);
-  const int kRowCls = kRowWaves * (int)gridDim.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) + kRowWaves * part_);
+  const int kRowCls = kRowWaves * split;
   const int64_t n6 = 6 * (int64_t)N;
   const int r36 = lane / 6, c36 = lane - 6 * r36;                  // (lanes 0..35: entry (r36, c36) of a 6 x 6 block)
   float* Srow = S + (int64_t)(6 * p) * n6;
@@ -560,7 +575,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   if (lane == 0 && wg_ < 1024) { gba_wave_buf[wg_][threadIdx.x >> 6][0] = (unsigned int)(wall_clock64() - wstart_); gba_wave_buf[wg_][threadIdx.x >> 6][1] = nblk_; }
   __syncthreads();
   if (threadIdx.x == 0 && wg_ < 4096) { gba_wg_buf[wg_][1] = wall_clock64(); gba_wg_buf[wg_][2] = it_; }
-  if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x == (int)gridDim.x / 2) gba_trace_buf[95] = it_;
+  if (threadIdx.x == 0 && part_ == 0 && p == N / 2) gba_trace_buf[95] = it_;
 #endif
 }
 
@@ -691,8 +706,12 @@ static int gba_linearize_impl(const float* poses, const float* patches, const fl
                      edgebuf, Ecol, M);
   hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
                      plan + PL.patch_off, plan + PL.kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself);
-  hipLaunchKernelGGL(gba_row_kernel, dim3((unsigned)N, N <= 64 ? 4u : (N <= 128 ? 2u : 1u)), dim3(64 * kRowWaves), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
-                     pairbuf, Q, U, Ecol, Eself, M, f0, n_frames, t0, N, S, y);
+  {
+    const int split = N <= 64 ? 4 : (N <= 128 ? 2 : 1);
+    const unsigned nwg = (unsigned)((N * split + 7) / 8 * 8);       // (a multiple of 8: the XCD-major numbering of the kernel is a bijection on it)
+    hipLaunchKernelGGL(gba_row_kernel, dim3(nwg), dim3(64 * kRowWaves), 0, st, plan + PL.pair_ij, n_pairs, run_lo, tgt_off, tgt_list,
+                       pairbuf, Q, U, Ecol, Eself, M, f0, n_frames, t0, N, split, S, y);
+  }
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

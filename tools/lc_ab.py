@@ -24,8 +24,12 @@ if os.environ.get("LC_AB_ALL"):        # the two switches that measured within t
                      ("back substitution per column (DPVO_CHOL_BACK_STEPS=1)", {"DPVO_CHOL_BACK_STEPS": "1"})]
 _BV0 = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_bv0.so")          # tools/gba_bv_ab.sh build: the row kernel of rounds 4-5
 if os.path.exists(_BV0):
-    VARIANTS.insert(len(VARIANTS) - 1, ("row kernel of rounds 4-5 (libdpvo_hip_bv0.so)", {"DPVO_HIP_LIB": _BV0}))
-    VARIANTS[-1] = (VARIANTS[-1][0] + " + that row kernel", dict(VARIANTS[-1][1], DPVO_HIP_LIB=_BV0))
+    _LBL = os.environ.get("LC_AB_LIB_LABEL", "row kernel of rounds 4-5")
+    VARIANTS.insert(len(VARIANTS) - 1, (_LBL + " (libdpvo_hip_bv0.so)", {"DPVO_HIP_LIB": _BV0}))
+    VARIANTS[-1] = (VARIANTS[-1][0] + " + " + _LBL, dict(VARIANTS[-1][1], DPVO_HIP_LIB=_BV0))
+if os.environ.get("LC_AB_ONLY"):       # comma-separated substrings of the variant names to keep
+    keep = [k.strip() for k in os.environ["LC_AB_ONLY"].split(",")]
+    VARIANTS = [v for v in VARIANTS if any(k in v[0] for k in keep)]
 CHILD = r"""
 import json, sys, torch
 sys.path.insert(0, %r)
@@ -61,7 +65,7 @@ def main():
     for name, _ in VARIANTS:
         v = [x for x in res[name] if x]
         print(f"{name:86s} mean {sum(v) / max(len(v), 1):7.1f} frames/sec over {len(v)} runs  {v}")
-    for name, env in (VARIANTS[0], VARIANTS[-1]):
+    for name, env in ((VARIANTS[0], VARIANTS[-1]) if not os.environ.get("LC_AB_ONLY") else ()):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lc_profile.py")], env=dict(os.environ, LC_SYNC="1", **env),
                              capture_output=True, text=True, timeout=600)
         for line in out.stdout.splitlines():
