@@ -23,6 +23,9 @@
 //   dpvo_gba_solve       S += I*(1e-4*S+1); blocked Cholesky + both substitutions on the device (chol.hip)
 //   gba_retr_kernel      dZ = Q (u - e^T dX), depth + pose retraction
 #include "ba_common.h"
+#ifndef GBA_FUSE_SP
+#define GBA_FUSE_SP 1     // 0: gba_scatter_kernel and gba_patch_kernel as two launches (rounds 3-5)
+#endif
 
 namespace {
 using namespace ba;
@@ -49,32 +52,40 @@ inline void gba_layout(int64_t E, int64_t n_pairs, int64_t n_frames, int M, int6
 }
 
 // Ecol[pair][kk[e] % M][0..5] = sum over the pair's edges e with that slot of Ej_e, in list order (perm_p is the stable sort by
-// (ii, jj): ascending edge number inside a pair).  One block per pair; the slots of a chunk of 128 edges go through LDS.
-__global__ __launch_bounds__(128) void gba_scatter_kernel(const int64_t* __restrict__ kk, const int32_t* __restrict__ perm_p,
-                                                          const int32_t* __restrict__ pair_off, const int32_t* __restrict__ n_pairs,
-                                                          const float* __restrict__ edgebuf, float* __restrict__ Ecol, int M) {
-  __shared__ int sl[128];
-  __shared__ int se[128];
-  const int ng = *n_pairs, t = threadIdx.x;
-  for (int g = blockIdx.x; g < ng; g += gridDim.x) {
-    const int p0 = pair_off[g], p1 = pair_off[g + 1];
+// (ii, jj): ascending edge number inside a pair).  128 threads per pair, a thread per patch slot; the slots of a chunk of 128 edges go
+// through LDS.  `half` of `nhalf` 128-thread groups share a workgroup (the fused launch below runs two pairs per 256-thread
+// workgroup): every group runs `nch` chunk steps -- the larger count of the workgroup's pairs -- because the barriers are the
+// workgroup's; a group whose pair has fewer chunks (or no pair at all: g >= ng) idles through the surplus steps.
+__device__ __forceinline__ void gba_scatter_body(const int64_t* __restrict__ kk, const int32_t* __restrict__ perm_p,
+                                                 const int32_t* __restrict__ pair_off, const int32_t* __restrict__ n_pairs,
+                                                 const float* __restrict__ edgebuf, float* __restrict__ Ecol, int M, int bid, int nblk,
+                                                 int nhalf, int (*sl)[128], int (*se)[128]) {
+  const int ng = *n_pairs, half = (int)threadIdx.x >> 7, t = (int)threadIdx.x & 127;
+  for (int gb = bid * nhalf; gb < ng; gb += nblk * nhalf) {            // (uniform over the workgroup)
+    const int g = gb + half;
+    const bool on = g < ng;
+    const int p0 = on ? pair_off[g] : 0, p1 = on ? pair_off[g + 1] : 0;
+    int nch = 0;                                                       // chunk steps of the workgroup = the largest of its pairs'
+    for (int h = 0; h < nhalf; ++h)
+      if (gb + h < ng) { const int len = pair_off[gb + h + 1] - pair_off[gb + h]; const int c = (len + 127) >> 7; nch = c > nch ? c : nch; }
     for (int s0 = 0; s0 < M; s0 += 128) {
       const int slot = s0 + t;
       float acc[6] = {0, 0, 0, 0, 0, 0};
-      for (int c0 = p0; c0 < p1; c0 += 128) {
+      for (int ch = 0; ch < nch; ++ch) {
+        const int c0 = p0 + 128 * ch;
         __syncthreads();
-        if (c0 + t < p1) { const int e = perm_p[c0 + t]; se[t] = e; sl[t] = (int)(kk[e] % M); } else sl[t] = -1;
+        if (c0 + t < p1) { const int e = perm_p[c0 + t]; se[half][t] = e; sl[half][t] = (int)(kk[e] % M); } else sl[half][t] = -1;
         __syncthreads();
-        const int nq = p1 - c0 < 128 ? p1 - c0 : 128;
+        const int nq = p1 - c0 < 128 ? p1 - c0 : 128;                  // (<= 0 for a group that is past its pair's last chunk)
         if (slot < M)
           for (int q = 0; q < nq; ++q)
-            if (sl[q] == slot) {
-              const float* eb = edgebuf + (int64_t)se[q] * kEdgeStride + 8;
+            if (sl[half][q] == slot) {
+              const float* eb = edgebuf + (int64_t)se[half][q] * kEdgeStride + 8;
 #pragma unroll
               for (int a = 0; a < 6; ++a) acc[a] += eb[a];
             }
       }
-      if (slot < M) {
+      if (on && slot < M) {
         float* dst = Ecol + (int64_t)g * 6 * M + slot;                  // [pair][6][M]: component-major (see gba_row_kernel)
 #pragma unroll
         for (int a = 0; a < 6; ++a) dst[(int64_t)a * M] = acc[a];
@@ -83,13 +94,13 @@ __global__ __launch_bounds__(128) void gba_scatter_kernel(const int64_t* __restr
   }
 }
 
-// per patch k (index into kx): Q, u and the i-side block, stored by (frame - f0, slot)
-__global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32_t* __restrict__ patch_off,
-                                 const int32_t* __restrict__ kx, const int32_t* __restrict__ n_patches,
-                                 const float* __restrict__ edgebuf, float lmbda, int M, int f0, int n_frames,
-                                 float* __restrict__ Q, float* __restrict__ U, float* __restrict__ Eself) {
+// per patch k (index into kx): Q, u and the i-side block, stored by (frame - f0, slot); thread gt of nthr
+__device__ __forceinline__ void gba_patch_body(const int32_t* __restrict__ perm_k, const int32_t* __restrict__ patch_off,
+                                               const int32_t* __restrict__ kx, const int32_t* __restrict__ n_patches,
+                                               const float* __restrict__ edgebuf, float lmbda, int M, int f0, int n_frames,
+                                               float* __restrict__ Q, float* __restrict__ U, float* __restrict__ Eself, int gt, int nthr) {
   const int np = *n_patches;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < np; k += gridDim.x * blockDim.x) {
+  for (int k = gt; k < np; k += nthr) {
     float C = 0.f, u = 0.f, Ei[6] = {0, 0, 0, 0, 0, 0};
     // four edges' records in flight (edge number, then its two 16-byte loads); the sums stay in list order.  One edge at a time this
     // loop was two dependent round trips per edge, ~28 edges per patch at the global BA's size: 44 us of every linearisation
@@ -121,6 +132,39 @@ __global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32
     for (int a = 0; a < 6; ++a) Eself[((int64_t)fr * 6 + a) * M + slot] = Ei[a];          // [frame][6][M]
   }
 }
+
+// The two are independent (both read the edge records of ba_pair_kernel, they write different arrays): ONE launch instead of two
+// dependent ones of ~30 us each (round 5, last session).  The first n_patch workgroups are the patches' (few, latency bound: they
+// start at once and run beside the others), the rest take two pairs each.
+struct GbaSP {
+  const int64_t* kk; const int32_t *perm_p, *pair_off, *n_pairs, *perm_k, *patch_off, *kx, *n_patches;
+  const float* edgebuf; float *Ecol, *Q, *U, *Eself; float lmbda; int M, f0, n_frames, n_patch;
+};
+__global__ __launch_bounds__(256) void gba_scatter_patch_kernel(GbaSP A) {
+  __shared__ int sl[2][128];
+  __shared__ int se[2][128];
+  if ((int)blockIdx.x < A.n_patch)
+    gba_patch_body(A.perm_k, A.patch_off, A.kx, A.n_patches, A.edgebuf, A.lmbda, A.M, A.f0, A.n_frames, A.Q, A.U, A.Eself,
+                   (int)blockIdx.x * 256 + (int)threadIdx.x, A.n_patch * 256);
+  else
+    gba_scatter_body(A.kk, A.perm_p, A.pair_off, A.n_pairs, A.edgebuf, A.Ecol, A.M, (int)blockIdx.x - A.n_patch, (int)gridDim.x - A.n_patch, 2, sl, se);
+}
+#if !GBA_FUSE_SP
+__global__ __launch_bounds__(128) void gba_scatter_kernel(const int64_t* __restrict__ kk, const int32_t* __restrict__ perm_p,
+                                                          const int32_t* __restrict__ pair_off, const int32_t* __restrict__ n_pairs,
+                                                          const float* __restrict__ edgebuf, float* __restrict__ Ecol, int M) {
+  __shared__ int sl[1][128];
+  __shared__ int se[1][128];
+  gba_scatter_body(kk, perm_p, pair_off, n_pairs, edgebuf, Ecol, M, (int)blockIdx.x, (int)gridDim.x, 1, sl, se);
+}
+__global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32_t* __restrict__ patch_off,
+                                 const int32_t* __restrict__ kx, const int32_t* __restrict__ n_patches,
+                                 const float* __restrict__ edgebuf, float lmbda, int M, int f0, int n_frames,
+                                 float* __restrict__ Q, float* __restrict__ U, float* __restrict__ Eself) {
+  gba_patch_body(perm_k, patch_off, kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself,
+                 (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+}
+#endif
 
 // Q, u, Eself = 0 in front of a linearisation (hipMemsetAsync of these ~0.3 MB is a 23 us fill on this runtime,
 // profiles/r05_e_lc_timeline.txt; a plain store kernel is a launch)
@@ -702,10 +746,19 @@ static int gba_linearize_impl(const float* poses, const float* patches, const fl
   if (!reuse_index)
     hipLaunchKernelGGL(gba_index_kernel, dim3(1), dim3(1024), 0, st, plan + PL.pair_ij, n_pairs, f0, n_frames, t0, N, run_lo,
                        tgt_off, tgt_cnt, tgt_list);
+#if GBA_FUSE_SP
+  {
+    const int n_patch_blocks = (int)((n_patches_h + 255) / 256);
+    const GbaSP A = {kk, plan + PL.perm_p, plan + PL.pair_off, n_pairs, plan + PL.perm_k, plan + PL.patch_off, plan + PL.kx, n_patches,
+                     edgebuf, Ecol, Q, U, Eself, lmbda, M, f0, n_frames, n_patch_blocks};
+    hipLaunchKernelGGL(gba_scatter_patch_kernel, dim3((unsigned)n_patch_blocks + (pair_grid + 1) / 2), dim3(256), 0, st, A);
+  }
+#else
   hipLaunchKernelGGL(gba_scatter_kernel, dim3(pair_grid), dim3(128), 0, st, kk, plan + PL.perm_p, plan + PL.pair_off, n_pairs,
                      edgebuf, Ecol, M);
   hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
                      plan + PL.patch_off, plan + PL.kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself);
+#endif
   {
     const int split = N <= 64 ? 4 : (N <= 128 ? 2 : 1);
     const unsigned nwg = (unsigned)((N * split + 7) / 8 * 8);       // (a multiple of 8: the XCD-major numbering of the kernel is a bijection on it)

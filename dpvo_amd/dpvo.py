@@ -32,6 +32,7 @@ _CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0"))
 # the update operator has run, which costs the host its lead (measured: 814 -> 809 frames/sec, +0.6 ms of host CPU per frame).
 _DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '0')))
 _COMPOSITE_LR = bool(int(__import__('os').environ.get('DPVO_COMPOSITE_LR', '1')))   # 0: frame state entry by entry while long-range edges are active (measurements)
+_PLAN_FIRST = bool(int(__import__('os').environ.get('DPVO_PLAN_FIRST', '0')))     # 1: update() builds the plan in front of reproject / corr (rounds 1-5; measurements)
 _GBA_CAT = bool(int(__import__('os').environ.get('DPVO_GBA_CAT', '0')))      # 1: the global BA's edge lists as five torch.cat (measurements)
 _PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
 # The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
@@ -924,11 +925,20 @@ class DPVO:
                 corr = self.corr(coords)
                 plan = self.plan(edges_ready=self._edges_ev)
                 self.plan_sync()
-            else:
+            elif _PLAN_FIRST:
                 self.plan_sync()
                 plan = self.plan()
                 coords = self.reproject()
                 corr = self.corr(coords)
+            else:
+                # reprojection and correlation first: neither reads the plan, and on this call-by-call path (initialisation, frames
+                # with long-range edges active: the global-BA frames of config 5) the frame's start is paced by the host -- the plan's
+                # host work (buffer, two C calls, the bound watch) then runs while the GPU is busy with the correlation instead of in
+                # front of it
+                self.plan_sync()
+                coords = self.reproject()
+                corr = self.corr(coords)
+                plan = self.plan()
             # the hidden state, updated in place (the reference reassigns pg.net); a removal of this frame may still be pending
             # on it (EdgeStore.keep(defer_net=True)): the update operator's first kernel gathers the rows, its last one
             # writes them back in compact order

@@ -16,8 +16,9 @@ VARIANTS = [
     ("radix plans (DPVO_PLAN_WIDE=0)", {"DPVO_PLAN_WIDE": "0"}),
     ("PatchGraph.normalize as torch operations (DPVO_NORMALIZE_FUSED=0)", {"DPVO_NORMALIZE_FUSED": "0"}),
     ("frame state entry by entry (DPVO_COMPOSITE_LR=0)", {"DPVO_COMPOSITE_LR": "0"}),
+    ("plan in front of reproject / corr (DPVO_PLAN_FIRST=1)", {"DPVO_PLAN_FIRST": "1"}),
     ("all switches back", {"DPVO_PLAN_WIDE": "0", "DPVO_GBA_CAT": "1", "DPVO_CHOL_BACK_STEPS": "1", "DPVO_COMPOSITE_LR": "0",
-                           "DPVO_NORMALIZE_FUSED": "0"}),
+                           "DPVO_NORMALIZE_FUSED": "0", "DPVO_PLAN_FIRST": "1"}),
 ]
 if os.environ.get("LC_AB_ALL"):        # the two switches that measured within the noise (profiles/r05_f_lc_ab.txt)
     VARIANTS[3:3] = [("five torch.cat (DPVO_GBA_CAT=1)", {"DPVO_GBA_CAT": "1"}),
