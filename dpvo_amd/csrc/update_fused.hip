@@ -62,34 +62,38 @@ struct P1 {
 };
 
 // K1 -----------------------------------------------------------------------------------------------
-template <int RT, int DW, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
+// NT = 3: 4 waves; OCC = workgroups per CU (1: everything an epilogue needs is requested one GEMM early; 2: nothing is, the neighbour
+// workgroup covers the round trips).  NT = 1: 12 waves, three per SIMD, one workgroup per CU; EARLY = what OCC == 1 means for NT = 3.
+template <int RT, int DW, int OCC = 1, int NT = 3>
+__global__ __launch_bounds__(64 * (12 / NT), OCC * 3 / NT) void k1_corr_norm(const P1 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = Geo<RT>::R;
+  using G_ = Geo<RT, NT>;
+  constexpr int R = G_::R, NTHR = G_::NTHR;
+  constexpr bool EARLY = OCC == 1 && NT == 3;
   const Lane l = lane_of();
   const int64_t tile = blockIdx.x, row0 = tile * R;
   char* act = smem;
-  float* red = reinterpret_cast<float*>(smem + Geo<RT>::ACT_BYTES);
+  float* red = reinterpret_cast<float*>(smem + G_::ACT_BYTES);
   char* al = act + l.n * PITCH + 16 * l.h;
 
   soft_start(p.skew);
   FU_T(0, 0);
-  f16v acc[RT][3];
-  h8 wf[DW][3];
-  Bias bias;
+  f16v acc[RT][NT];
+  h8 wf[DW][NT];
+  Bias<NT> bias;
   // ---- Linear(882 -> 384) + ReLU over K = 896 streamed from global memory in 7 chunks of 128, two LDS stages
   {
-    const h8* wp = w_base(p.c0.w, 56, l);
-    w_preload<DW>(wf, wp);
-    if constexpr (OCC == 1) bias_load(bias, p.c0.b, l);
-    constexpr int NS = RT * 2;                         // 16-byte pieces per thread per chunk
+    const h8* wp = w_base<NT>(p.c0.w, 56, l);
+    w_preload<DW, NT>(wf, wp);
+    if constexpr (EARLY) bias_load<NT>(bias, p.c0.b, l);
+    constexpr int NS = RT * 2 * 256 / NTHR;            // 16-byte pieces per thread per chunk
     // chunk kc + 2 is requested (into one of two register sets) while chunk kc is multiplied and chunk kc + 1 waits in the
     // other set for its LDS stage: a chunk lasts ~1 us of MFMAs, a miss to HBM under load about twice that.
     h8 st[2][NS];
     auto load = [&](h8 (&d)[NS], int kc) {
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int idx = l.tid + 256 * i, row = idx >> 4, ch = idx & 15;
+        const int idx = l.tid + NTHR * i, row = idx >> 4, ch = idx & 15;
         int64_t g = row0 + row;
         g = g < p.E ? g : p.E - 1;
         d[i] = *reinterpret_cast<const h8*>(p.corr + g * p.ld_corr + kc * KCH + ch * 8);
@@ -98,13 +102,13 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
     auto store = [&](const h8 (&d)[NS], int b) {
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int idx = l.tid + 256 * i, row = idx >> 4, ch = idx & 15;
+        const int idx = l.tid + NTHR * i, row = idx >> 4, ch = idx & 15;
         *reinterpret_cast<h8*>(smem + b * R * CPITCH + row * CPITCH + ch * 16) = d[i];
       }
     };
     load(st[0], 0);
     load(st[1], 1);
-    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.c0.b, l);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.c0.b, l);
     store(st[0], 0);
     __syncthreads();
     FU_T(0, 1);
@@ -124,13 +128,13 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < RT; ++r)
             acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % DW][t], bf[ks & 1][r], acc[r][t], 0, 0, 0);
         if (s + DW < 56) {
 #pragma unroll
-          for (int t = 0; t < 3; ++t) wf[s % DW][t] = wp[((s + DW) * 3 + t) * 64];
+          for (int t = 0; t < NT; ++t) wf[s % DW][t] = wp[((s + DW) * 3 + t) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -139,27 +143,27 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
     }
   }
   FU_T(0, 2);
-  const h8* wp2 = w_base(p.c2.w, KS384, l);
-  w_preload<DW>(wf, wp2);
-  if constexpr (OCC == 1) bias_load(bias, p.c2.b, l);
-  to_lds<RT, 1>(acc, al, l);                            // (the last barrier of the chunk loop freed the stages)
+  const h8* wp2 = w_base<NT>(p.c2.w, KS384, l);
+  w_preload<DW, NT>(wf, wp2);
+  if constexpr (EARLY) bias_load<NT>(bias, p.c2.b, l);
+  to_lds<RT, 1, NT>(acc, al, l);                            // (the last barrier of the chunk loop freed the stages)
   __syncthreads();
   // ---- Linear, LayerNorm, ReLU
-  if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.c2.b, l);
-  gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp2, al);
+  if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.c2.b, l);
+  gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wp2, al);
   FU_T(0, 3);
-  const h8* wp3 = w_base(p.c5.w, KS384, l);
-  w_preload<DW>(wf, wp3);
-  if constexpr (OCC == 1) bias_load(bias, p.c5.b, l);
-  round_f16<RT>(acc);
-  if constexpr (OCC == 1) layernorm_tile<RT>(acc, red, p.cln_g, p.cln_b, l); else layernorm_tile_late<RT>(acc, red, p.cln_g, p.cln_b, l);
-  to_lds<RT, 1>(acc, al, l);
+  const h8* wp3 = w_base<NT>(p.c5.w, KS384, l);
+  w_preload<DW, NT>(wf, wp3);
+  if constexpr (EARLY) bias_load<NT>(bias, p.c5.b, l);
+  round_f16<RT, NT>(acc);
+  if constexpr (EARLY) layernorm_tile<RT, NT>(acc, red, p.cln_g, p.cln_b, l); else layernorm_tile_late<RT, NT>(acc, red, p.cln_g, p.cln_b, l);
+  to_lds<RT, 1, NT>(acc, al, l);
   __syncthreads();
   FU_T(0, 4);
   // ---- Linear; net = LayerNorm(net + inp + .).
   if constexpr (OCC == 1) {
     // one workgroup per CU: the rows of net (feature order) are requested before the GEMM
-    Img<RT> nv;
+    Img<RT, NT> nv;
     int64_t ir[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -169,26 +173,26 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
       if (p.inp_rows) { ir[r] = p.inp_rows[g]; if (p.inp_mod > 0) ir[r] %= p.inp_mod; }
       const int64_t gs = !p.net_rows ? g : (g < p.n_kept ? p.net_rows[g] : -1);
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          nv.v[r][t][j] = gs >= 0 ? *reinterpret_cast<const f4*>(p.net + gs * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h) : (f4)0.f;
+          nv.v[r][t][j] = gs >= 0 ? *reinterpret_cast<const f4*>(p.net + gs * D + 32 * (NT * l.w + t) + 8 * j + 4 * l.h) : (f4)0.f;
     }
-    acc_init<RT>(acc, bias);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp3, al);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.c5.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wp3, al);
     FU_T(0, 5);
-    h4 iv[RT][3][4];
+    h4 iv[RT][NT][4];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) iv[r][t][j] = *reinterpret_cast<const h4*>(p.inp + ir[r] * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
-    round_f16<RT>(acc);
+        for (int j = 0; j < 4; ++j) iv[r][t][j] = *reinterpret_cast<const h4*>(p.inp + ir[r] * D + 32 * (NT * l.w + t) + 8 * j + 4 * l.h);
+    round_f16<RT, NT>(acc);
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -196,10 +200,10 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
             acc[r][t][4 * j + q] = (nv.v[r][t][j][q] + (float)iv[r][t][j][q]) + acc[r][t][4 * j + q];
   } else {
     // several workgroups per CU: no registers for rows in flight under the GEMM; one 32-row tile at a time afterwards
-    acc_init_mem<RT>(acc, p.c5.b, l);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wp3, al);
+    acc_init_mem<RT, NT>(acc, p.c5.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wp3, al);
     FU_T(0, 5);
-    round_f16<RT>(acc);
+    round_f16<RT, NT>(acc);
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       int64_t g = row0 + r * 32 + l.n;
@@ -207,16 +211,16 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
       int64_t ir = g;
       if (p.inp_rows) { ir = p.inp_rows[g]; if (p.inp_mod > 0) ir %= p.inp_mod; }
       const int64_t gs = !p.net_rows ? g : (g < p.n_kept ? p.net_rows[g] : -1);
-      f4 nv[3][4]; h4 iv[3][4];
+      f4 nv[NT][4]; h4 iv[NT][4];
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          nv[t][j] = gs >= 0 ? *reinterpret_cast<const f4*>(p.net + gs * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h) : (f4)0.f;
-          iv[t][j] = *reinterpret_cast<const h4*>(p.inp + ir * D + 96 * l.w + 32 * t + 8 * j + 4 * l.h);
+          nv[t][j] = gs >= 0 ? *reinterpret_cast<const f4*>(p.net + gs * D + 32 * (NT * l.w + t) + 8 * j + 4 * l.h) : (f4)0.f;
+          iv[t][j] = *reinterpret_cast<const h4*>(p.inp + ir * D + 32 * (NT * l.w + t) + 8 * j + 4 * l.h);
         }
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -225,12 +229,12 @@ __global__ __launch_bounds__(256, OCC) void k1_corr_norm(const P1 p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if constexpr (OCC == 1) layernorm_tile<RT>(acc, red, p.norm_g, p.norm_b, l); else layernorm_tile_late<RT>(acc, red, p.norm_g, p.norm_b, l);
+  if constexpr (EARLY) layernorm_tile<RT, NT>(acc, red, p.norm_g, p.norm_b, l); else layernorm_tile_late<RT, NT>(acc, red, p.norm_g, p.norm_b, l);
   FU_T(0, 6);
-  img_store<RT>(acc, img_ptr<RT>(p.img, tile, l));
-  to_lds<RT, 0>(acc, al, l);
+  img_store<RT, NT>(acc, img_ptr<RT, NT>(p.img, tile, l));
+  to_lds<RT, 0, NT>(acc, al, l);
   __syncthreads();
-  scatter_rows<RT>(act, p.rows16, row0, p.E, l.tid);
+  scatter_rows<RT, NTHR>(act, p.rows16, row0, p.E, l.tid);
   FU_T(0, 7);
 }
 
@@ -247,10 +251,12 @@ struct P2 {
 };
 enum { MODE_C1 = 0, MODE_C2 = 1, MODE_H = 2 };
 
-template <int RT, int DW, int MODE, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void k_chain(const P2 p) {
+template <int RT, int DW, int MODE, int OCC = 1, int NT = 3>
+__global__ __launch_bounds__(64 * (12 / NT), OCC * 3 / NT) void k_chain(const P2 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = Geo<RT>::R;
+  using G_ = Geo<RT, NT>;
+  constexpr int R = G_::R, NTHR = G_::NTHR;
+  constexpr bool EARLY = OCC == 1 && NT == 3;       // one wave per SIMD: biases / image requested one GEMM early
   const Lane l = lane_of();
   const int64_t tile = blockIdx.x, row0 = tile * R;
   char* act = smem;
@@ -258,68 +264,68 @@ __global__ __launch_bounds__(256, OCC) void k_chain(const P2 p) {
 
   soft_start(p.skew);
   FU_T(1 + MODE, 0);
-  f16v acc[RT][3];
-  h8 wf[DW][3];
-  Bias bias;
-  Img<RT> im;
-  float* ip = img_ptr<RT>(p.img, tile, l);
-  const h8* wpa = w_base(MODE == MODE_H ? p.b.w : p.a.w, KS384, l);
-  w_preload<DW>(wf, wpa);
-  if constexpr (OCC == 1) bias_load(bias, MODE == MODE_H ? p.b.b : p.a.b, l);
-  gather_rows<RT>(act, p.src, p.rows, row0, p.E, l.tid, reinterpret_cast<int32_t*>(smem + Geo<RT>::ACT_BYTES));
-  if constexpr (MODE == MODE_H && OCC == 1) img_load<RT>(im, ip);
+  f16v acc[RT][NT];
+  h8 wf[DW][NT];
+  Bias<NT> bias;
+  Img<RT, NT> im;
+  float* ip = img_ptr<RT, NT>(p.img, tile, l);
+  const h8* wpa = w_base<NT>(MODE == MODE_H ? p.b.w : p.a.w, KS384, l);
+  w_preload<DW, NT>(wf, wpa);
+  if constexpr (EARLY) bias_load<NT>(bias, MODE == MODE_H ? p.b.b : p.a.b, l);
+  gather_rows<RT, NTHR>(act, p.src, p.rows, row0, p.E, l.tid, reinterpret_cast<int32_t*>(smem + G_::ACT_BYTES));
+  if constexpr (MODE == MODE_H && EARLY) img_load<RT, NT>(im, ip);
   FU_T(1 + MODE, 1);
   __syncthreads();
   FU_T(1 + MODE, 2);
   if constexpr (MODE != MODE_H) {
-    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.a.b, l);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpa, al);
-    const h8* wpb = w_base(p.b.w, KS384, l);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.a.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wpa, al);
+    const h8* wpb = w_base<NT>(p.b.w, KS384, l);
     FU_T(1 + MODE, 3);
-    w_preload<DW>(wf, wpb);
-    if constexpr (OCC == 1) bias_load(bias, p.b.b, l);
-    if constexpr (OCC == 1) img_load<RT>(im, ip);   // lands under the second GEMM
+    w_preload<DW, NT>(wf, wpb);
+    if constexpr (EARLY) bias_load<NT>(bias, p.b.b, l);
+    if constexpr (EARLY) img_load<RT, NT>(im, ip);   // lands under the second GEMM
     __syncthreads();
-    to_lds<RT, 1>(acc, al, l);
+    to_lds<RT, 1, NT>(acc, al, l);
     __syncthreads();
     FU_T(1 + MODE, 4);
-    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.b.b, l);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpb, al);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.b.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wpb, al);
   } else {
-    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.b.b, l);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpa, al);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.b.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wpa, al);
   }
   FU_T(1 + MODE, 5);
   const h8* wpf = nullptr;
-  if constexpr (MODE != MODE_C1) { wpf = w_base(p.f.w, KS384, l); w_preload<DW>(wf, wpf); if constexpr (OCC == 1) bias_load(bias, p.f.b, l); }
-  round_f16<RT>(acc);
-  if constexpr (OCC == 1) {
-    img_add<RT>(acc, im);
-    img_store<RT>(acc, ip);
+  if constexpr (MODE != MODE_C1) { wpf = w_base<NT>(p.f.w, KS384, l); w_preload<DW, NT>(wf, wpf); if constexpr (EARLY) bias_load<NT>(bias, p.f.b, l); }
+  round_f16<RT, NT>(acc);
+  if constexpr (EARLY) {
+    img_add<RT, NT>(acc, im);
+    img_store<RT, NT>(acc, ip);
   } else {
-    img_add_store_stream<RT>(acc, ip);
+    img_add_store_stream<RT, NT>(acc, ip);
   }
   FU_T(1 + MODE, 6);
   __syncthreads();
-  to_lds<RT, 0>(acc, al, l);
+  to_lds<RT, 0, NT>(acc, al, l);
   __syncthreads();
   FU_T(1 + MODE, 7);
   if constexpr (MODE == MODE_C1) {
-    scatter_rows<RT>(act, p.rows16, row0, p.E, l.tid);
+    scatter_rows<RT, NTHR>(act, p.rows16, row0, p.E, l.tid);
     FU_T(1 + MODE, 8);
   } else {
-    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.f.b, l);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpf, al);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.f.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wpf, al);
     FU_T(1 + MODE, 8);
-    const h8* wpg = w_base(p.g.w, KS384, l);
-    w_preload<DW>(wf, wpg);
-    if constexpr (OCC == 1) bias_load(bias, p.g.b, l);
-    to_rows<RT>(acc, p.fg, 768, row0, p.E, l);
+    const h8* wpg = w_base<NT>(p.g.w, KS384, l);
+    w_preload<DW, NT>(wf, wpg);
+    if constexpr (EARLY) bias_load<NT>(bias, p.g.b, l);
+    to_rows<RT, NT>(acc, p.fg, 768, row0, p.E, l);
     FU_T(1 + MODE, 9);
-    if constexpr (OCC == 1) acc_init<RT>(acc, bias); else acc_init_mem<RT>(acc, p.g.b, l);
-    gemm_lds<RT, KS384, DW, PITCH>(acc, wf, wpg, al);
+    if constexpr (EARLY) acc_init<RT, NT>(acc, bias); else acc_init_mem<RT, NT>(acc, p.g.b, l);
+    gemm_lds<RT, KS384, DW, PITCH, NT>(acc, wf, wpg, al);
     FU_T(1 + MODE, 10);
-    to_rows<RT>(acc, p.fg + D, 768, row0, p.E, l);
+    to_rows<RT, NT>(acc, p.fg + D, 768, row0, p.E, l);
     FU_T(1 + MODE, 11);
   }
 }
@@ -465,8 +471,8 @@ extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, c
 #define FU_DW2C 6            // the chain kernels fit a 6-deep ring in 250 registers at two workgroups per CU (K1 spills beyond 3)
 #endif
 #define FU_CFG_DEFAULT 1            // chains: 64-row tiles x 2 workgroups per CU; K1 and K7: 96-row tiles x 1 (A/B in the frame, round 3: cfg 1 / 3 / 0 / 2 = 828 / 817 / 814 / 800 frames/sec on one box)
-#define FU_DWPM 4
-#define FU_DWKB 6
+#define FU_DW1W 5              // K1's weight ring at three waves per SIMD (NT = 1: 6 spills one register)
+#define FU_DWCW 6              // the chain kernels' ring at three waves per SIMD
 
 extern "C" size_t dpvo_update_fused_pack_bytes(int K) { return K > 0 && (K % 16) == 0 ? (size_t)384 * K * 2 : 0; }
 
@@ -523,7 +529,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   constexpr int RT = FU_RT, DW = FU_DW;
   constexpr int RT2 = FU_RT2, DW2 = FU_DW2, OCC2 = FU_OCC2;
   constexpr int RT2C = FU_RT2C, DW2C = FU_DW2C;       // chain kernels' own tile height / ring at several workgroups per CU  // several workgroups per CU, 64-row tiles
-  const int cfg = (p->tiling < 0 ? FU_CFG_DEFAULT : p->tiling) & 3;
+  const int cfg = (p->tiling < 0 ? FU_CFG_DEFAULT : p->tiling) & 31;
   const int skew = p->start_skew < 0 ? 0 : (p->start_skew > 1000 ? 1000 : p->start_skew);
   const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
   Ws L;
@@ -543,19 +549,22 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   {
     P1 a{lin(DPVO_UF_C0), lin(DPVO_UF_C2), lin(DPVO_UF_C5), p->ln_g[0], p->ln_b[0], p->ln_g[1], p->ln_b[1],
          (const _Float16*)corr, ld_corr, net, net_rows, n_kept, (const _Float16*)inp, inp_rows, inp_mod, img, r16a, E, skew};
-    if (cfg & 2) FU(launch<k1_corr_norm<RT2, DW2, OCC2>>(tiles2, Geo<RT2>::LDS_BYTES, a, st));
+    if (cfg & 8) FU(launch<k1_corr_norm<RT, FU_DW1W, 1, 1>, P1, Geo<RT, 1>::NTHR>(tiles, Geo<RT, 1>::LDS_BYTES, a, st));
+    else if (cfg & 2) FU(launch<k1_corr_norm<RT2, DW2, OCC2>>(tiles2, Geo<RT2>::LDS_BYTES, a, st));
     else FU(launch<k1_corr_norm<RT, FU_DW1>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C1_0), lin(DPVO_UF_C1_2), Lin{nullptr, nullptr}, Lin{nullptr, nullptr}, r16a, plan + PL.ix, img, r16b,
          nullptr, E, skew};
-    if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_C1, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
+    if (cfg & 16) FU(launch<k_chain<RT, FU_DWCW, MODE_C1, 1, 1>, P2, Geo<RT, 1>::NTHR>(tiles, Geo<RT, 1>::LDS_BYTES, a, st));
+    else if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_C1, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
     else FU(launch<k_chain<RT, DW, MODE_C1>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   {
     P2 a{lin(DPVO_UF_C2N_0), lin(DPVO_UF_C2N_2), lin(DPVO_UF_AKK_F), lin(DPVO_UF_AKK_G), r16b, plan + PL.jx, img, nullptr, fg,
          E, skew};
-    if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_C2, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
+    if (cfg & 16) FU(launch<k_chain<RT, FU_DWCW, MODE_C2, 1, 1>, P2, Geo<RT, 1>::NTHR>(tiles, Geo<RT, 1>::LDS_BYTES, a, st));
+    else if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_C2, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
     else FU(launch<k_chain<RT, DW, MODE_C2>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   int64_t ngk = n_patches_ub < 1 ? 1 : (n_patches_ub > E ? E : n_patches_ub);
@@ -563,7 +572,8 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   FU(dpvo_softagg(fg, 768, plan + PL.perm_k, plan + PL.patch_off, plan + PL.counts + 0, ngk, y, 384, stream));
   {
     P2 a{Lin{nullptr, nullptr}, lin(DPVO_UF_AKK_H), lin(DPVO_UF_AIJ_F), lin(DPVO_UF_AIJ_G), y, plan + PL.ku, img, nullptr, fg, E, skew};
-    if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_H, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
+    if (cfg & 16) FU(launch<k_chain<RT, FU_DWCW, MODE_H, 1, 1>, P2, Geo<RT, 1>::NTHR>(tiles, Geo<RT, 1>::LDS_BYTES, a, st));
+    else if (cfg & 1) FU(launch<k_chain<RT2C, DW2C, MODE_H, OCC2>>(tiles2c, Geo<RT2C>::LDS_BYTES, a, st));
     else FU(launch<k_chain<RT, DW, MODE_H>>(tiles, Geo<RT>::LDS_BYTES, a, st));
   }
   FU(dpvo_softagg(fg, 768, plan + PL.perm_p, plan + PL.pair_off, plan + PL.counts + 1, ngp, y, 384, stream));
@@ -576,7 +586,7 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
     a.d_w = (const _Float16*)p->d_w; a.d_b = (const _Float16*)p->d_b; a.w_w = (const _Float16*)p->w_w; a.w_b = (const _Float16*)p->w_b;
     a.y = y; a.rows = plan + PL.pu; a.img = img; a.coords = coords; a.pp = P * P;
     a.net_out = net_out; a.delta = delta; a.weight = weight; a.target = target; a.E = E; a.skew = skew;
-    FU(dpvo_fu::launch_k7(tiles, a, stream));          // (update_fused_k7.hip: 96-row tiles, one workgroup per CU)
+    FU(dpvo_fu::launch_k7(tiles, a, cfg & 4, stream));          // (update_fused_k7.hip: 96-row tiles, one workgroup per CU)
   }
 #undef FU
   return DPVO_OK;

@@ -356,7 +356,9 @@ typedef struct {
   const void *d_w, *d_b, *w_w, *w_b;
   /* tuning knobs of the seven-launch path (no reference counterpart), per call -- the library holds no mutable state:
    * tiling: bit 0 = chain kernels, bit 1 = the correlation-MLP kernel use 64-row tiles with two workgroups per CU instead of
-   *   96-row tiles with one; < 0 = dpvo_update_fused_default_tiling().  start_skew: workgroup b begins (b & 3) * us / 4
+   *   96-row tiles with one; bits 2 / 3 / 4 = the last kernel / the correlation-MLP kernel / the chain kernels run 96-row tiles with
+   *   TWELVE waves (three per SIMD, 32 output features per wave) instead of four (one per SIMD, 96 features per wave); bits 3 and 4
+   *   take precedence over bits 1 and 0; < 0 = dpvo_update_fused_default_tiling().  start_skew: workgroup b begins (b & 3) * us / 4
    *   microseconds late (0 = off).  Results are bit-identical for every setting. */
   int32_t tiling, start_skew;
 } dpvo_update_fused_params_t;

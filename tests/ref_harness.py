@@ -171,6 +171,9 @@ def attribute(cap, c, ours, e_inac_before=0, reruns=3, pose_max=0.0, lim0=float(
     from dpvo_amd import fastba as our_fastba
     n = c["t1"]
     out = {"yard": 0.0, "eff_impl": bool(c["eff_impl"]), "E_ba": int(c["ii"].numel())}
+    # step_ref: how far the reference's own call moved the poses (|poses_after - poses_before|, same metric as every distance below): the
+    # scale a one-step tolerance has to be tied to -- a bundle adjustment that did NOTHING is exactly step_ref away from the reference
+    out["step_ref"] = pose_dist(c["poses_after"], c["poses"], n)
     for _ in range(reruns):
         p, _pt = cap.rerun(c)
         out["yard"] = max(out["yard"], pose_dist(p, c["poses_after"], n))
@@ -291,6 +294,9 @@ def run_lockstep(ours, theirs, frames, n_frames, intr, feed=True, seed0=5000, fl
             #  dropped behind it the poses have moved down a slot and the edges were renumbered: the BA-on-the-same-inputs figures do
             #  not care, the attribution against our final poses is not available for that frame)
             with torch.no_grad():
+                # (all of the frame's bundle adjustments: 12 in the initialisation frame, dpvo.py:461-465 -- the scale its pose
+                #  difference is measured against; one otherwise, where it equals step_ref)
+                d["step_frame"] = float(sum(pose_dist(c["poses_after"], c["poses"], c["t1"]) for c in cap.calls))
                 d.update(attribute(cap, cap.calls[-1], ours, e_inac_before=e_inac_before, pose_max=d.get("pose_max", 0.0),
                                    lim0=1e-3 * max(1.0, d.get("extent", 0.0))))
             cap.calls.clear()
@@ -322,12 +328,15 @@ def summarise(recs):
                    pose_max_first24=max((r["pose_max"] for r in ok if r["t"] < 24), default=None),
                    pose_max_first16=max((r["pose_max"] for r in ok if r["t"] < 16), default=None),
                    above_1e3=[{k: (float(f"{r[k]:.3g}") if isinstance(r.get(k), float) else r.get(k)) for k in
-                               ("t", "pose_max", "extent", "yard", "ba_dist", "attr_dist", "ref_exact", "ours_exact", "attr_exact", "eff_impl")}
+                               ("t", "pose_max", "extent", "yard", "step_ref", "ba_dist", "attr_dist", "ref_exact", "ours_exact", "attr_exact", "eff_impl")}
                               for r in ok if max(r["pose_max"], r.get("ba_dist", 0.0)) > 1e-3 * max(1.0, r["extent"])],
                    pose_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['extent']:.3g}")] for r in ok[::4]])
     at = [r for r in ok if "ba_dist" in r]
     if at:
         out.update(yard_max=max(r["yard"] for r in at), ba_dist_max=max(r["ba_dist"] for r in at),
+                   step_ref_min_med_max=[float(f"{v:.3g}") for v in np.quantile([r["step_ref"] for r in at], [0.0, 0.5, 1.0])],
+                   step_series=[[r["t"], float(f"{r['step_ref']:.3g}"), float(f"{r['yard']:.3g}"), float(f"{r['ba_dist']:.3g}"),
+                                 float(f"{r['pose_max']:.3g}"), float(f"{r.get('ref_exact', float('nan')):.3g}"), float(f"{r['extent']:.3g}")] for r in at],
                    attr_dist_max=max((r["attr_dist"] for r in at if "attr_dist" in r), default=None),
                    ba_series=[[r["t"], float(f"{r['pose_max']:.3g}"), float(f"{r['yard']:.3g}"), float(f"{r['ba_dist']:.3g}"),
                                float(f"{r.get('attr_dist', float('nan')):.3g}")] for r in at[::4]])
