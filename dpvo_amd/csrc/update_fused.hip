@@ -256,7 +256,9 @@ __global__ __launch_bounds__(64 * (12 / NT), OCC * 3 / NT) void k_chain(const P2
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G_ = Geo<RT, NT>;
   constexpr int R = G_::R, NTHR = G_::NTHR;
-  constexpr bool EARLY = OCC == 1 && NT == 3;       // one wave per SIMD: biases / image requested one GEMM early
+  constexpr bool EARLY = OCC == 1 && NT == 3;       // one wave per SIMD: biases requested one GEMM early
+  constexpr bool IMG_EARLY = OCC == 1;              // one workgroup per CU: the f32 image requested one GEMM early (12 waves: three
+                                                    // dependent image round trips behind the last GEMM were 4 of a tile's 24 us)
   const Lane l = lane_of();
   const int64_t tile = blockIdx.x, row0 = tile * R;
   char* act = smem;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64 * (12 / NT), OCC * 3 / NT) void k_chain(const P2
   w_preload<DW, NT>(wf, wpa);
   if constexpr (EARLY) bias_load<NT>(bias, MODE == MODE_H ? p.b.b : p.a.b, l);
   gather_rows<RT, NTHR>(act, p.src, p.rows, row0, p.E, l.tid, reinterpret_cast<int32_t*>(smem + G_::ACT_BYTES));
-  if constexpr (MODE == MODE_H && EARLY) img_load<RT, NT>(im, ip);
+  if constexpr (MODE == MODE_H && IMG_EARLY) img_load<RT, NT>(im, ip);
   FU_T(1 + MODE, 1);
   __syncthreads();
   FU_T(1 + MODE, 2);
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64 * (12 / NT), OCC * 3 / NT) void k_chain(const P2
     FU_T(1 + MODE, 3);
     w_preload<DW, NT>(wf, wpb);
     if constexpr (EARLY) bias_load<NT>(bias, p.b.b, l);
-    if constexpr (EARLY) img_load<RT, NT>(im, ip);   // lands under the second GEMM
+    if constexpr (IMG_EARLY) img_load<RT, NT>(im, ip);   // lands under the second GEMM
     __syncthreads();
     to_lds<RT, 1, NT>(acc, al, l);
     __syncthreads();
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(64 * (12 / NT), OCC * 3 / NT) void k_chain(const P2
   const h8* wpf = nullptr;
   if constexpr (MODE != MODE_C1) { wpf = w_base<NT>(p.f.w, KS384, l); w_preload<DW, NT>(wf, wpf); if constexpr (EARLY) bias_load<NT>(bias, p.f.b, l); }
   round_f16<RT, NT>(acc);
-  if constexpr (EARLY) {
+  if constexpr (IMG_EARLY) {
     img_add<RT, NT>(acc, im);
     img_store<RT, NT>(acc, ip);
   } else {
@@ -470,9 +472,12 @@ extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, c
 #ifndef FU_DW2C
 #define FU_DW2C 6            // the chain kernels fit a 6-deep ring in 250 registers at two workgroups per CU (K1 spills beyond 3)
 #endif
-#define FU_CFG_DEFAULT 1            // chains: 64-row tiles x 2 workgroups per CU; K1 and K7: 96-row tiles x 1 (A/B in the frame, round 3: cfg 1 / 3 / 0 / 2 = 828 / 817 / 814 / 800 frames/sec on one box)
+// chains: 64-row tiles x 2 workgroups per CU, 4 waves each (A/B in the frame, round 3: cfg 1 / 3 / 0 / 2 = 828 / 817 / 814 / 800 frames/sec on one
+// box); K1 and K7: 96-row tiles x 1 workgroup of TWELVE waves (round 6: 516 -> 483 us alone, 0.512 -> 0.483 ms in the frame, 956-966 -> 984-993
+// frames/sec on one box, profiles/r06_b_*; the chains gain nothing from the 12-wave geometry: 481 us with all five kernels on it)
+#define FU_CFG_DEFAULT 13
 #define FU_DW1W 5              // K1's weight ring at three waves per SIMD (NT = 1: 6 spills one register)
-#define FU_DWCW 6              // the chain kernels' ring at three waves per SIMD
+#define FU_DWCW 5              // the chain kernels' ring at three waves per SIMD (6 spills six registers in the c1 kernel)
 
 extern "C" size_t dpvo_update_fused_pack_bytes(int K) { return K > 0 && (K % 16) == 0 ? (size_t)384 * K * 2 : 0; }
 

@@ -52,13 +52,15 @@ namespace fu {
 using ::dpvo_fu::Lin;
 using ::dpvo_fu::P7;
 
-// Soft start (dpvo_update_fused_start_skew): the workgroups of a launch begin in four groups, skew / 4 microseconds apart,
-// instead of all 256 CUs entering the same phase in the same microsecond.  A candidate of the autotune only: it costs a few
-// microseconds per kernel on a normal box (measured: 0 / +10 / +60 us at 4 / 10 / 20 us) and exists for the boxes on which the
-// FIRST, synchronous round of workgroups of every such kernel runs 2x slower than the second, staggered one.
+// Soft start (dpvo_update_fused_params_t.start_skew): the FIRST ROUND of workgroups of a launch (one per CU: blockIdx < 256 on MI355X)
+// begins in four groups, skew / 4 microseconds apart, instead of all 256 CUs entering the same phase in the same microsecond -- every
+// workgroup runs the same chain of memory and compute phases, so in lock step the HBM is saturated during the gathers / image loads /
+// stores and idle during the GEMMs.  The groups interleave inside an XCD (block b runs on XCD b % 8: (b >> 3) & 3 staggers neighbours on
+// one L2).  Later rounds start whenever a CU falls free, i.e. already out of step: delaying them would be pure loss.
 __device__ __forceinline__ void soft_start(int skew_us) {
-  if (skew_us > 0 && (blockIdx.x & 3)) {
-    const unsigned long long t0 = wall_clock64(), d = (unsigned long long)(blockIdx.x & 3) * (unsigned)skew_us * 25ull;   // 100 MHz ticks
+  const unsigned g = (blockIdx.x >> 3) & 3;
+  if (skew_us > 0 && g && blockIdx.x < 256) {
+    const unsigned long long t0 = wall_clock64(), d = (unsigned long long)g * (unsigned)skew_us * 25ull;   // 100 MHz ticks
     while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
   }
 }

@@ -373,7 +373,7 @@ int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* p, const fl
                                    float* net_out, float* delta, float* weight, float* target, int64_t E, void* ws,
                                    size_t ws_bytes, void* stream);
 size_t dpvo_update_fused_workspace_bytes(int64_t E, int64_t max_groups);
-int dpvo_update_fused_default_tiling(void);      /* 1 */
+int dpvo_update_fused_default_tiling(void);      /* 13 */
 int dpvo_update_forward_fused(const dpvo_update_fused_params_t* params, const float* net, const void* inp,
                               const int64_t* inp_rows, int64_t inp_mod, const void* corr, int64_t ld_corr, const int32_t* plan,
                               int64_t n_patches_ub, int64_t n_pairs_ub, const float* coords, int P, float* net_out,

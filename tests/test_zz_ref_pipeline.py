@@ -101,10 +101,12 @@ def _int_exact(recs, n_frames):
     return s
 
 
-def _float_state(name, recs, min_regular, tol=POSE_TOL, out_scale=1.0, flow_tol=FLOW_TOL, collect=False):
+def _float_state(name, recs, min_regular, tol=POSE_TOL, out_scale=1.0, flow_tol=FLOW_TOL, collect=False, skip_singular=False):
     """module docstring, FLOAT state: strict assertions on every frame up to the run's first singular frame (decided by the reference's
     own noise floor); at least `min_regular` frames must have been regular.  Prints the measured values; returns the first singular
-    frame (None: the whole run was regular).  collect=True: returns (first singular frame, list of violations) instead of asserting."""
+    frame (None: the whole run was regular).  collect=True: returns (first singular frame, list of violations) instead of asserting.
+    skip_singular=True (teacher-forced runs only: every frame starts from the REFERENCE's state, so a frame after a singular one is a
+    sound one-step comparison again whenever the reference's own noise floor says so): singular frames are skipped, not terminal."""
     first, bad, checked, attributed = None, [], 0, []
     worst = dict(pose=0.0, ba=0.0, net_max=0.0, net_rms=0.0, target_max=0.0, weight_max=0.0, flow=0.0, yard=0.0, ba_rel=0.0, pose_rel=0.0,
                  step_min=float("inf"), step_max=0.0)
@@ -124,7 +126,9 @@ def _float_state(name, recs, min_regular, tol=POSE_TOL, out_scale=1.0, flow_tol=
                 bad.append((t, "flow", r["flow_ours"], r["flow_ref"]))
         nf = max(r.get("yard", 0.0), r.get("ref_exact", 0.0))
         if nf > lim0:
-            first = t
+            first = t if first is None else first
+            if skip_singular:
+                continue
             break
         checked += 1
         # the step-relative bounds (only where the frame's BA was captured: step_ref is the reference's own step)
@@ -242,19 +246,24 @@ def test_free_running_bounded(dev, RP, stream):
 
 
 def test_teacher_forced_mid_scale(dev, RP, stream):
-    """MID (flow head x 0.1): a trajectory with an extent worth the name -- 0.75 by frame 52, 2.7 by frame 80 (>= 0.05 required on the
-    regular part) -- on which the reference stays regular for 52 .. 80 teacher-forced frames from run to run (its first singular frame,
-    when there is one, is its OWN f32 result leaving the f64 solution by more than 1e-3: measured ref_exact 1.9e-3 against ours_exact
-    3.8e-5 at t = 52; the sweep: profiles/r06_a_delta_scale_sweep.txt).  The absolute and the step-relative bounds on every regular
-    frame, steps 8e-5 .. 0.4."""
+    """MID (flow head x 0.1): a trajectory with an extent worth the name.  At the swept mid scales the random-weight tracker sits still for
+    ~50 frames (extent 0.006-0.04) and then leaves in one or two steps of 0.05-0.4 (profiles/r06_a_delta_scale_sweep.txt); from there on
+    every frame is a step of 0.05-0.5 on an extent of 0.6-2.8 that the reference reproduces to 1e-6-3e-5 -- the frames a one-step
+    comparison is worth most on.  The leaving frame itself is, from run to run, singular by the reference's own account (yard 2e-3, or its
+    f32 result 1.9e-3 away from the f64 solution where ours is 3.8e-5 away) -- so this test SKIPS singular frames instead of ending at the
+    first one (teacher forcing restarts every frame from the reference's state) and requires: >= 60 regular frames, >= 10 of them at an
+    extent >= 0.05 with a reference step >= 0.01, the absolute and the step-relative bounds on every regular frame."""
     frames, intr = stream
     ours, theirs, _ = H.build_pair(dev, HT, WD, M, KEYFRAME_THRESH=-1.0, **MID)
     recs = H.run_lockstep(ours, theirs, frames, 80, intr, feed=True, teacher=True, attribute_ba=True)
     s = _int_exact(recs, 80)
-    first = _float_state("teacher forced (mid scale)", recs, min_regular=40)
-    ext = max(r.get("extent", 0.0) for r in recs if first is None or r["t"] < first)
-    print(f"mid scale: extent of the regular part {ext:.3g} (whole run {s['extent_last']:.3g}), first singular frame {first}")
-    assert s["E_last"] == 45312 and ext >= 0.05
+    first = _float_state("teacher forced (mid scale)", recs, min_regular=60, skip_singular=True)
+    big = [r for r in recs if "step_ref" in r and max(r.get("yard", 0.0), r.get("ref_exact", 0.0)) <= POSE_TOL * max(1.0, r["extent"])
+           and r["extent"] >= 0.05 and r["step_ref"] >= 0.01]
+    print(f"mid scale: extent {s['extent_last']:.3g}, first singular frame {first}, regular frames at extent >= 0.05 with a step >= 0.01: {len(big)}"
+          + (f" (steps {min(r['step_ref'] for r in big):.3g} .. {max(r['step_ref'] for r in big):.3g}, |pose difference| / step <= "
+             f"{max(r['pose_max'] / r['step_ref'] for r in big):.2e})" if big else ""))
+    assert s["E_last"] == 45312 and s["extent_last"] >= 0.05 and len(big) >= 10
 
 
 def test_negative_control_noop_bundle_adjustment(dev, RP, stream, monkeypatch):
@@ -281,16 +290,17 @@ def test_negative_control_noop_bundle_adjustment(dev, RP, stream, monkeypatch):
 
 
 def test_fast_yaml_lockstep(dev, RP, stream):
-    """config/fast.yaml:1-19 (48 patches per frame, REMOVAL_WINDOW 16, OPTIMIZATION_WINDOW 7, PATCH_LIFETIME 11 -> E = 13 008 in steady
-    state, appendix A.1): other plan windows, tile counts and M than every other tracker-level test.  40 frames teacher forced in the
-    bounded scenario: integer state bit-exact, every frame regular, absolute and step-relative bounds; and the one-call frame path is
-    the one that ran."""
+    """config/fast.yaml:1-19 (48 patches per frame, REMOVAL_WINDOW 16, OPTIMIZATION_WINDOW 7, PATCH_LIFETIME 11): other plan windows, tile
+    counts and M than every other tracker-level test.  Steady state E = 48 (16 x 11 + sum_{a<16} min(10, a)) = 48 (176 + 105) = 13 488
+    on BOTH trackers (SURVEY appendix A.1 prints 48 (176 + 95) = 13 008: the second sum is 0 + 1 + ... + 9 + 6 x 10 = 105).  44 frames
+    teacher forced in the bounded scenario: integer state bit-exact, every frame regular, absolute and step-relative bounds; and the
+    one-call frame path is the one that ran."""
     frames, intr = stream
     ours, theirs, _ = H.build_pair(dev, HT, WD, 48, KEYFRAME_THRESH=-1.0, **FAST, **WELL)
     recs = H.run_lockstep(ours, theirs, frames, 44, intr, feed=True, teacher=True, attribute_ba=True)
     s = _int_exact(recs, 44)
     first = _float_state("fast.yaml (bounded)", recs, min_regular=30)
-    assert first is None and s["E_last"] == 13008 and ours._fu is not None, (first, s["E_last"])
+    assert first is None and s["E_last"] == 13488 and ours._fu is not None, (first, s["E_last"])
 
 
 def test_teacher_forced_end_to_end_encoders(dev, RP, stream):

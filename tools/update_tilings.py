@@ -4,7 +4,7 @@ per tiling of dpvo_update_fused_params_t.tiling (include/dpvo_hip.h): bit 0 / 1 
 CU, bits 2 / 3 / 4 = last kernel / first kernel / chains in the 12-wave geometry.  Interleaved A/B/A/B rounds so that a clock drift of the
 box shows up as a spread, not as a difference.
 
-    python tools/update_tilings.py [tilings, default 1,5,9,13,29] [rounds, default 3]
+    python tools/update_tilings.py [tilings, default 1,5,9,13,29] [rounds, default 3] [start skews in us, default 0]
 """
 import os
 import sys
@@ -20,6 +20,8 @@ from dpvo_amd.graph import GraphPlan          # noqa: E402
 def main():
     tilings = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,5,9,13,29").split(",")]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    skews = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "0").split(",")]
+    tilings = [(t, k) for t in tilings for k in skews]
     dev = torch.device("cuda:0")
     i0, j0, k0 = S.replay_graph(40)
     cfg = S.GraphCfg()
@@ -45,7 +47,7 @@ def main():
     outs = {}
     for rd in range(rounds):
         for t in tilings:
-            upd.tiling = t
+            upd.tiling, upd.start_skew = t
             for _ in range(3):
                 o = upd(net, imap[None], corr[None], None, ii, jj, kk, **kw)
             outs[t] = o
@@ -60,8 +62,8 @@ def main():
     for t in tilings:
         ts = times[t]
         o = outs[t]
-        print(f"E={E} tiling {t:2d}: " + " ".join(f"{v:7.1f}" for v in ts) + f" us   best {min(ts):7.1f} us = {flops / min(ts) / 1e6 / 2500:.3f} of the dense f16 peak"
-              f"   net equal to tiling {tilings[0]}: {bool(torch.equal(o[0], ref[0]))}  |delta| diff {(o[1][0] - ref[1][0]).abs().max().item():.1e}  |weight| diff {(o[1][1] - ref[1][1]).abs().max().item():.1e}")
+        print(f"E={E} tiling {t[0]:2d} skew {t[1]:2d}: " + " ".join(f"{v:7.1f}" for v in ts) + f" us   best {min(ts):7.1f} us = {flops / min(ts) / 1e6 / 2500:.3f} of the dense f16 peak"
+              f"   net equal to tiling {tilings[0][0]}: {bool(torch.equal(o[0], ref[0]))}  |delta| diff {(o[1][0] - ref[1][0]).abs().max().item():.1e}  |weight| diff {(o[1][1] - ref[1][1]).abs().max().item():.1e}")
 
 
 if __name__ == "__main__":
