@@ -17,17 +17,17 @@
 //   HBM/L2-bound by design: ~52.9 KB of algorithmic traffic per edge for 0.3 MFLOP.
 #include "corr_dev.h"
 
-template <int OCC>
+// WIDE: ld_out == 896 and a 16-byte aligned output (what the tracker allocates): the row incl. its 14 zero padding columns leaves as
+// 112 sixteen-byte pieces, two per lane, instead of seven 4-byte pieces per lane and a padding loop.
+template <int OCC, bool WIDE>
 __global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel(
     const _Float16* __restrict__ gmap, const _Float16* __restrict__ fmap0, const _Float16* __restrict__ fmap1,
     const float* __restrict__ coords, const int64_t* __restrict__ us, const int64_t* __restrict__ vs,
     const int32_t* __restrict__ order, _Float16* __restrict__ out, int64_t ld_out, int64_t E, int H0, int W0,
     int H1, int W1, int N1, int N2) {
-  __shared__ __attribute__((aligned(16))) float raw[CORR_NPIX * CORR_MAXPOS];
-  __shared__ __attribute__((aligned(16))) _Float16 orow[2 * CORR_NOUT + 2];
-  __shared__ int meta_i[32];
-  __shared__ float meta_f[32];
+  __shared__ CorrShared sm;
   const int lane = threadIdx.x;
+  if (lane < 14) sm.orow[2 * CORR_NOUT + lane] = (_Float16)0;       // the padding columns 882..895: written once, never overwritten
   const int64_t nblk = order ? ((E + 7) >> 3) << 3 : E;
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     int64_t e = blk;
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel(
     }
     CORR_T(0);
     // ring-buffer indices (dpvo.py:202-203: ii % (M * pmem), jj % mem), reduced here instead of by two elementwise launches
-    const int64_t u = (int)us[e] % N1, v = (int)vs[e] % N2;
+    // (non-negative and < 2^31 by the entry's contract: unsigned remainders)
+    const int64_t u = (unsigned)us[e] % (unsigned)N1, v = (unsigned)vs[e] % (unsigned)N2;
     // A fragments: template pixel m = lane&15 (<9), channels [(4s+kg)*8, +8)
     h8 a[4];
     {
@@ -64,20 +65,27 @@ __global__ __launch_bounds__(64, OCC) void corr_pyramid_kernel(
     { float s0 = cx + (float)a[0][0]; asm volatile("" :: "v"(s0)); }        // (stamp 1 = indices, coordinates and templates have landed)
 #endif
     CORR_T(1);
-    corr_level(a, fmap0 + (int64_t)v * H0 * W0 * CORR_C, H0, W0, cx, cy, raw, meta_i, meta_f, lane, orow, 0);
+    corr_level(a, fmap0 + (int64_t)v * H0 * W0 * CORR_C, H0, W0, cx, cy, sm, lane, 0);
     CORR_T(3);
-    corr_level(a, fmap1 + (int64_t)v * H1 * W1 * CORR_C, H1, W1, cx * 0.25f, cy * 0.25f, raw, meta_i, meta_f, lane, orow, 1);
+    corr_level(a, fmap1 + (int64_t)v * H1 * W1 * CORR_C, H1, W1, cx * 0.25f, cy * 0.25f, sm, lane, 1);
     CORR_T(5);
-    // coalesced row store: 441 packed (level0, level1) words
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(orow);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
+    if constexpr (WIDE) {
+      const u4* src = reinterpret_cast<const u4*>(sm.orow);
+      u4* dst = reinterpret_cast<u4*>(out + e * ld_out);
+      dst[lane] = src[lane];
+      if (lane < CORR_ROW_BYTES / 16 - 64) dst[64 + lane] = src[64 + lane];
+    } else {
+      // coalesced row store: 441 packed (level0, level1) words
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(sm.orow);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const int q = lane + 64 * s;
-      if (q < CORR_NOUT) dst[q] = src[q];
+      for (int s = 0; s < 7; ++s) {
+        const int q = lane + 64 * s;
+        if (q < CORR_NOUT) dst[q] = src[q];
+      }
+      // zero the padding columns [882, ld_out)
+      for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
     }
-    // zero the padding columns [882, ld_out)
-    for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
     __syncthreads();
     CORR_T(6);
   }
@@ -194,9 +202,14 @@ extern "C" int dpvo_corr_pyramid_forward(const void* gmap, const void* fmap0, co
   // three waves per SIMD (launch bound of the kernel): 2 / 3 measure the same, 4 and 5 are slower (263 -> 275 -> 332 us, round 2).
   // Rounds 1-3 read DPVO_CORR_OCC from the environment once per process into a static; a library entry has no business doing
   // either: one instantiation, no state.
-  hipLaunchKernelGGL(corr_pyramid_kernel<3>, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
-                     (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
-                     (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2);
+  if (ld_out == CORR_ROW_BYTES / 2 && ((uintptr_t)out & 15) == 0)
+    hipLaunchKernelGGL((corr_pyramid_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+                       (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
+                       (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2);
+  else
+    hipLaunchKernelGGL((corr_pyramid_kernel<3, false>), dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+                       (const _Float16*)gmap, (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, order,
+                       (_Float16*)out, ld_out, E, H0, W0, H1, W1, (int)N1, (int)N2);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

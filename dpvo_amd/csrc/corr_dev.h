@@ -19,6 +19,18 @@ __device__ unsigned long long* g_corr_trace = nullptr;
 #define CORR_NPIX 9
 #define CORR_NOUT 441          // 7*7*9 outputs per level
 #define CORR_MAXPOS 144        // bounding boxes up to 144 positions (e.g. 12x12) take the single-pass path
+#define CORR_RS 12             // floats per POSITION of the raw volume: patch pixels 0..8, then three padding rows (written, never read)
+#define CORR_RAWPOS 192         // 12 MFMA tiles of 16 positions: the tile loop runs in batches of CORR_U = 4 and stores every tile it runs
+#define CORR_ROW_BYTES 1792    // one output row incl. the zero padding columns 882..895 when ld_out == 896
+
+// The workgroup's LDS (one wave = one edge).  raw[pos][m]: dot(template m, feature at bounding-box position pos), position-major so
+// that a lane's four accumulator rows of one MFMA tile are ONE ds_write_b128 (rounds 1-5: raw[m][pos], four exec-masked ds_write_b32 per
+// tile -- the store predicates alone were ~250 of the kernel's ~760 scalar instructions per edge and level: round 6, §3.1).
+struct CorrShared {
+  float raw[CORR_RAWPOS * CORR_RS];                          // 9 216 B
+  __attribute__((aligned(16))) _Float16 orow[CORR_ROW_BYTES / 2];      // the [882] row, both levels interleaved, + 14 zero columns
+  __attribute__((aligned(16))) f4 meta[16];                  // per patch pixel: {dx, dy, bit pattern of its window's first position, 0}
+};
 
 __device__ __forceinline__ int safe_floor_int(float v) {
   float f = floorf(v);
@@ -33,26 +45,69 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ h8 as_h8(u4 v) { return __builtin_bit_cast(h8, v); }
 
-// raw[m * np + pos] for m < 9, pos < np = bw*bh: dot(template m, feature(y0+pos/bw, x0+pos%bw)), 0 if OOB.
-// Features are fetched with bounds-checked buffer loads (out-of-image / padding lanes get an offset
-// beyond num_records and read zeros without a branch); CORR_U tiles (= 16 x 16 B per lane) are put in
-// flight before the first MFMA consumes them.
+// Bounding box of the nine patch pixels (lanes 0..8; the other lanes of row 0 carry the identities): min / max over lanes 0..15 of
+// row 0, result in lane 15 -- sixteen v_{min,max}_i32 with a DPP row shift each (a lane without a source is not written: it keeps its
+// own value) instead of sixteen ds_bpermute round trips with their index arithmetic.  Hand-placed: the compiler expands
+// __builtin_amdgcn_update_dpp into mov + mov_dpp + min with s_nops between dependent steps; here the four independent chains are
+// interleaved, so every DPP read is three instructions behind the write it depends on (two wait states required).
+__device__ __forceinline__ void bbox_reduce(int& mnx, int& mxx, int& mny, int& mxy) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_i32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(mnx), "+v"(mxx), "+v"(mny), "+v"(mxy));
+}
+
+// raw[pos][m] for pos < np = bw*bh (and the padding positions of the last tile), m < 12: dot(template m, feature(y0+pos/bw, x0+pos%bw)),
+// 0 if out of the image.  Features are fetched with bounds-checked buffer loads: a lane whose position is outside the image or is tile
+// padding gets the offset 0x8000'0000 (beyond num_records, and far from the 2^32 wrap of offset + instruction offset + 16) and reads
+// zeros without a branch.  CORR_U tiles (= 16 x 16 B per lane) are put in flight before the first MFMA consumes them.
 #define CORR_U 4
-__device__ __forceinline__ void corr_bbox_mfma(const h8 (&a)[4], __amdgpu_buffer_rsrc_t rsrc, int H, int W, int x0,
-                                               int y0, int bw, int bh, float* __restrict__ raw, int lane) {
-  const int np = bw * bh;
+// QUADLOAD (tools/probes/corr_variant.hip only; results WRONG on purpose): four consecutive lanes fetch the 64 contiguous bytes of ONE
+// position instead of 16 bytes of four positions 256 bytes apart -- what the window loads would cost if the L1's request stream were
+// coalesced per quad (the MFMA fragment layout ties a lane's low four bits to the position, so the product cannot load this way).
+template <bool QUADLOAD = false>
+__device__ __forceinline__ void corr_bbox_mfma(const h8 (&a)[4], __amdgpu_buffer_rsrc_t rsrc, int H, int W, int x0, int y0, int bw, int np,
+                                               bool any_in, float* __restrict__ raw, int lane) {
   const int n = lane & 15, kg = lane >> 4;
   const int ntiles = (np + 15) >> 4;
-  const float inv_bw = 1.0f / (float)bw;   // pos / bw via float: exact for pos < 2^12 (distance to an integer >= 0.5/bw)
+  float* sp = raw + n * CORR_RS + 4 * kg;      // this lane's four accumulator rows m = 4 kg .. 4 kg + 3 of tile 0
+  if (!any_in) {                               // (uniform) the whole box is outside the image: zeros, no loads
+    if (kg < 3)
+      for (int t = 0; t < ntiles; ++t) *reinterpret_cast<f4*>(sp + t * 16 * CORR_RS) = (f4){0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const float inv_bw = 1.0f / (float)bw;       // pos / bw via float: exact for pos < 2^12 (distance to an integer >= 0.5/bw)
+  const float half_inv = 0.5f * inv_bw;
   for (int t0 = 0; t0 < ntiles; t0 += CORR_U) {
     u4 b[CORR_U][4];
 #pragma unroll
     for (int u = 0; u < CORR_U; ++u) {
-      const int pos = (t0 + u) * 16 + n;
-      const int py = (int)(((float)pos + 0.5f) * inv_bw), px = pos - py * bw;
+      const int pos = (t0 + u) * 16 + (QUADLOAD ? (lane >> 2) : n);
+      const int py = (int)fmaf((float)pos, inv_bw, half_inv), px = pos - __mul24(py, bw);
       const int y = y0 + py, x = x0 + px;
-      const bool ok = (pos < np) && (y >= 0) && (y < H) && (x >= 0) && (x < W);
-      const unsigned voff = ok ? (unsigned)(((y * W + x) * CORR_C + kg * 8) * 2) : 0x80000000u;
+      const bool ok = (pos < np) & ((unsigned)x < (unsigned)W) & ((unsigned)y < (unsigned)H);
+      // (24-bit multiplies: the caller's `any_in` keeps |y| < 2^11, W < 2^15.  The address is computed for every lane and the invalid
+      //  ones are redirected by mask arithmetic: as `ok ? address : 0x80000000` the compiler computes the address under an exec mask --
+      //  two scalar instructions and a branch shadow per tile)
+      const unsigned addr = (unsigned)(__mul24(y, W) + x) * (CORR_C * 2) + (QUADLOAD ? (lane & 3) : kg) * 16;
+      const unsigned keep = ok ? 0xffffffffu : 0u;
+      const unsigned voff = (addr & keep) | (~keep & 0x80000000u);
 #pragma unroll
       for (int s = 0; s < 4; ++s) b[u][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + s * 64, 0, 0);
     }
@@ -61,69 +116,56 @@ __device__ __forceinline__ void corr_bbox_mfma(const h8 (&a)[4], __amdgpu_buffer
       f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], as_h8(b[u][s]), acc, 0, 0, 0);
-      // D[row = 4*(lane>>4)+r][col = lane&15]; rows are the patch pixels (only 0..8 are real)
-      const int pos = (t0 + u) * 16 + n;
-      if (pos < np) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 4 * kg + r;
-          if (m < CORR_NPIX) raw[m * np + pos] = acc[r];
-        }
-      }
+      // D[row = 4*(lane>>4)+r][col = lane&15]; rows are the patch pixels (0..8 real, 9..11 padding; 12..15 not stored)
+      if (kg < 3) *reinterpret_cast<f4*>(sp + (t0 + u) * 16 * CORR_RS) = acc;
     }
   }
 }
 
 // One level: blends this level's 441 outputs from the raw volume into the LDS row image
 // orow[q*2 + level] (f16), q = ((x*7+y)*3+i0)*3+j0.
-__device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fmap, int H, int W,
-                                           float cx, float cy, float* __restrict__ raw, int* __restrict__ meta_i,
-                                           float* __restrict__ meta_f, int lane, _Float16* __restrict__ orow,
-                                           int level) {
+template <bool QUADLOAD = false>
+__device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fmap, int H, int W, float cx, float cy, CorrShared& sm,
+                                           int lane, int level) {
+  float* __restrict__ raw = sm.raw;
+  _Float16* __restrict__ orow = sm.orow;
   // lanes 0..8 own one patch pixel each
-  int fx = safe_floor_int(cx), fy = safe_floor_int(cy);
-  float dx = cx - floorf(cx), dy = cy - floorf(cy);
-  int mnx = (lane < CORR_NPIX) ? fx : INT_MAX, mxx = (lane < CORR_NPIX) ? fx : INT_MIN;
-  int mny = (lane < CORR_NPIX) ? fy : INT_MAX, mxy = (lane < CORR_NPIX) ? fy : INT_MIN;
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    mnx = min(mnx, __shfl_xor(mnx, o)); mxx = max(mxx, __shfl_xor(mxx, o));
-    mny = min(mny, __shfl_xor(mny, o)); mxy = max(mxy, __shfl_xor(mxy, o));
-  }
-  mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);
-  mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
-  const int64_t bw64 = (int64_t)mxx - mnx + CORR_D, bh64 = (int64_t)mxy - mny + CORR_D;
-  const bool single = (bw64 * bh64 <= CORR_MAXPOS);
-
-  if (lane < CORR_NPIX) { meta_f[lane] = dx; meta_f[16 + lane] = dy; }
+  const int fx = safe_floor_int(cx), fy = safe_floor_int(cy);
+  const float dx = cx - floorf(cx), dy = cy - floorf(cy);
+  const bool pl = lane < CORR_NPIX;
+  int rnx = pl ? fx : INT_MAX, rxx = pl ? fx : INT_MIN, rny = pl ? fy : INT_MAX, rxy = pl ? fy : INT_MIN;
+  bbox_reduce(rnx, rxx, rny, rxy);
+  const int mnx = __builtin_amdgcn_readlane(rnx, 15), mxx = __builtin_amdgcn_readlane(rxx, 15);
+  const int mny = __builtin_amdgcn_readlane(rny, 15), mxy = __builtin_amdgcn_readlane(rxy, 15);
+  const int bw = mxx - mnx + CORR_D, bh = mxy - mny + CORR_D;      // (|coordinates| <= 1e6: no overflow)
+  const bool single = (bw <= CORR_MAXPOS) & (bh <= CORR_MAXPOS) && (bw * bh <= CORR_MAXPOS);
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)fmap, (short)0, H * W * CORR_C * 2, 0x00020000);
 
   if (single) {
-    const int bw = (int)bw64, bh = (int)bh64;
     const int x0 = mnx - CORR_R, y0 = mny - CORR_R;
-    if (lane < CORR_NPIX) { meta_i[lane] = fx - mnx; meta_i[16 + lane] = fy - mny; }
-    corr_bbox_mfma(a, rsrc, H, W, x0, y0, bw, bh, raw, lane);
+    const int np = bw * bh;
+    if (pl) sm.meta[lane] = (f4){dx, dy, __int_as_float((fy - mny) * bw + (fx - mnx)), 0.f};
+    const bool any_in = (x0 + bw > 0) & (x0 < W) & (y0 + bh > 0) & (y0 < H);
+    corr_bbox_mfma<QUADLOAD>(a, rsrc, H, W, x0, y0, bw, np, any_in, raw, lane);
     __syncthreads();
     CORR_T(2 + 2 * level);
-    const int np = bw * bh;
     // Blend (correlation_kernel.cu:221-230): lane = (patch pixel p = lane % 9, window column bx = lane / 9) walks the 7 window
     // rows ay of its column.  Its four weights are computed once, every raw row is read once (the lower pair of row ay is the
-    // upper pair of row ay + 1), no index arithmetic is left inside the loop -- rounds 1-3 gave every lane 7 arbitrary outputs
-    // (q = lane + 64 s: two integer divisions, six LDS look-ups and the weight products PER OUTPUT): ~280 of the kernel's 815
-    // VALU instructions per edge and level, in a kernel that tools/corr_variants.sh shows to be bound by exactly those (with every
-    // window load served cache-hot it still takes 187 of its 270 us).  Same products, same order of additions: same bits.
+    // upper pair of row ay + 1), no index arithmetic is left inside the loop.  Same products, same order of additions as rounds 1-5.
     if (lane < 63) {
       const int p = lane % 9, bx = lane / 9;
-      const float ddx = meta_f[p], ddy = meta_f[16 + p];
+      const f4 m = sm.meta[p];
+      const float ddx = m[0], ddy = m[1];
       const float w00 = (1.f - ddx) * (1.f - ddy), w01 = ddx * (1.f - ddy), w10 = (1.f - ddx) * ddy, w11 = ddx * ddy;
-      const float* rp = raw + p * np + meta_i[16 + p] * bw + meta_i[p] + bx;
+      const float* rp = raw + (__float_as_int(m[2]) + bx) * CORR_RS + p;
+      const int rstep = bw * CORR_RS;
       _Float16* op = orow + 2 * (bx * 63 + p) + level;          // q = (bx * 7 + ay) * 9 + p
-      float a0 = rp[0], a1 = rp[1];
+      float a0 = rp[0], a1 = rp[CORR_RS];
 #pragma unroll
       for (int ay = 0; ay < 7; ++ay) {
-        rp += bw;
-        const float b0 = rp[0], b1 = rp[1];
+        rp += rstep;
+        const float b0 = rp[0], b1 = rp[CORR_RS];
         float o = w00 * a0;
         o += w01 * a1;
         o += w10 * b0;
@@ -135,21 +177,20 @@ __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fma
     __syncthreads();
   } else {
     // scattered windows (extreme scale change / far out of bounds): one 8x8 box per patch pixel
+    if (pl) sm.meta[lane] = (f4){dx, dy, 0.f, 0.f};
 #pragma unroll 1
     for (int p = 0; p < CORR_NPIX; ++p) {
-      const int pfx = __shfl(fx, p), pfy = __shfl(fy, p);
+      const int pfx = __builtin_amdgcn_readlane(fx, p), pfy = __builtin_amdgcn_readlane(fy, p);
       const int x0 = pfx - CORR_R, y0 = pfy - CORR_R;
-      const bool any_in = (x0 + CORR_D > 0) && (x0 < W) && (y0 + CORR_D > 0) && (y0 < H);
-      if (any_in) corr_bbox_mfma(a, rsrc, H, W, x0, y0, CORR_D, CORR_D, raw, lane);
+      const bool any_in = (x0 + CORR_D > 0) & (x0 < W) & (y0 + CORR_D > 0) & (y0 < H);
+      corr_bbox_mfma<QUADLOAD>(a, rsrc, H, W, x0, y0, CORR_D, CORR_D * CORR_D, any_in, raw, lane);
       __syncthreads();
       if (lane < 49) {                       // 49 outputs of pixel p: lane = bx*7 + ay
         const int bx = lane / 7, ay = lane - bx * 7;
-        const float ddx = meta_f[p], ddy = meta_f[16 + p];
-        float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
-        if (any_in) {
-          const float* rp = raw + p * 64 + ay * CORR_D + bx;
-          c00 = rp[0]; c01 = rp[1]; c10 = rp[CORR_D]; c11 = rp[CORR_D + 1];
-        }
+        const f4 m = sm.meta[p];
+        const float ddx = m[0], ddy = m[1];
+        const float* rp = raw + (ay * CORR_D + bx) * CORR_RS + p;
+        const float c00 = rp[0], c01 = rp[CORR_RS], c10 = rp[CORR_D * CORR_RS], c11 = rp[(CORR_D + 1) * CORR_RS];
         float o = (1.f - ddx) * (1.f - ddy) * c00;
         o += ddx * (1.f - ddy) * c01;
         o += (1.f - ddx) * ddy * c10;

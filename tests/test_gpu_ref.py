@@ -143,7 +143,7 @@ def _run_both(rb, dev, poses, patches, intr, target, weight, ii, jj, kk, t0, t1,
     return rp[0].cpu(), rpt[0].cpu(), hp.cpu(), hpt.cpu()
 
 
-@pytest.mark.parametrize("case", ["small", "small_init", "full"])
+@pytest.mark.parametrize("case", ["small", "small_init", "full", "fast"])
 def test_ba_vs_reference_kernel(ref, oracle, dev, case):
     """cuda_ba.forward, eff_impl=False (ba_cuda.cu:433-582): two Gauss-Newton iterations in f32 with float atomics on the
     reference side (run-to-run noise ~1e-6) and ordered f32 reductions here.  Same stated tolerance as against the oracle:
@@ -151,6 +151,9 @@ def test_ba_vs_reference_kernel(ref, oracle, dev, case):
     _, rb = ref
     if case == "full":
         ii, jj, kk = S.replay_graph(40); n, M, t0, t1 = 40, 96, 30, 40
+    elif case == "fast":            # config/fast.yaml:4-7: 48 patches, windows 16 / 7 / 11 -> E = 13 488, 7 free poses
+        ii, jj, kk = S.replay_graph(40, S.GraphCfg(M=48, REMOVAL_WINDOW=16, OPTIMIZATION_WINDOW=7, PATCH_LIFETIME=11)); n, M, t0, t1 = 40, 48, 33, 40
+        assert ii.numel() == 13488
     else:
         ii, jj, kk, _ = H.small_graph(14, 8); n, M = 14, 8
         t0, t1 = (9, 14) if case == "small" else (1, 14)

@@ -297,7 +297,7 @@ def test_fused_tilings_are_bit_identical(dev, E_frames):
 _FULL_ORACLE = {}
 
 
-@pytest.mark.parametrize("path", ["default", "launch_by_launch"])
+@pytest.mark.parametrize("path", ["default", "launch_by_launch", "fast_yaml"])
 def test_update_full_size_vs_oracle(oracle, dev, path):
     """E = 45 312 (BASELINE config 2): ONE full Update.forward against oracle/update_ref.py on every edge (f64 math with the
     autocast rounding points; ~20 s of CPU, computed once for the two cases).  "default" is exactly what DPVO.update() and
@@ -311,19 +311,25 @@ def test_update_full_size_vs_oracle(oracle, dev, path):
         for p in upd.parameters():
             if p.dim() == 1:
                 p.add_(0.05 * torch.randn_like(p))
-    ii, jj, kk = S.replay_graph(40)
-    E = ii.numel()
-    assert E == 45312
+    if path == "fast_yaml":     # config/fast.yaml:4-7: other tile counts (141 row tiles of 96: less than one per CU), M = 48 per frame pair
+        ii, jj, kk = S.replay_graph(40, S.GraphCfg(M=48, REMOVAL_WINDOW=16, OPTIMIZATION_WINDOW=7, PATCH_LIFETIME=11))
+        E = ii.numel()
+        assert E == 13488
+    else:
+        ii, jj, kk = S.replay_graph(40)
+        E = ii.numel()
+        assert E == 45312
     g = torch.Generator().manual_seed(11)
     net = torch.randn(E, 384, generator=g); inp = torch.randn(E, 384, generator=g).half()
     corr = torch.randn(E, 882, generator=g).half()
     sd = {k: v for k, v in upd.state_dict().items()}
-    if "ref" not in _FULL_ORACLE:
-        _FULL_ORACLE["ref"] = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
-    rn, rd, rw = _FULL_ORACLE["ref"]
+    okey = "fast" if path == "fast_yaml" else "ref"
+    if okey not in _FULL_ORACLE:
+        _FULL_ORACLE[okey] = update_ref.update_forward(sd, net, inp, corr, ii, jj, kk, half_scatter=False)
+    rn, rd, rw = _FULL_ORACLE[okey]
     upd = upd.to(dev)
     args = (net[None].to(dev), inp[None].to(dev), corr[None].to(dev), None, ii.to(dev), jj.to(dev), kk.to(dev))
-    if path == "default":
+    if path in ("default", "fast_yaml"):
         assert N.FUSED_DEFAULT and upd.tiling == -1 and upd.start_skew == 0
         out, (d, w, _) = upd(*args)
     else:

@@ -8,7 +8,9 @@
 //   6: the per-edge FIXED work made free -- ring indices computed instead of loaded, the nine templates taken from patch 0 (cache-hot),
 //      coordinates still loaded: the most that several edges of one patch per workgroup sharing the index / template round trips
 //       could save;  7: as 6, and the output row is not written (the most a correlation fused into the update
-//      operator's first kernel could save on THIS side of the fusion).
+//      operator's first kernel could save on THIS side of the fusion);
+//   8: the window loads with four consecutive lanes fetching 64 contiguous bytes of ONE position (corr_dev.h: QUADLOAD) -- what the
+//      kernel would cost if the L1's request stream were coalesced per quad of lanes (round 6).
 #include "../../dpvo_amd/csrc/corr_dev.h"
 
 template <int VARIANT>
@@ -16,15 +18,14 @@ __global__ __launch_bounds__(64, 3) void corr_pyramid_variant_kernel(
     const _Float16* __restrict__ gmap, const _Float16* __restrict__ fmap0, const _Float16* __restrict__ fmap1,
     const float* __restrict__ coords, const int64_t* __restrict__ us, const int64_t* __restrict__ vs, _Float16* __restrict__ out,
     int64_t ld_out, int64_t E, int H0, int W0, int H1, int W1, int N1, int N2) {
-  __shared__ __attribute__((aligned(16))) float raw[CORR_NPIX * CORR_MAXPOS];
-  __shared__ __attribute__((aligned(16))) _Float16 orow[2 * CORR_NOUT + 2];
-  __shared__ int meta_i[32];
-  __shared__ float meta_f[32];
+  __shared__ CorrShared sm;
+  constexpr bool Q = VARIANT == 8;
   const int lane = threadIdx.x;
+  if (lane < 14) sm.orow[2 * CORR_NOUT + lane] = (_Float16)0;
   for (int64_t e = blockIdx.x; e < E; e += gridDim.x) {
     int64_t u, v;
     if constexpr (VARIANT == 6 || VARIANT == 7) { u = 0; v = (int)(e / 1326) % N2; }      // (1 326 = E / 36: same frames, no dependent loads)
-    else { u = (int)us[e] % N1; v = (int)vs[e] % N2; }
+    else { u = (unsigned)us[e] % (unsigned)N1; v = (unsigned)vs[e] % (unsigned)N2; }
     h8 a[4];
     {
       const int m = lane & 15, kg = lane >> 4;
@@ -44,28 +45,25 @@ __global__ __launch_bounds__(64, 3) void corr_pyramid_variant_kernel(
     }
     if constexpr (VARIANT != 2) {
       if constexpr (VARIANT == 5)
-        corr_level(a, fmap0, H0, W0, 20.f + (cx - floorf(cx)), 20.f + (cy - floorf(cy)), raw, meta_i, meta_f, lane, orow, 0);
+        corr_level(a, fmap0, H0, W0, 20.f + (cx - floorf(cx)), 20.f + (cy - floorf(cy)), sm, lane, 0);
       else
-        corr_level(a, fmap0 + (int64_t)v * H0 * W0 * CORR_C, H0, W0, cx, cy, raw, meta_i, meta_f, lane, orow, 0);
+        corr_level<Q>(a, fmap0 + (int64_t)v * H0 * W0 * CORR_C, H0, W0, cx, cy, sm, lane, 0);
     }
     if constexpr (VARIANT != 1) {
       if constexpr (VARIANT == 4 || VARIANT == 5)
-        corr_level(a, fmap1, H1, W1, 10.f + (cx * 0.25f - floorf(cx * 0.25f)), 10.f + (cy * 0.25f - floorf(cy * 0.25f)), raw, meta_i, meta_f,
-                   lane, orow, 1);
+        corr_level(a, fmap1, H1, W1, 10.f + (cx * 0.25f - floorf(cx * 0.25f)), 10.f + (cy * 0.25f - floorf(cy * 0.25f)), sm, lane, 1);
       else
-        corr_level(a, fmap1 + (int64_t)v * H1 * W1 * CORR_C, H1, W1, cx * 0.25f, cy * 0.25f, raw, meta_i, meta_f, lane, orow, 1);
+        corr_level<Q>(a, fmap1 + (int64_t)v * H1 * W1 * CORR_C, H1, W1, cx * 0.25f, cy * 0.25f, sm, lane, 1);
     }
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(orow);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
     if constexpr (VARIANT == 7) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(sm.orow);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(out + e * ld_out);
       if (src[lane] == 0x7fff7fffu) dst[lane] = 1;       // (keeps the blend alive without the row store)
-    } else {
-#pragma unroll
-      for (int s = 0; s < 7; ++s) {
-        const int q = lane + 64 * s;
-        if (q < CORR_NOUT) dst[q] = src[q];
-      }
-      for (int64_t c = 2 * CORR_NOUT + lane; c < ld_out; c += 64) out[e * ld_out + c] = (_Float16)0;
+    } else {                                             // (ld_out == 896, 16-byte aligned: the product's wide row store)
+      const u4* src = reinterpret_cast<const u4*>(sm.orow);
+      u4* dst = reinterpret_cast<u4*>(out + e * ld_out);
+      dst[lane] = src[lane];
+      if (lane < CORR_ROW_BYTES / 16 - 64) dst[64 + lane] = src[64 + lane];
     }
     __syncthreads();
   }
@@ -76,6 +74,7 @@ extern "C" int dpvo_corr_pyramid_variant(const void* gmap, const void* fmap0, co
                                          const int64_t* vs, void* out, int64_t ld_out, int64_t E, int64_t N1, int64_t N2, int H0, int W0,
                                          int H1, int W1, int variant, void* stream) {
   if (E <= 0 || !gmap || !fmap0 || !fmap1 || !coords || !us || !vs || !out) return DPVO_E_INVALID;
+  if (ld_out != CORR_ROW_BYTES / 2 || ((uintptr_t)out & 15)) return DPVO_E_UNSUPPORTED;
 #define CV(V)                                                                                                                    \
   hipLaunchKernelGGL(corr_pyramid_variant_kernel<V>, dim3((unsigned)E), dim3(64), 0, (hipStream_t)stream, (const _Float16*)gmap,  \
                      (const _Float16*)fmap0, (const _Float16*)fmap1, coords, us, vs, (_Float16*)out, ld_out, E, H0, W0, H1, W1,  \
@@ -88,6 +87,7 @@ extern "C" int dpvo_corr_pyramid_variant(const void* gmap, const void* fmap0, co
     case 5: CV(5); break;
     case 6: CV(6); break;
     case 7: CV(7); break;
+    case 8: CV(8); break;
     default: return DPVO_E_UNSUPPORTED;
   }
 #undef CV
