@@ -23,9 +23,6 @@
 //   dpvo_gba_solve       S += I*(1e-4*S+1); blocked Cholesky + both substitutions on the device (chol.hip)
 //   gba_retr_kernel      dZ = Q (u - e^T dX), depth + pose retraction
 #include "ba_common.h"
-#ifndef GBA_FUSE_SP
-#define GBA_FUSE_SP 1     // 0: gba_scatter_kernel and gba_patch_kernel as two launches (rounds 3-5)
-#endif
 
 namespace {
 using namespace ba;
@@ -149,22 +146,6 @@ __global__ __launch_bounds__(256) void gba_scatter_patch_kernel(GbaSP A) {
   else
     gba_scatter_body(A.kk, A.perm_p, A.pair_off, A.n_pairs, A.edgebuf, A.Ecol, A.M, (int)blockIdx.x - A.n_patch, (int)gridDim.x - A.n_patch, 2, sl, se);
 }
-#if !GBA_FUSE_SP
-__global__ __launch_bounds__(128) void gba_scatter_kernel(const int64_t* __restrict__ kk, const int32_t* __restrict__ perm_p,
-                                                          const int32_t* __restrict__ pair_off, const int32_t* __restrict__ n_pairs,
-                                                          const float* __restrict__ edgebuf, float* __restrict__ Ecol, int M) {
-  __shared__ int sl[1][128];
-  __shared__ int se[1][128];
-  gba_scatter_body(kk, perm_p, pair_off, n_pairs, edgebuf, Ecol, M, (int)blockIdx.x, (int)gridDim.x, 1, sl, se);
-}
-__global__ void gba_patch_kernel(const int32_t* __restrict__ perm_k, const int32_t* __restrict__ patch_off,
-                                 const int32_t* __restrict__ kx, const int32_t* __restrict__ n_patches,
-                                 const float* __restrict__ edgebuf, float lmbda, int M, int f0, int n_frames,
-                                 float* __restrict__ Q, float* __restrict__ U, float* __restrict__ Eself) {
-  gba_patch_body(perm_k, patch_off, kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself,
-                 (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
-}
-#endif
 
 // Q, u, Eself = 0 in front of a linearisation (hipMemsetAsync of these ~0.3 MB is a 23 us fill on this runtime,
 // profiles/r05_e_lc_timeline.txt; a plain store kernel is a launch)
@@ -275,15 +256,6 @@ __global__ __launch_bounds__(1024) void gba_index_kernel(const int32_t* __restri
 // alternative: the frame's blocks staged in LDS + the row in an LDS strip, 16 waves: slower (two barriers and a 64 KB copy per
 // source frame); the atomics version this replaces: 0.28 ms.)  `S` and `y` must be zero on entry.
 constexpr int kRowWaves = 16;
-#ifndef GBA_XCD
-#define GBA_XCD 1        // 0: workgroup b = (pose, part) number b (rounds 4-5)
-#endif
-#ifndef GBA_TILE96
-#define GBA_TILE96 1     // 0: the tile's operands 48 slots at a time whatever M (rounds 4-5)
-#endif
-#ifndef GBA_BV_REG
-#define GBA_BV_REG 1      // 0: the B / v part as one read-modify-write chain per pair (rounds 4-5; tools/gba_bv_ab.sh builds it for the comparison)
-#endif
 #ifdef GBA_TRACE
 // instrumentation build (tools/gba_trace.sh): wave 0 of the workgroup of the middle pose stamps the 100 MHz wall clock
 __device__ unsigned long long gba_trace_buf[96];
@@ -305,12 +277,8 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   // the blocks of the same ~40 source frames, 3-4 MB: an XCD's L2 -- share an XCD instead of being dealt out round robin over all
   // eight (the E blocks, 13 MB at the bench leg's size, then come from the Infinity Cache at twice the latency).  Placement only:
   // every entry is still written by the same wave in the same order.
-#if GBA_XCD
   const int chunk_ = ((int)gridDim.x + 7) / 8;
   const int lidx_ = ((int)blockIdx.x % 8) * chunk_ + (int)blockIdx.x / 8;
-#else
-  const int lidx_ = (int)blockIdx.x;
-#endif
   if (lidx_ >= N * split) return;
   const int p = lidx_ / split, part_ = lidx_ - p * split, j = p + t0;
   GT(0);
@@ -328,7 +296,6 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
   const bool own = frj >= 0 && frj < n_frames;
   const int ja = own ? run_lo[frj] : 0, jb = own ? run_lo[frj + 1] : 0;
   // ---- B and v (ba_cuda.cu:335-349,363-368): pairs with source j, then pairs with target j, ascending pair index each
-#if GBA_BV_REG
   // Round 5 (last session).  The two loops used to be one dependent chain per pair for EVERY wave of the row: the pair's target (loop 1)
   // resp. the list entry, then the pair's source (loop 2) loaded one at a time just to find out whose column it is, and the diagonal
   // block and y[p] read-modify-written in memory once per pair -- ~60 pairs x 2-3 round trips in front of the Schur terms.  Now the
@@ -406,23 +373,6 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
     if (dl) Srow[(int64_t)r36 * n6 + 6 * p + c36] = dacc;
     if (yl) y[6 * p + lane] = yacc;
   }
-#else
-  for (int g = ja; g < jb; ++g) {
-    const float* pb = pairbuf + (int64_t)g * kPairStride;
-    const int jx = pair_ij[2 * g + 1] - t0;
-    if (wave == (p % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[r36 * 16 + c36];
-    if (jx >= 0 && jx < N && wave == (jx % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * jx + c36] -= pb[r36 * 16 + 6 + c36];
-    if (wave == 0 && lane < 6) y[6 * p + lane] -= pb[lane * 16 + 12];
-  }
-  for (int q = tl0; q < tl1; ++q) {
-    const int g = tgt_list[q];
-    const float* pb = pairbuf + (int64_t)g * kPairStride;
-    const int ix = pair_ij[2 * g] - t0;
-    if (wave == (p % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * p + c36] += pb[(6 + r36) * 16 + 6 + c36];
-    if (ix >= 0 && ix < N && wave == (ix % kRowCls) && lane < 36) Srow[(int64_t)r36 * n6 + 6 * ix + c36] -= pb[c36 * 16 + 6 + r36];   // mirror of block (ix, p)
-    if (wave == 0 && lane < 6) y[6 * p + lane] += pb[(6 + lane) * 16 + 12];
-  }
-#endif
   // ---- Schur terms: every source frame f that has a block with pose p -- the sources of the target list, and j itself (its
   //      self block; a pair (j, j) of self edges is in the target list too) -- in ascending f
   GT(1);
@@ -507,7 +457,6 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
           else if (rl) d0 = y + 6 * p + 4 * lk;
         }
         const int64_t dstride = li < 12 ? n6 : 1;
-#if GBA_TILE96
         {
           // (loaded by every lane, from somewhere readable when the lane has no entry: straight-line code, so that these loads and the
           //  operands' below are issued back to back -- behind a branch each the compiler waited for them group by group)
@@ -516,11 +465,6 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
 #pragma unroll
           for (int r = 0; r < 4; ++r) cur[r] = cs[(r < nr ? r : 0) * cst];
         }
-#else
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (d0 && r < nr) cur[r] = d0[r * dstride];
-#endif
         // operands: the blocks are stored component-major ([6][M]), so a lane's operands of FOUR chain steps are one 16-byte load: in
         // step (u, c) the four k-lanes of the tile take the slots 16 u + 4 lk + c.  48 slots per trip: 9 loads in flight, then 12
         // MFMAs.  (Slot-major blocks meant 72 four-byte gathers per tile and wave; a CU's 16 waves push them through one texture
@@ -539,7 +483,6 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
         };
         const float* arow = Ea + (int64_t)(li < 6 ? li : 0) * M;
         const float* brow = Eb ? Eb + (int64_t)cj * M : (rl ? Uf : nullptr);
-#if GBA_TILE96
         // M = 96 (default.yaml's PATCHES_PER_FRAME): all 18 operand loads of the tile in flight at once, then the 24 MFMAs in the same
         // order -- one memory round trip per tile instead of one per 48 slots
         if (M == 96) {
@@ -561,7 +504,6 @@ __global__ __launch_bounds__(64 * kRowWaves) void gba_row_kernel(const int32_t* 
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][c], q4[u][c] * b4[u][c], acc, 0, 0, 0);
         } else
-#endif
         for (int s0 = 0; s0 < M; s0 += 48) {
           f4 a4[3], b4[3], q4[3];
 #pragma unroll
@@ -746,19 +688,12 @@ static int gba_linearize_impl(const float* poses, const float* patches, const fl
   if (!reuse_index)
     hipLaunchKernelGGL(gba_index_kernel, dim3(1), dim3(1024), 0, st, plan + PL.pair_ij, n_pairs, f0, n_frames, t0, N, run_lo,
                        tgt_off, tgt_cnt, tgt_list);
-#if GBA_FUSE_SP
   {
     const int n_patch_blocks = (int)((n_patches_h + 255) / 256);
     const GbaSP A = {kk, plan + PL.perm_p, plan + PL.pair_off, n_pairs, plan + PL.perm_k, plan + PL.patch_off, plan + PL.kx, n_patches,
                      edgebuf, Ecol, Q, U, Eself, lmbda, M, f0, n_frames, n_patch_blocks};
     hipLaunchKernelGGL(gba_scatter_patch_kernel, dim3((unsigned)n_patch_blocks + (pair_grid + 1) / 2), dim3(256), 0, st, A);
   }
-#else
-  hipLaunchKernelGGL(gba_scatter_kernel, dim3(pair_grid), dim3(128), 0, st, kk, plan + PL.perm_p, plan + PL.pair_off, n_pairs,
-                     edgebuf, Ecol, M);
-  hipLaunchKernelGGL(gba_patch_kernel, dim3((unsigned)((n_patches_h + 255) / 256)), dim3(256), 0, st, plan + PL.perm_k,
-                     plan + PL.patch_off, plan + PL.kx, n_patches, edgebuf, lmbda, M, f0, n_frames, Q, U, Eself);
-#endif
   {
     const int split = N <= 64 ? 4 : (N <= 128 ? 2 : 1);
     const unsigned nwg = (unsigned)((N * split + 7) / 8 * 8);       // (a multiple of 8: the XCD-major numbering of the kernel is a bijection on it)

@@ -20,18 +20,7 @@
 namespace {
 
 constexpr int TH = 8, TW = 32;           // output tile (pixels)
-#ifndef ENC_TH2
-#define ENC_TH2 4
-#endif
-#ifndef ENC_WN2
-#define ENC_WN2 2
-#endif
-#ifndef ENC_WN1
-#define ENC_WN1 2
-#endif
-#ifndef ENC_PD
-#define ENC_PD 5
-#endif
+constexpr int ENC_TH2 = 4, ENC_WN2 = 2, ENC_WN1 = 2, ENC_PD = 5;      // quarter-resolution tile height, wave tilings, weight prefetch depth (round 3)
 constexpr float kInEps = 1e-5f;          // nn.InstanceNorm2d default eps
 constexpr int kStatCopies = 16;          // accumulator copies per statistics set: spreads the same-address f64 atomics
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -311,20 +300,14 @@ __global__ __launch_bounds__(256) void conv_kernel(EncArgs args, int Hin, int Wi
   for (int t = 0; t < PD && t < T; ++t) wload(t, fwr[t]);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-#ifndef ENC_PROBE_NOW
     if (t + PD < T) wload(t + PD, fwr[(t + PD) % RING]);
-#endif
     const int kc = t % KC, kw = (t / KC) % KS, kh = t / (KC * KS);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int ly = row_of(i) * S + kh, lx = ((i & 1) * 16 + m) * S + kw;
       const int ch = kc * 4 + kg;
       const int sch = (CIN == 32) ? (ch ^ swz4(lx)) : (ch ^ (lx & 7));
-#ifdef ENC_PROBE_NOLDS
-      h8 fa = fwr[t % RING][i % NTW];
-#else
       const h8 fa = *reinterpret_cast<const h8*>(halo + ((int64_t)(ly * IW + lx) * CPP + sch) * 8);
-#endif
 #pragma unroll
       for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwr[t % RING][j], fa, acc[i][j], 0, 0, 0);
     }

@@ -447,31 +447,14 @@ extern "C" int dpvo_softagg(const void* fg, int64_t ldfg, const int32_t* perm, c
 
 
 
-#define FU_RT 3
-#ifndef FU_DW
-#define FU_DW 6
-#endif
-#ifndef FU_DW7
-#define FU_DW7 6
-#endif
-#ifndef FU_DW1
-#define FU_DW1 6
-#endif
-#ifndef FU_DW2
-#define FU_DW2 3
-#endif
-#ifndef FU_OCC2
+// One fixed set of tile shapes / weight-ring depths (the A/B switches of rounds 2-5 are gone; their measurements: DESIGN.md 3.4):
+#define FU_RT 3                // 96-row tiles (one workgroup per CU)
+#define FU_DW 6                // weight ring of the 4-wave kernels at one workgroup per CU
+#define FU_DW1 6               // ... of K1 there
+#define FU_RT2 2               // 64-row tiles (two workgroups per CU, 4 waves each)
+#define FU_DW2 3               // K1's ring there (spills beyond 3)
+#define FU_DW2C 6              // the chain kernels' ring there (6 fits 250 registers)
 #define FU_OCC2 2
-#endif
-#ifndef FU_RT2
-#define FU_RT2 2
-#endif
-#ifndef FU_RT2C
-#define FU_RT2C FU_RT2
-#endif
-#ifndef FU_DW2C
-#define FU_DW2C 6            // the chain kernels fit a 6-deep ring in 250 registers at two workgroups per CU (K1 spills beyond 3)
-#endif
 // chains: 64-row tiles x 2 workgroups per CU, 4 waves each (A/B in the frame, round 3: cfg 1 / 3 / 0 / 2 = 828 / 817 / 814 / 800 frames/sec on one
 // box); K1 and K7: 96-row tiles x 1 workgroup of TWELVE waves (round 6: 516 -> 483 us alone, 0.512 -> 0.483 ms in the frame, 956-966 -> 984-993
 // frames/sec on one box, profiles/r06_b_*; the chains gain nothing from the 12-wave geometry: 481 us with all five kernels on it)
@@ -532,8 +515,8 @@ extern "C" int dpvo_update_forward_fused_rows(const dpvo_update_fused_params_t* 
   for (int i = 0; i < DPVO_UF_NLIN; ++i)
     if (!p->w[i] || !p->b[i]) return DPVO_E_INVALID;
   constexpr int RT = FU_RT, DW = FU_DW;
-  constexpr int RT2 = FU_RT2, DW2 = FU_DW2, OCC2 = FU_OCC2;
-  constexpr int RT2C = FU_RT2C, DW2C = FU_DW2C;       // chain kernels' own tile height / ring at several workgroups per CU  // several workgroups per CU, 64-row tiles
+  constexpr int RT2 = FU_RT2, DW2 = FU_DW2, OCC2 = FU_OCC2;       // several workgroups per CU, 64-row tiles
+  constexpr int RT2C = FU_RT2, DW2C = FU_DW2C;
   const int cfg = (p->tiling < 0 ? FU_CFG_DEFAULT : p->tiling) & 31;
   const int skew = p->start_skew < 0 ? 0 : (p->start_skew > 1000 ? 1000 : p->start_skew);
   const int64_t maxg = n_patches_ub > n_pairs_ub ? n_patches_ub : n_pairs_ub;
