@@ -53,6 +53,8 @@ import time
 
 import torch
 
+PROFILE_EVERY = 4       # HIP events around the correlation kernel / the update operator on every 4th timed frame (see main())
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -192,7 +194,7 @@ def loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed, warm=70, ti
         c.LOOP_CLOSURE = True
         c.BUFFER_SIZE = max(c.BUFFER_SIZE, warm + timed + 80)
         torch.manual_seed(seed)
-        slam = DPVO(c, VONet(), ht=ht, wd=wd, device=device, defer_keyframe=True, overlap_encoders=True)
+        slam = DPVO(c, VONet(), ht=ht, wd=wd, device=device)
         slam.motion_probe = lambda: 1.0e9
         with torch.no_grad():
             for t in range(warm):
@@ -238,6 +240,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-baseline", action="store_true")
     ap.add_argument("--config", default="default", choices=["default", "fast"])
+    ap.add_argument("--update-tiling", type=int, default=None,
+                    help="measurements: dpvo_update_fused_params_t.tiling of the update operator (include/dpvo_hip.h; default: the library's)")
     ap.add_argument("--seed-offset", type=int, default=None, help="sequence / weight seed offset (default: the rank)")
     ap.add_argument("--drop-every", type=int, default=0,
                     help="k > 0: the keyframe test drops keyframe n - KEYFRAME_INDEX on every k-th frame (scripted decision: the "
@@ -268,10 +272,11 @@ def main():
     if world > 1:
         dist = multiseq.init_distributed(backend, device)          # (raises if RCCL cannot be brought up: never a silent gloo run)
 
-    os.environ.setdefault("DPVO_PROFILE_EVENTS", "1")      # the tracker creates its pool of timing events up front (warm-up), not in the timed region
+    import dpvo_amd.dpvo as dpvo_mod
+    dpvo_mod._PROFILE_POOL = True       # the tracker creates its pool of timing events up front (warm-up), not in the timed region
     # HIP events around the correlation kernel / the update operator on every 4th timed frame: each event record is a marker the
     # stream stalls on, three of them per frame cost ~10 us of every frame (946-955 -> 957-960 frames/sec on one box, 963 without any)
-    os.environ.setdefault("DPVO_PROFILE_EVERY", "4")
+    dpvo_mod._PROFILE_EVERY = PROFILE_EVERY
     from dpvo_amd import altcorr
     from dpvo_amd.altcorr import correlation as corr_mod
     from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML, FAST_YAML
@@ -294,10 +299,13 @@ def main():
     torch.manual_seed(1234 + seed_off)
     net = VONet()
     shared = world > 1 and backend != "nccl"        # smoke mode: ranks share a device (see docstring)
-    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, defer_keyframe=bool(int(os.environ.get("DPVO_DEFER_KEYFRAME", "1"))),      # decision of frame t resolved under frame t+1's encoders
-                # ... on a second HIP stream.  Not when several ranks share one device: two processes time-slicing a GPU
-                # with a multi-stream tracker each hit a memory access fault on this ROCm stack (profiles/README.md)
-                overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "0" if shared else "1"))))
+    # The tracker as a drop-in caller constructs it (demo.py:46: DPVO(cfg, network, ht, wd, viz)): since round 6 the defaults ARE the
+    # pipeline (decision of frame t resolved under frame t + 1's encoders, which run on a second HIP stream).  The one exception: several
+    # ranks sharing one device (smoke mode) -- two processes time-slicing a GPU with a multi-stream tracker each hit a memory access
+    # fault on this ROCm stack (profiles/README.md) -- run without the second stream.
+    slam = DPVO(cfg, net, ht=ht, wd=wd, device=device, **({"overlap_encoders": False} if shared else {}))
+    if args.update_tiling is not None:
+        slam.network.update.tiling = args.update_tiling
     slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
     if args.drop_every > 0:
         slam.keyframe_override = lambda counter: counter % args.drop_every == 0
@@ -395,7 +403,7 @@ def main():
     # frame-to-frame period on the device (start of one frame's correlation kernel to the next one's): with 20-60 timed frames one
     # hiccup moves `value` by several per cent -- the median says what the steady state is, the max what the hiccup was
     period = None
-    stride = max(1, int(os.environ.get("DPVO_PROFILE_EVERY", "1")))     # (events on every stride-th frame: a window is stride frames)
+    stride = PROFILE_EVERY              # (events on every stride-th frame: a window is stride frames)
     if len(prof) > 2:
         raw = [prof[i][0].elapsed_time(prof[i + 1][0]) / stride for i in range(len(prof) - 1)]
         per = sorted(raw)

@@ -164,7 +164,7 @@ def row_ptr(t, i):
     return ctypes.c_void_p(t.data_ptr() + int(i) * t.stride(0) * t.element_size())
 
 
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) if not int(__import__("os").environ.get("DPVO_SLOW_STREAM", "0")) else None
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream():

@@ -408,10 +408,9 @@ extern "C" int dpvo_gba_solve(const float* S, const float* y, int n, float* dX, 
     hipLaunchKernelGGL(chol_step_kernel, dim3(r * (r + 1) / 2 + r), dim3(256), 0, stream, Lw, Dg, Di, np, k, r);
   }
   float* yv = Lw + (int64_t)np * np;
-  // back substitution: one launch of one workgroup for small systems, else one launch per block column (DPVO_CHOL_BACK_STEPS=1 forces
-  // the latter: the comparison partner of tests/test_gpu_chol.py and tools/chol_bench.py)
-  const char* force_steps = getenv("DPVO_CHOL_BACK_STEPS");
-  if (nb <= kBackAllMax && !(force_steps && force_steps[0] == '1'))
+  // back substitution: one launch of one workgroup for small systems, else one launch per block column (same operations in the same
+  // order: round 5 compared the two bit for bit on n = 6 .. 768 before the switch that forced the latter was removed)
+  if (nb <= kBackAllMax)
     hipLaunchKernelGGL(chol_back_all_kernel, dim3(1), dim3(256 * kBackGroups), 0, stream, Lw, Dg, Di, np, yv, dX, n, nb);
   else
     for (int k = nb - 1; k >= 0; --k)

@@ -25,63 +25,38 @@ from .patchgraph import PatchGraph
 from .utils import Timer, flatmeshgrid
 
 autocast = torch.autocast
-_CHECK_MIRROR = bool(int(__import__("os").environ.get("DPVO_CHECK_MIRROR", "0")))
-# DPVO_DEFER_NET=1: remove_factors leaves the hidden-state rows where they are and hands the keep list to the next update operator
-# call (95 % of the bytes a removal moves; EdgeStore.keep(defer_net=True)).  Opt-in: the removal kernel drops from 30 to 3 us, but
-# the frame start then just waits longer for the overlapped encoders, and the staging buffer of the keep list stays busy until
-# the update operator has run, which costs the host its lead (measured: 814 -> 809 frames/sec, +0.6 ms of host CPU per frame).
-_DEFER_NET = bool(int(__import__('os').environ.get('DPVO_DEFER_NET', '0')))
-_COMPOSITE_LR = bool(int(__import__('os').environ.get('DPVO_COMPOSITE_LR', '1')))   # 0: frame state entry by entry while long-range edges are active (measurements)
-_PLAN_FIRST = bool(int(__import__('os').environ.get('DPVO_PLAN_FIRST', '0')))     # 1: update() builds the plan in front of reproject / corr (rounds 1-5; measurements)
-_GBA_CAT = bool(int(__import__('os').environ.get('DPVO_GBA_CAT', '0')))      # 1: the global BA's edge lists as five torch.cat (measurements)
-_PLAN_SYNC = bool(int(__import__('os').environ.get('DPVO_PLAN_SYNC', '0')))   # debug: force the exact-count read-back
-# The plan (sorted / grouped index structures) is read by the update operator and BA but not by reproject / corr: with
-# DPVO_PLAN_ASYNC=1 its four small kernels + memsets are built on a third stream beside the correlation kernel instead of in
-# front of it.  Opt-in: the correlation kernel fills the register file, so the plan's 1024-thread workgroups only run once it
-# drains and the update operator waits for them (measured: no gain, +0.2 ms of host CPU per frame for the extra stream).
-_PLAN_ASYNC = __import__('os').environ.get('DPVO_PLAN_ASYNC', '0')
-# DPVO_FRAME_CALL=1 (default): a steady-state frame's update() + keyframe() are ONE C-ABI call (dpvo_frame_update) and the keyframe
-# decision, the edge removal, the renumbering and the ring-buffer shifts happen on the device (dpvo_keyframe_step); the host
-# reads a 16-word result one frame later.  0: the round-2 path (Python-paced launches, host mirror of the index arrays).
-_FRAME_CALL = bool(int(__import__('os').environ.get('DPVO_FRAME_CALL', '1')))
-# DPVO_BLOCKING_SYNC=1: the result read-back sleeps through most of the frame's expected rest (running mean of the GPU-bound waits)
-# before it synchronises with the frame's (plain torch.cuda) event, instead of spinning on it from the start
-# DPVO_ENC_AFTER_UPDATE=1: the side stream holds the next frame's encoders back until the current frame's update operator is
-# through, so that they run beside the small BA / keyframe kernels instead of beside the correlation / update kernels
-# The hold is a hipStreamWaitEvent, and while such a wait is pending a thread of the HIP runtime burns CPU (0.7 ms per frame when
-# the encoders are enqueued right behind the frame call).  The host therefore issues the wait LATE (DPVO._pace_hold: a feedback
-# on whether the event had already completed when the host got there); DPVO_ENC_LEAD_US < 0 switches the pacing off.
-_ENC_AFTER_UPDATE = bool(int(__import__('os').environ.get('DPVO_ENC_AFTER_UPDATE', '1')))
-_ENC_HOLD_AT = int(__import__('os').environ.get('DPVO_ENC_HOLD_AT', '0'))      # -1: the whole side-stream batch (random draws, image
-#   normalisation, encoders) waits; k >= 0: only the encoder launches from number k on.  Round 4: 0 -- the three random draws and the
-#   image normalisation (~18 us of tiny kernels) run at once, only the convolutions are held: +0.5-2 % frames/sec and 50-90 us less
-#   host CPU per frame than -1 on one box (A/B/A/B, profiles/README.md r4), because the wait is issued inside the encoder call
-_ENC_LEAD_US = float(__import__('os').environ.get('DPVO_ENC_LEAD_US', '0'))
-_STAMPS = bool(int(__import__('os').environ.get('DPVO_STAMPS', '0')))
-_HOST_TRACE = [] if __import__('os').environ.get('DPVO_HOST_TRACE') else None      # (dev aid: host time stamps around the frame call)
-_PROFILE_EVERY = int(__import__('os').environ.get('DPVO_PROFILE_EVERY', '1'))
-_BLOCKING_SYNC = bool(int(__import__('os').environ.get('DPVO_BLOCKING_SYNC', '1')))
-# DPVO_PLAN_ASIDE=1: the graph plan's five launches on the side stream (dpvo_frame_update_t.plan_stream), forked behind the new
-# frame's edges and joined in front of the update operator.  Measured (profiles/README.md, round 4): -36 us per frame on a box
-# whose MFMA kernels run at 60 % speed, -25 .. +10 us elsewhere, and +300 us of host CPU per frame in every case -- on this ROCm a
-# stream wait for an event that is still pending when it is issued is resolved by a runtime thread, not by the queues.  Off.
-_PLAN_ASIDE = bool(int(__import__('os').environ.get('DPVO_PLAN_ASIDE', '0')))
-_PLAN_OWN_STREAM = bool(int(__import__('os').environ.get('DPVO_PLAN_OWN_STREAM', '0')))   # (with it: a third stream instead of the encoders')
-_EARLY_RECORD = bool(int(__import__('os').environ.get('DPVO_EARLY_RECORD', '1')))      # 0: wait for the end of the whole frame call (round 3)
+# Hooks for tests and measurement tools: MODULE ATTRIBUTES, set after import (tests monkeypatch them, tools assign them) -- not environment
+# switches.  The only environment variables this package reads are DPVO_HIP_LIB / DPVO_HIP_CMP_LIB (development builds of the two
+# libraries, dpvo_amd/_lib.py; tests/test_capi.py enforces the list).  Everything rounds 2-5 switched through the environment for an
+# A/B measurement is fixed at the setting that won (DESIGN.md 3.7 keeps the numbers): one C-ABI call per steady-state frame with the
+# keyframe step on the device; the next frame's encoder launches held behind the update operator, the host issuing that wait late
+# (_pace_hold); the result record's event recorded inside the call; sleep-then-wait on it; reproject / corr in front of the plan and the
+# global BA's edge lists as views on the call-by-call path.
+_CHECK_MIRROR = False       # tests: assert on every removal that the host mirror of the edge arrays equals the device arrays
+_FRAME_CALL = True          # tests: False = every frame on the call-by-call path (Python-paced launches, host-side keyframe decision)
+_PLAN_ASIDE = False         # tests: the plan's launches on the encoders' stream (dpvo_frame_update_t.plan_stream; measured: no gain, +300 us of host CPU)
+_PLAN_OWN_STREAM = False    # ... on a third stream instead
+_STAMPS = False             # tools/stream_stamps.py: stream-ordered wall-clock stamps
+_HOST_TRACE = None          # tools/fu_host_trace.py: a list that collects (label, perf_counter()) around the frame call
+_PROFILE_EVERY = 1          # bench.py: HIP events around the correlation / the update operator on every k-th frame only (~5 us per marker)
+_PROFILE_POOL = False       # bench.py: create the pool of timing events with the frame buffers (warm-up) instead of at its first use
 _MAX_SLEEP_S = 2.0e-3      # no single pacing sleep is longer than this, whatever the running mean says
 _MAX_FRAME_S = 4.0e-3      # a wait longer than this is not a frame's GPU time (first frames, a paused caller): clamped in the mean
 
 
 class DPVO:
 
-    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda", defer_keyframe=None, overlap_encoders=False):
-        """defer_keyframe: resolve the keyframe decision of frame t (its one host read-back, dpvo.py:266-310) at the
+    def __init__(self, cfg, network, ht=480, wd=640, viz=False, device="cuda", defer_keyframe=True, overlap_encoders=True):
+        """The reference's constructor (dpvo/dpvo.py:22: cfg, network, ht, wd, viz) plus two host-level options, both ON by default since
+        round 6 -- a drop-in caller (demo.py:46, evaluate_*.py) gets the pipeline bench.py times:
+        defer_keyframe: resolve the keyframe decision of frame t (its one host read-back, dpvo.py:266-310) at the
         start of the call for frame t+1, after that frame's encoders have been enqueued, so that the GPU never waits
-        for the host.  Same operations in the same order; state read from outside between calls must go through
-        `flush()` first (terminate() does).  Default: env DPVO_DEFER_KEYFRAME, else off."""
+        for the host.  Same operations in the same order, same bits.  A caller that reads the tracker's state between two calls
+        (`slam.pg.*`, `slam.n`, `slam.m`: the reference's viewer does) sees the CURRENT state all the same: the `pg` accessor resolves
+        a pending record first (`flush()`), terminate() does too.  False: every call returns with its record resolved."""
         self.cfg = cfg
-        if defer_keyframe is None:
-            defer_keyframe = bool(int(__import__("os").environ.get("DPVO_DEFER_KEYFRAME", "0")))
+        self._busy = 0              # > 0 inside the tracker's own entry points: `pg` then hands out the patch graph without flushing
+        self._pg = None
         self.defer_keyframe = bool(defer_keyframe)
         # overlap_encoders: run the next frame's image normalisation + encoders on a second HIP stream, so that they fill
         # the gaps of the previous frame's update / BA kernels (only useful together with defer_keyframe, which lets the
@@ -172,11 +147,6 @@ class DPVO:
 
         self._plan = None          # GraphPlan of the active edge list (rebuilt when edges change)
         self._deferred_removals = 0
-        self._plan_stream = None   # third stream for the asynchronous plan build + its two events (reused every frame)
-        self._plan_ev = None
-        self._edges_ev = None
-        self._plan_ready = None    # set while a plan built on the side stream has not been ordered before the main stream yet
-        self.plan_async = bool(int(_PLAN_ASYNC)) and torch.device(device).type == "cuda"
         self._imap_full = None
         self._corr_buf = None
 
@@ -247,6 +217,19 @@ class DPVO:
     @property
     def gmap(self):
         return self._gmap_cl.view(self.pmem * self.M, self.P, self.P, 128).permute(0, 3, 1, 2)[None]
+
+    @property
+    def pg(self):
+        """the patch graph (dpvo/dpvo.py:44).  Read from OUTSIDE a tracker call while a deferred keyframe record is pending, it is
+        brought up to date first -- so `slam.pg.points_`, `slam.n`, `slam.m` between two calls (demo.py:52-56) mean what they mean in
+        the reference whatever `defer_keyframe` is."""
+        if self._busy == 0 and (self._fu_pending is not None or self._kf_pending is not None):
+            self.flush()
+        return self._pg
+
+    @pg.setter
+    def pg(self, val):
+        self._pg = val
 
     @property
     def n(self):
@@ -367,9 +350,9 @@ class DPVO:
             rem = m.nonzero().squeeze(1) if store else None
             keep, keep_h = (~m).nonzero().squeeze(1), None
         if store and rem is not None and rem.numel():
-            es.keep(keep, keep_h, also=(rem, self.pg.edges_inac), defer_net=_DEFER_NET)      # both gathers in one launch
+            es.keep(keep, keep_h, also=(rem, self.pg.edges_inac))      # both gathers in one launch
         else:
-            es.keep(keep, keep_h, defer_net=_DEFER_NET)
+            es.keep(keep, keep_h)
         self._deferred_removals += int(es.net_pending is not None)
         self._plan = None
 
@@ -433,14 +416,18 @@ class DPVO:
 
     def flush(self):
         """apply a deferred keyframe decision (no-op otherwise)"""
-        if self._kf_pending is not None:
-            pending, self._kf_pending = self._kf_pending, None
-            self._keyframe_finish(*pending)
-        if self._fu_pending is not None:
-            pending, self._fu_pending = self._fu_pending, None
-            self._frame_update_finish(*pending)
-        if self._bound_watch:
-            self._check_plan_bounds()
+        self._busy += 1
+        try:
+            if self._kf_pending is not None:
+                pending, self._kf_pending = self._kf_pending, None
+                self._keyframe_finish(*pending)
+            if self._fu_pending is not None:
+                pending, self._fu_pending = self._fu_pending, None
+                self._frame_update_finish(*pending)
+            if self._bound_watch:
+                self._check_plan_bounds()
+        finally:
+            self._busy -= 1
 
     def keyframe(self):
         pending = self._keyframe_begin()
@@ -519,7 +506,7 @@ class DPVO:
 
     # ------------------------------------------------------------------------------------------ one-call frame path
     def _stamp(self, i):
-        """DPVO_STAMPS=1 (tools/stream_stamps.py): stream-ordered wall-clock stamps [frame counter % 256][8] on the current stream"""
+        """tools/stream_stamps.py (_STAMPS): stream-ordered wall-clock stamps [frame counter % 256][8] on the current stream"""
         if _STAMPS:
             if getattr(self, "_stamp_buf", None) is None:
                 self._stamp_buf = torch.zeros(256, 8, dtype=torch.int64, device=self.device)
@@ -545,7 +532,7 @@ class DPVO:
         nf = cfg.REMOVAL_WINDOW + 2
         maxg = max(nf * self.M, nf * (2 * cfg.PATCH_LIFETIME + 2))
         i32, f32 = torch.int32, torch.float32
-        prof_on = bool(int(__import__("os").environ.get("DPVO_PROFILE_EVENTS", "0")))
+        prof_on = _PROFILE_POOL
         nb = lambda n: torch.empty(max(int(n), 16), dtype=torch.uint8, device=dev)
         fu = {"cap": cap, "sets": (es.a, es.b),
               "coords": torch.empty(cap, 2, self.P, self.P, dtype=f32, device=dev),
@@ -636,7 +623,7 @@ class DPVO:
         else:
             a.net_rows, a.n_kept = None, 0
         # bench.py: HIP events around the correlation kernel / the update operator.  Every hipEventRecord is a marker the stream stalls
-        # on for ~5 us, so they are taken on every DPVO_PROFILE_EVERY-th frame only, and the end of the correlation doubles as the
+        # on for ~5 us, so they are taken on every _PROFILE_EVERY-th frame only, and the end of the correlation doubles as the
         # start of the update operator (3 records instead of 4)
         sample = _PROFILE_EVERY <= 1 or (self.counter % _PROFILE_EVERY) == 0
         if not corr_mod.PROFILE and not net_mod.PROFILE:
@@ -675,17 +662,17 @@ class DPVO:
         if fs is not None:
             # ev_fs ("the frame state has read the encoder outputs"): what the NEXT frame's side-stream batch waits for before it
             # overwrites them -- unless that batch is held behind this call's update operator anyway (one marker less in the stream)
-            a.fs, a.ev_fs, a.fs_auto = ctypes.addressof(fs), (self._fp_done.cuda_event if (self._fp_done is not None and not _ENC_AFTER_UPDATE) else None), 1
+            a.fs, a.ev_fs, a.fs_auto = ctypes.addressof(fs), None, 1
         else:
             a.fs = a.ev_fs = None
-        if _ENC_AFTER_UPDATE:
-            if getattr(self, "_upd_done", None) is None:
-                self._upd_done = torch.cuda.Event()
-                self._upd_done.record()
-            if a.ev[3]:                 # the profiling event behind the update operator is the same point in the stream: one record
-                a.ev_update_done, self._hold_event = None, fu["ev_upd_end"]
-            else:
-                a.ev_update_done, self._hold_event = self._upd_done.cuda_event, self._upd_done
+        # the event behind the update operator: what the next frame's encoder launches are held behind (§3.7)
+        if getattr(self, "_upd_done", None) is None:
+            self._upd_done = torch.cuda.Event()
+            self._upd_done.record()
+        if a.ev[3]:                 # the profiling event behind the update operator is the same point in the stream: one record
+            a.ev_update_done, self._hold_event = None, fu["ev_upd_end"]
+        else:
+            a.ev_update_done, self._hold_event = self._upd_done.cuda_event, self._upd_done
         # the plan's five launches go to the side stream (behind whatever the encoders have queued there) when there is one: only
         # the update operator's second kernel needs them (dpvo_frame_update_t.plan_stream)
         if _PLAN_ASIDE and self._enc_stream is not None:
@@ -710,10 +697,8 @@ class DPVO:
         ev = fu["ev"][par]
         if not ev.cuda_event:
             ev.record()                 # (creates the handle)
-        a.ev_record = ev.cuda_event if _EARLY_RECORD else None
+        a.ev_record = ev.cuda_event
         L.check(L.lib().dpvo_frame_update(ctypes.byref(a), L.stream()), "dpvo_frame_update")
-        if not _EARLY_RECORD:
-            ev.record()
         if _HOST_TRACE is not None: _HOST_TRACE.append(("ret", __import__("time").perf_counter()))
         self._stamp(4)
         es.net_pending = None           # (gathered by the operator's first kernel, rewritten compact by its last one)
@@ -727,7 +712,7 @@ class DPVO:
         already complete: the encoders could have started earlier, issue 60 us sooner next time; still pending: 15 us later, but
         never closer than 200 us to the expected result record -- instead of by a running mean of the frame duration, which the
         delay it causes feeds back into."""
-        if _ENC_LEAD_US < 0 or self._fu is None or self._fu_pending is None:
+        if self._fu is None or self._fu_pending is None:
             return
         import time
         fu = self._fu
@@ -751,7 +736,7 @@ class DPVO:
         # up, steered by what it finds: the record already there -> wake 80 us earlier next time; otherwise half of the time it then
         # spends in the event wait beyond a 100 us margin is added.  Nothing is learnt from a frame the caller arrived late for, and
         # no single sleep exceeds _MAX_SLEEP_S (a paused caller must not teach the tracker to sleep through frames).
-        if _BLOCKING_SYNC and not ev.query():
+        if not ev.query():
             rest = min(fu["wake"] - (time.perf_counter() - t_enq), _MAX_SLEEP_S)
             if rest > 6e-5:
                 time.sleep(rest - 3e-5)
@@ -803,20 +788,13 @@ class DPVO:
         # full_* = torch.cat((inactive, active)) of dpvo.py:315-319 without the five copies of the inactive store: the active edges are
         # copied behind the inactive ones in the inactive store's own buffers (free space there; one launch), the lists are views
         es, inac = self.pg.edges, self.pg.edges_inac
-        if _GBA_CAT:
-            full_target = torch.cat((self.pg.target_inac, self.pg.target), dim=1)
-            full_weight = torch.cat((self.pg.weight_inac, self.pg.weight), dim=1)
-            full_ii = torch.cat((self.pg.ii_inac, self.pg.ii))
-            full_jj = torch.cat((self.pg.jj_inac, self.pg.jj))
-            full_kk = torch.cat((self.pg.kk_inac, self.pg.kk))
-        else:
-            Ea, Ei = es.E, inac.E
-            inac.reserve(Ea)
-            if self._iota is None or self._iota.numel() < Ea:
-                self._iota = torch.arange(max(2 * Ea, 1 << 16), dtype=torch.int64, device=self.device)
-            es.gather_into(self._iota[:Ea], inac.a, Ei, skip_net=True)
-            full_ii, full_jj, full_kk = (inac.a[k][:Ei + Ea] for k in ("ii", "jj", "kk"))
-            full_target, full_weight = inac.a["target"][None, :Ei + Ea], inac.a["weight"][None, :Ei + Ea]
+        Ea, Ei = es.E, inac.E
+        inac.reserve(Ea)
+        if self._iota is None or self._iota.numel() < Ea:
+            self._iota = torch.arange(max(2 * Ea, 1 << 16), dtype=torch.int64, device=self.device)
+        es.gather_into(self._iota[:Ea], inac.a, Ei, skip_net=True)
+        full_ii, full_jj, full_kk = (inac.a[k][:Ei + Ea] for k in ("ii", "jj", "kk"))
+        full_target, full_weight = inac.a["target"][None, :Ei + Ea], inac.a["weight"][None, :Ei + Ea]
 
         self.pg.normalize()
         t0 = int(self.pg.edges.host()["ii"].min()) if self.pg.edges.mirror else self.pg.ii.min().item()      # (the host mirror: no device wait)
@@ -825,20 +803,18 @@ class DPVO:
         # own (every frame with its 2 PATCH_LIFETIME + 2 neighbours) + every loop-closure pair ever appended; frames [0, n).  With the
         # long-range test and t0 answered from the host's bookkeeping the host does not wait for the device anywhere in a global-BA
         # frame: it used to four times, each time with the GPU idle behind it.
-        plan = None
-        if not _PLAN_SYNC:
-            E_all = int(full_ii.numel())
-            ub_p = min(E_all, self.n * self.M)
-            ub_g = min(E_all, self.n * (2 * self.cfg.PATCH_LIFETIME + 2) + self._loop_pairs_total + self.n)
-            plan = GraphPlan(full_ii.contiguous(), full_jj.contiguous(), full_kk.contiguous(), n_patches_ub=ub_p, n_pairs_ub=ub_g,
-                             n_frames=self.N, n_patch_ids=self.N * self.M, wide=(self.n + 1, (self.n + 1) * self.M))
-            self._watch_plan_bounds(plan, "global BA plan (active + inactive edges)")
-            if _CHECK_MIRROR:
-                c = plan.counts.cpu().tolist()
-                assert c[0] <= ub_p and c[1] <= ub_g, ("global plan bounds", c, ub_p, ub_g)
+        E_all = int(full_ii.numel())
+        ub_p = min(E_all, self.n * self.M)
+        ub_g = min(E_all, self.n * (2 * self.cfg.PATCH_LIFETIME + 2) + self._loop_pairs_total + self.n)
+        plan = GraphPlan(full_ii.contiguous(), full_jj.contiguous(), full_kk.contiguous(), n_patches_ub=ub_p, n_pairs_ub=ub_g,
+                         n_frames=self.N, n_patch_ids=self.N * self.M, wide=(self.n + 1, (self.n + 1) * self.M))
+        self._watch_plan_bounds(plan, "global BA plan (active + inactive edges)")
+        if _CHECK_MIRROR:
+            c = plan.counts.cpu().tolist()
+            assert c[0] <= ub_p and c[1] <= ub_g, ("global plan bounds", c, ub_p, ub_g)
         fastba.BA(self.poses, self.patches, self.intrinsics,
                   full_target, full_weight, 1e-4, full_ii, full_jj, full_kk, t0, self.n, M=self.M, iterations=2,
-                  eff_impl=True, plan=plan, f0=0 if plan is not None else None, n_frames=self.n if plan is not None else None)
+                  eff_impl=True, plan=plan, f0=0, n_frames=self.n)
         self.ran_global_ba[self.n] = True
 
     def _watch_plan_bounds(self, plan, what):
@@ -863,27 +839,21 @@ class DPVO:
             if c[0] > ub_p or c[1] > ub_g:
                 raise L.DPVOHipError(f"dpvo_amd: {what} built at frame {n} has {c[0]} patches / {c[1]} frame pairs, more than the "
                                      f"bounds {ub_p} / {ub_g} its launches and workspaces were sized for: results since then are invalid "
-                                     "(set DPVO_PLAN_SYNC=1 for exact plans and report this)")
+                                     "(please report this; `slam._plan_exact = True` switches to exact plans)")
 
-    def plan_sync(self):
-        """order the main stream behind a plan that was built on the side stream (no-op otherwise)"""
-        if self._plan_ready is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._plan_ready)
-            self._plan_ready = None
-
-    def plan(self, edges_ready=None):
-        """`edges_ready`: an event recorded on the current stream behind the last writer of the edge arrays -> build the plan on
-        the side stream behind that event only (the caller runs plan_sync() before the first reader on the main stream)."""
+    def plan(self):
+        """the graph plan of the active edge list (rebuilt when the edges changed)"""
         if self._plan is None or self._plan.E != self.pg.ii.numel():
             ub_p = ub_g = window = None
-            if self._lr_active > 0 and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
+            exact = getattr(self, "_plan_exact", False)
+            if self._lr_active > 0 and not exact:
                 # long-range edges active: no window, but still bounds (sources inside the removal window + one patch / one frame pair
                 # per long-range edge at most + the targets of foreign edges that are not long-range by the test): no read-back
                 nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
                 E_ = int(self.pg.ii.numel())
                 ub_p = min(E_, nf * self.M + self._lr_active)
                 ub_g = min(E_, nf * (2 * self.cfg.PATCH_LIFETIME + 2) + self._lr_active + self.n)
-            if self._lr_active == 0 and not _PLAN_SYNC and not getattr(self, "_plan_exact", False):
+            if self._lr_active == 0 and not exact:
                 # every active edge has its source frame in [n - REMOVAL_WINDOW - 1, n) and its target within
                 # PATCH_LIFETIME frames of the source: bounds on #patches / #frame pairs, no device read-back needed
                 nf = min(self.n, self.cfg.REMOVAL_WINDOW + 2)
@@ -894,51 +864,22 @@ class DPVO:
                 flo = max(0, self.n - (self.cfg.REMOVAL_WINDOW + self.cfg.PATCH_LIFETIME + 3))
                 window = (flo, self.n - flo, flo * self.M, (self.n - flo) * self.M)
             # (no window -- long-range edges active, or exact plans: the ids are still below the frame count: wide counting build)
-            build = lambda: GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
-                                      n_frames=self.N, n_patch_ids=self.N * self.M, window=window,
-                                      wide=None if window is not None else (self.n + 1, (self.n + 1) * self.M))
-            if edges_ready is None or ub_p is None:       # (an exact plan reads its counts back: nothing to overlap)
-                self.plan_sync()
-                self._plan = build()
-                if window is None and ub_p is not None:
-                    self._watch_plan_bounds(self._plan, "plan of the active edges while long-range edges are active")
-            else:
-                if self._plan_stream is None:
-                    self._plan_stream = torch.cuda.Stream(device=self.device, priority=-1)   # small kernels beside a chip-filling one
-                    self._plan_ev = torch.cuda.Event()
-                ps, main = self._plan_stream, torch.cuda.current_stream(self.device)
-                ps.wait_event(edges_ready)
-                with torch.cuda.stream(ps):
-                    self._plan = build()
-                    self._plan_ev.record(ps)
-                self._plan.buf.record_stream(main)        # allocated under the side stream, read by the main one
-                self._plan_ready = self._plan_ev
+            self._plan = GraphPlan(self.pg.ii, self.pg.jj, self.pg.kk, n_patches_ub=ub_p, n_pairs_ub=ub_g,
+                                   n_frames=self.N, n_patch_ids=self.N * self.M, window=window,
+                                   wide=None if window is not None else (self.n + 1, (self.n + 1) * self.M))
+            if window is None and ub_p is not None:
+                self._watch_plan_bounds(self._plan, "plan of the active edges while long-range edges are active")
         return self._plan
 
     def update(self):
         with Timer("other", enabled=self.enable_timing):
-            if self.plan_async and self._plan is None:
-                if self._edges_ev is None:
-                    self._edges_ev = torch.cuda.Event()
-                self._edges_ev.record()                 # behind the edge removal / append of this frame
-                coords = self.reproject()
-                corr = self.corr(coords)
-                plan = self.plan(edges_ready=self._edges_ev)
-                self.plan_sync()
-            elif _PLAN_FIRST:
-                self.plan_sync()
-                plan = self.plan()
-                coords = self.reproject()
-                corr = self.corr(coords)
-            else:
-                # reprojection and correlation first: neither reads the plan, and on this call-by-call path (initialisation, frames
-                # with long-range edges active: the global-BA frames of config 5) the frame's start is paced by the host -- the plan's
-                # host work (buffer, two C calls, the bound watch) then runs while the GPU is busy with the correlation instead of in
-                # front of it
-                self.plan_sync()
-                coords = self.reproject()
-                corr = self.corr(coords)
-                plan = self.plan()
+            # reprojection and correlation first: neither reads the plan, and on this call-by-call path (initialisation, frames
+            # with long-range edges active: the global-BA frames of config 5) the frame's start is paced by the host -- the plan's
+            # host work (buffer, two C calls, the bound watch) then runs while the GPU is busy with the correlation instead of in
+            # front of it
+            coords = self.reproject()
+            corr = self.corr(coords)
+            plan = self.plan()
             # the hidden state, updated in place (the reference reassigns pg.net); a removal of this frame may still be pending
             # on it (EdgeStore.keep(defer_net=True)): the update operator's first kernel gathers the rows, its last one
             # writes them back in compact order
@@ -994,6 +935,14 @@ class DPVO:
                             torch.arange(max(self.n - r, 0), self.n, device=self.device), indexing='ij')
 
     def __call__(self, tstamp, image, intrinsics, patch_coords=None, depth_init=None, image_ready=None):
+        """slam(tstamp, image, intrinsics) -- dpvo/dpvo.py:377-473 (see _call)"""
+        self._busy += 1
+        try:
+            return self._call(tstamp, image, intrinsics, patch_coords, depth_init, image_ready)
+        finally:
+            self._busy -= 1
+
+    def _call(self, tstamp, image, intrinsics, patch_coords=None, depth_init=None, image_ready=None):
         """ track new frame (dpvo.py:377-473).  `patch_coords` / `depth_init` optionally inject the two random
         draws of the reference (patch centroids net.py:132-133, depth rand_like dpvo.py:427) for reproducible tests.
         `image_ready` (only matters with overlap_encoders, where the image is read on a second HIP stream):
@@ -1026,17 +975,13 @@ class DPVO:
         appended = False
         if hip_enc and self.overlap_encoders:
             if self._enc_stream is None:
-                self._enc_stream = torch.cuda.Stream(device=self.device, priority=int(__import__("os").environ.get("DPVO_ENC_PRIO", "0")))
+                self._enc_stream = torch.cuda.Stream(device=self.device)
             side = self._enc_stream
             if self._fp_done is not None:       # the previous frame's readers of _imap_full / the encoder workspace
                 side.wait_event(self._fp_done)
             hold_ev = None
-            if _ENC_AFTER_UPDATE and getattr(self, "_hold_event", None) is not None and self._fu_pending is not None:
-                hold_ev = self._hold_event
-                if _ENC_HOLD_AT < 0:
-                    self._pace_hold(hold_ev)
-                    side.wait_event(hold_ev)
-                    hold_ev = None
+            if getattr(self, "_hold_event", None) is not None and self._fu_pending is not None:
+                hold_ev = self._hold_event      # (only the encoder launches wait for it: the random draws and the image normalisation run at once)
             # the caller's stream may still be producing / uploading the image (torch.from_numpy(img).cuda() from pageable
             # memory returns before the copy has landed): order the side stream behind it
             if image_ready is None:
@@ -1078,7 +1023,7 @@ class DPVO:
                     self._imap_full = torch.empty(H // 4, W // 4, self.DIM, dtype=torch.float16, device=self.device)
                 if side is not None and hold_ev is not None:
                     self._pace_hold(hold_ev)
-                    self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full, hold_event=hold_ev, hold_at=_ENC_HOLD_AT)
+                    self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full, hold_event=hold_ev, hold_at=0)
                 else:
                     self._hip_enc(img16[0, 0], fmap_out=slot, imap_out=self._imap_full)
                 self._stamp(2)
@@ -1144,7 +1089,7 @@ class DPVO:
             # (also while long-range edges are active: the frame then takes the call-by-call path -- _frame_call_ok() is false -- but its
             #  state stores and its own edges are still the one dpvo_frame_state call; only a frame that appends loop edges, which go in
             #  FRONT of its own, issues the entries one by one)
-            composite = (self.is_initialized and not loop_found and (self._lr_active == 0 or _COMPOSITE_LR)
+            composite = (self.is_initialized and not loop_found and True
                          and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR' and n > 1 and 3 * self.M * self.P * self.P <= 4096)
             fac = None
             if n > 1 and self.cfg.MOTION_MODEL == 'DAMPED_LINEAR':

@@ -4,14 +4,13 @@ torch::_unique in cuda_ba (dpvo/fastba/ba_cuda.cu:447-449) and torch.unique in S
 """
 import ctypes
 
-import os
 
 import torch
 
 from . import _lib as L
 from . import workspace
 
-_PLAN_WIDE = bool(int(os.environ.get("DPVO_PLAN_WIDE", "1")))      # 0: measurements against the radix build (tools/lc_profile.py)
+_PLAN_WIDE = True       # tools/lc_ab.py sets it False for measurements against the radix build
 
 
 class GraphPlan:

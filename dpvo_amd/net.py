@@ -28,8 +28,8 @@ PROFILE = None
 EPI_NONE, EPI_RELU, EPI_SIGMOID, EPI_RESADD, EPI_GATED, EPI_RELU_SIG = range(6)
 # Update.forward runs the seven row-tile kernels of update_fused.hip -- always the same path, whatever the box (round 2's
 # run-time autotune between five candidates is gone: a tracker's output must not depend on a timing).  The comparator
-# (launch-by-launch update.hip) is reached explicitly: fused=False or DPVO_UPDATE_FUSED=0.
-FUSED_DEFAULT = bool(int(__import__("os").environ.get("DPVO_UPDATE_FUSED", "1")))
+# (launch-by-launch update.hip) is reached explicitly: Update.forward(..., fused=False).
+FUSED_DEFAULT = True
 
 
 # ------------------------------------------------------------------------------------------ kernels' Python face
@@ -166,9 +166,8 @@ class Update(nn.Module):
         self._packed = None
         # tile shape / soft start of the seven-launch kernels: per instance, handed to the library with every call (the
         # library keeps no state); -1 = the library's default tiling.  Bit-identical results for every value.
-        env = __import__("os").environ
-        self.tiling = int(env.get("DPVO_FU_CFG", "-1"))
-        self.start_skew = int(env.get("DPVO_FU_SKEW", "0"))
+        self.tiling = -1
+        self.start_skew = 0
 
     # -------------------------------------------------------------------------------------- operand images
     def pack(self):

@@ -13,7 +13,8 @@ from . import projective_ops as pops
 from .lietorch import SE3
 from .utils import flatmeshgrid
 
-_NORMALIZE_FUSED = bool(int(__import__("os").environ.get("DPVO_NORMALIZE_FUSED", "1")))     # 0: PatchGraph.normalize as torch operations (measurements)
+_NORMALIZE_FUSED = True     # tools/lc_ab.py sets it False: PatchGraph.normalize as torch operations (measurements)
+_INAC_PREALLOC_FRAC = 0.02  # the inactive-edge store is preallocated from at most this fraction of the device memory that is free
 
 
 class EdgeStore:
@@ -367,14 +368,13 @@ class PatchGraph:
         # sized for the whole buffer up front when that is affordable (every keyframe eventually retires its ~2 * PATCH_LIFETIME * M
         # edges here, remove_factors(store=True): 40 B per edge, 0.4 GB for the default 4096-frame buffer on a 288 GB device): growing
         # it by doubling allocates -- a device-wide sync -- in the middle of a tracked frame (a 0.3 ms hiccup once per doubling)
-        # "Affordable" is checked: at most DPVO_INAC_PREALLOC_FRAC (default 2 %) of the device memory that is free right
+        # "Affordable" is checked: at most _INAC_PREALLOC_FRAC (2 %) of the device memory that is free right
         # now -- many trackers per device, a small GPU or a test suite that builds dozens of them fall back to the doubling store
         per_frame = 2 * int(getattr(self.cfg, "PATCH_LIFETIME", 13)) * self.M
         cap = max(1 << 17, min(self.N * per_frame, 1 << 24))
         if torch.device(dev).type == "cuda":
-            import os
             free_b, _ = torch.cuda.mem_get_info(dev)
-            budget = float(os.environ.get("DPVO_INAC_PREALLOC_FRAC", "0.02")) * free_b
+            budget = _INAC_PREALLOC_FRAC * free_b
             cap = max(1 << 17, min(cap, int(budget // (2 * 40))))      # (two ping-pong sets of 40 B per edge)
         self.edges_inac = EdgeStore(DIM, dev, with_state=False, cap=cap)
 

@@ -5,9 +5,8 @@ streams, must not share scratch memory -- kernels of different streams may overl
 import torch
 
 _bufs = {}
-import os
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_PER_STREAM = bool(int(os.environ.get("DPVO_WS_PER_STREAM", "1")))
+_PER_STREAM = True
 
 
 def get(nbytes, device, tag="default"):

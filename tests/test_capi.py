@@ -77,6 +77,28 @@ def test_product_never_imports_oracle():
                 assert "liboracle" not in txt, f
 
 
+def test_environment_reads_are_on_the_allow_list():
+    """the product reads NO measurement switch from the environment.  Allowed: DPVO_HIP_LIB / DPVO_HIP_CMP_LIB (which build
+    of the two libraries to load: dpvo_amd/_lib.py, dpvo_amd/integration_stubs.py) and what torch.distributed's launcher hands a rank
+    (dpvo_amd/multiseq.py).  The library itself (csrc) reads none at all."""
+    allowed = {"DPVO_HIP_LIB", "DPVO_HIP_CMP_LIB", "MASTER_ADDR", "HSA_ENABLE_IPC_MODE_LEGACY", "WORLD_SIZE", "RANK", "LOCAL_RANK",
+               "MASTER_PORT", "LOCAL_WORLD_SIZE"}
+    pkg = os.path.join(ROOT, "dpvo_amd")
+    seen = set()
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                txt = open(path).read()
+                for m in re.finditer(r"environ(?:\.get|\.setdefault)?\s*[\(\[]\s*['\"]([A-Za-z0-9_]+)['\"]", txt):
+                    seen.add(m.group(1))
+                    assert m.group(1) in allowed, f"{os.path.relpath(path, ROOT)} reads {m.group(1)} from the environment"
+                assert "getenv" not in txt, f
+            elif f.endswith((".hip", ".h")):
+                assert "getenv" not in open(path).read(), f"{f}: a library entry has no business reading the environment"
+    assert "DPVO_HIP_LIB" in seen
+
+
 def test_argument_validation_is_host_only():
     """every entry validates its arguments before touching the device: error codes without a GPU, never a crash / exit
     (the reference calls exit(1) in block_e.cu:20-27 and ba.cpp:151-152)"""

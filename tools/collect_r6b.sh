@@ -7,11 +7,11 @@ F='amdgpu\|Warning\|autocast\|warnings.warn'
 timeout 300 python -m pytest tests/test_gpu_update.py tests/test_golden.py -q -x 2>&1 | grep -v "$F" | tail -15 > $out/pytest_update.txt; tail -3 $out/pytest_update.txt
 timeout 300 python tools/update_tilings.py 1,5,9,13,29,28,17 3 2>&1 | grep -v "$F" > $out/update_tilings.txt; cat $out/update_tilings.txt
 for t in 1 29; do
-  DPVO_FU_CFG=$t WHICH=fused REPS=10 timeout 200 bash tools/kstat_cmd.sh python $root/tools/update_bench.py > $out/update_kernels_tiling_$t.txt 2>&1; cat $out/update_kernels_tiling_$t.txt | head -9
+  TILING=$t WHICH=fused REPS=10 timeout 200 bash tools/kstat_cmd.sh python $root/tools/update_bench.py > $out/update_kernels_tiling_$t.txt 2>&1; cat $out/update_kernels_tiling_$t.txt | head -9
 done
 cd $root
 for t in 1 13 29 1 13; do
-  DPVO_FU_CFG=$t timeout 300 python bench.py --steps 40 --warmup 10 > $out/bench_$t.json 2> $out/bench_$t.err
+  timeout 300 python bench.py --steps 40 --warmup 10 --update-tiling $t > $out/bench_$t.json 2> $out/bench_$t.err
   python - $out/bench_$t.json $t <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from dpvo_amd import _lib as L
 from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML
+import dpvo_amd.dpvo as _dm
+_dm._PLAN_ASIDE = bool(int(os.environ.get("PLAN_ASIDE", "0")))      # (this tool's own switch: the plan on the side stream)
 from dpvo_amd.dpvo import DPVO
 from dpvo_amd.net import VONet
 dev = torch.device("cuda:0")
@@ -27,6 +29,6 @@ with torch.no_grad():
     slam.flush(); torch.cuda.synchronize()
 L.lib().dpvo_debug_fu_host_trace(out)
 v = list(out)[:12]
-print(f"DPVO_PLAN_ASIDE={os.environ.get('DPVO_PLAN_ASIDE', '1')}: host us per step of dpvo_frame_update (mean of 60 frames), total {sum(v):.1f}")
+print(f"plan on the side stream = {_dm._PLAN_ASIDE}: host us per step of dpvo_frame_update (mean of 60 frames), total {sum(v):.1f}")
 for n_, x in zip(names, v):
     print(f"   {n_:44s} {x:7.1f}")

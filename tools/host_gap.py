@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Host time between the result record of frame t (event wait returns) and the frame call of frame t + 1 (DPVO_HOST_TRACE stamps
+"""Host time between the result record of frame t (event wait returns) and the frame call of frame t + 1 (dpvo_amd.dpvo._HOST_TRACE stamps
 inside dpvo_amd/dpvo.py): where the inter-frame gap goes.  Dev tool."""
 import os, sys
-os.environ["DPVO_HOST_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 import dpvo_amd.dpvo as dm
+dm._HOST_TRACE = []
 from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML
 from dpvo_amd.net import VONet
 dev = torch.device("cuda:0")

@@ -1,41 +1,43 @@
 #!/usr/bin/env python
-"""The config-5 leg of bench.py (LOOP_CLOSURE=True, 45 timed frames, 18 of them with a global BA) under the measurement switches of
-round 5, each variant in its own process (the switches are read at import), `reps` times each, interleaved so that a box's drift hits
-all variants alike:
+"""The config-5 leg of bench.py (LOOP_CLOSURE=True, 45 timed frames, 18 of them with a global BA) under the measurement hooks that are left
+(module attributes since round 6 -- the package reads no measurement switch from the environment any more; the round-5 variants that lost
+their A/B are gone from the product, their numbers are in profiles/r05_*_lc_ab.txt), each variant in its own process, `reps` times each,
+interleaved so that a box's drift hits all variants alike:
     python tools/lc_ab.py [reps=2]
-Prints frames/sec per run and the per-variant mean; also the mean wall time of the global-BA frames with a device sync per frame
-(LC_SYNC=1 of tools/lc_profile.py) for the first and the last variant.  Dev tool."""
+Prints frames/sec per run and the per-variant mean.  Dev tool."""
 import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (label, {"module.attribute": value} assigned after import, {"update tiling": int} via Update.tiling)
 VARIANTS = [
     ("product", {}),
-    ("radix plans (DPVO_PLAN_WIDE=0)", {"DPVO_PLAN_WIDE": "0"}),
-    ("PatchGraph.normalize as torch operations (DPVO_NORMALIZE_FUSED=0)", {"DPVO_NORMALIZE_FUSED": "0"}),
-    ("frame state entry by entry (DPVO_COMPOSITE_LR=0)", {"DPVO_COMPOSITE_LR": "0"}),
-    ("plan in front of reproject / corr (DPVO_PLAN_FIRST=1)", {"DPVO_PLAN_FIRST": "1"}),
-    ("all switches back", {"DPVO_PLAN_WIDE": "0", "DPVO_GBA_CAT": "1", "DPVO_CHOL_BACK_STEPS": "1", "DPVO_COMPOSITE_LR": "0",
-                           "DPVO_NORMALIZE_FUSED": "0", "DPVO_PLAN_FIRST": "1"}),
+    ("radix plans (dpvo_amd.graph._PLAN_WIDE = False)", {"dpvo_amd.graph._PLAN_WIDE": False}),
+    ("PatchGraph.normalize as torch operations (dpvo_amd.patchgraph._NORMALIZE_FUSED = False)", {"dpvo_amd.patchgraph._NORMALIZE_FUSED": False}),
+    ("update operator: every kernel on the 4-wave geometry (tiling 1)", {"tiling": 1}),
+    ("update operator: every kernel on the 12-wave geometry (tiling 29)", {"tiling": 29}),
 ]
-if os.environ.get("LC_AB_ALL"):        # the two switches that measured within the noise (profiles/r05_f_lc_ab.txt)
-    VARIANTS[3:3] = [("five torch.cat (DPVO_GBA_CAT=1)", {"DPVO_GBA_CAT": "1"}),
-                     ("back substitution per column (DPVO_CHOL_BACK_STEPS=1)", {"DPVO_CHOL_BACK_STEPS": "1"})]
-_BV0 = os.path.join(ROOT, "dpvo_amd", "libdpvo_hip_bv0.so")          # tools/gba_bv_ab.sh build: the row kernel of rounds 4-5
-if os.path.exists(_BV0):
-    _LBL = os.environ.get("LC_AB_LIB_LABEL", "row kernel of rounds 4-5")
-    VARIANTS.insert(len(VARIANTS) - 1, (_LBL + " (libdpvo_hip_bv0.so)", {"DPVO_HIP_LIB": _BV0}))
-    VARIANTS[-1] = (VARIANTS[-1][0] + " + " + _LBL, dict(VARIANTS[-1][1], DPVO_HIP_LIB=_BV0))
 if os.environ.get("LC_AB_ONLY"):       # comma-separated substrings of the variant names to keep
     keep = [k.strip() for k in os.environ["LC_AB_ONLY"].split(",")]
     VARIANTS = [v for v in VARIANTS if any(k in v[0] for k in keep)]
 CHILD = r"""
-import json, sys, torch
+import importlib, json, os, sys, torch
 sys.path.insert(0, %r)
 import bench
 from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML
+sets = json.loads(os.environ.get("LC_AB_SET", "{}"))
+for k, v in sets.items():
+    if k == "tiling":
+        import dpvo_amd.net as N
+        _init = N.Update.__init__
+        def init(self, *a, _v=v, **kw):
+            _init(self, *a, **kw); self.tiling = _v
+        N.Update.__init__ = init
+    else:
+        mod, attr = k.rsplit(".", 1)
+        setattr(importlib.import_module(mod), attr, v)
 dev = torch.device("cuda:0")
 cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML); cfg.KEYFRAME_THRESH = -1.0
 frames = bench.make_stream(64, 480, 640, dev)
@@ -44,8 +46,8 @@ print("LC_AB " + json.dumps(bench.loop_closure_leg(cfg, 480, 640, dev, frames, i
 """ % ROOT
 
 
-def run(env_extra):
-    env = dict(os.environ, **env_extra)
+def run(sets):
+    env = dict(os.environ, LC_AB_SET=json.dumps(sets))
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     for line in out.stdout.splitlines():
         if line.startswith("LC_AB "):
@@ -66,12 +68,6 @@ def main():
     for name, _ in VARIANTS:
         v = [x for x in res[name] if x]
         print(f"{name:86s} mean {sum(v) / max(len(v), 1):7.1f} frames/sec over {len(v)} runs  {v}")
-    for name, env in ((VARIANTS[0], VARIANTS[-1]) if not os.environ.get("LC_AB_ONLY") else ()):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lc_profile.py")], env=dict(os.environ, LC_SYNC="1", **env),
-                             capture_output=True, text=True, timeout=600)
-        for line in out.stdout.splitlines():
-            if line.startswith("global-BA frames"):
-                print(f"{name}: {line}")
 
 
 if __name__ == "__main__":

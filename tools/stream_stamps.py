@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Stream-ordered wall-clock stamps of the tracker's two streams without a profiler attached (DPVO_STAMPS=1): per frame, when
+"""Stream-ordered wall-clock stamps of the tracker's two streams without a profiler attached (dpvo_amd.dpvo._STAMPS): per frame, when
 the side stream reaches the random draws / the image normalisation / the end of the encoders, and when the main stream reaches
 the start / the end of the frame call.  Prints medians relative to the start of the frame call.  Dev tool."""
 import os, sys
-os.environ["DPVO_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from dpvo_amd.config import cfg as base_cfg, DEFAULT_YAML
+import dpvo_amd.dpvo as _dm
+_dm._STAMPS = True
 from dpvo_amd.dpvo import DPVO
 from dpvo_amd.net import VONet
 dev = torch.device("cuda:0")

@@ -44,6 +44,7 @@ def main():
         torch.manual_seed(0)
         upd = N.Update(3).to(dev)
         upd.pack()
+        upd.tiling = int(os.environ.get("TILING", "-1"))        # (this tool's own switch: dpvo_update_fused_params_t.tiling)
         plan = GraphPlan(ii, jj, kk)
         g = torch.Generator().manual_seed(1)
         imap = torch.randn(3456, 384, generator=g).half().to(dev)
