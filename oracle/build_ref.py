@@ -105,11 +105,17 @@ PY_FILES = ["__init__.py", "dpvo.py", "net.py", "patchgraph.py", "projective_ops
             "altcorr/__init__.py", "altcorr/correlation.py", "fastba/__init__.py", "fastba/ba.py", "loop_closure/optim_utils.py"]
 
 
+SCRIPTS = ["demo.py", "evaluate_euroc.py"]      # the reference's entry scripts: run UNMODIFIED on dpvo_amd by tests/test_gpu_dropin.py
+
+
 def stage_python():
-    """the reference's Python package, unmodified, as oracle/_ref/pyref/dpvo_reference/ (see module docstring)"""
+    """the reference's Python package, unmodified, as oracle/_ref/pyref/dpvo_reference/, and its entry scripts as
+    oracle/_ref/pyref/scripts/ (see module docstring)"""
     dst = os.path.join(OUT, "pyref", "dpvo_reference")
     for rel in PY_FILES:
         _write(os.path.join(dst, rel), _read("dpvo/" + rel))
+    for rel in SCRIPTS:
+        _write(os.path.join(OUT, "pyref", "scripts", rel), _read(rel))
     return dst
 
 
