@@ -75,7 +75,8 @@ __device__ unsigned long long kf_trace_buf[2][16];
 #define KFT(i) do {} while (0)
 #endif
 constexpr int KF_CHUNK = 1024;
-constexpr int KF_SPIN_LIMIT = 1 << 18;   // x s_sleep(8) = 512 cycles: ~0.2 s at 100 MHz granularity before a look-back gives up
+constexpr unsigned long long KF_WAIT_TICKS = 100000000ull;   // a look-back gives up after ONE SECOND of the 100 MHz wall clock (an
+                                                           // iteration count was 55-65 ms, which a time-sliced or profiled device can exceed)
 constexpr int KF_HDR = 4;         // scratch behind the 8 result words: [0] generation, [1] workgroups done, then per chunk {kept, removed, long-range, flag}
 // ONE launch (rounds 2-3: a count kernel and a select kernel, 21 + 20 us): every 1024-edge chunk classifies its edges, publishes its
 // three counts with a flag (= the call's generation number, so nothing has to be cleared between calls) and reads the counts of the
@@ -140,9 +141,11 @@ __global__ __launch_bounds__(KF_CHUNK) void kf_decide_kernel(const dpvo_keyframe
       const int32_t* o = sc + KF_HDR + 4 * b;
       // (bounded: a scratch that was cleared or reused between calls, or a launch that died half way, leaves flags this call never
       //  sees -- ~0.2 s of polling, then the chunk gives up and the record says so (RES_OVERFLOW bit 1) instead of hanging the queue)
-      int spins = 0;
+      unsigned long long t_wait = 0;
       while (__hip_atomic_load(&o[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-        if (++spins > KF_SPIN_LIMIT) { pre[3] = 1; break; }
+        const unsigned long long now = wall_clock64();
+        if (t_wait == 0) t_wait = now;
+        if (now - t_wait > KF_WAIT_TICKS) { pre[3] = 1; break; }
         __builtin_amdgcn_s_sleep(8);
       }
       ak += __hip_atomic_load(&o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

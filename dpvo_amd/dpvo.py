@@ -825,8 +825,11 @@ class DPVO:
         did not hold (this was only asserted under DPVO_CHECK_MIRROR)."""
         if plan is None or plan.exact:
             return
-        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        host.copy_(plan.counts[:2], non_blocking=True)
+        # counts = {patches, frame pairs, 0, id-range flag}: [2] of the copy = the flag of the window / wide builds (an id outside the range
+        # the caller promised was clamped: the plan's groups are then wrong for this call)
+        host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        host[:2].copy_(plan.counts[:2], non_blocking=True)
+        host[2:3].copy_(plan.counts[3:4], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._bound_watch.append((host, ev, plan.n_patches_host, plan.n_pairs_host, what, self.n))
@@ -836,9 +839,12 @@ class DPVO:
             host, ev, ub_p, ub_g, what, n = self._bound_watch.pop(0)
             ev.synchronize()
             c = host.tolist()
-            if c[0] > ub_p or c[1] > ub_g:
+            if c[0] > ub_p or c[1] > ub_g or (len(c) > 2 and c[2] != 0):
+                # every later plan is built exactly (one read-back each) and the cached one is dropped BEFORE raising: a caller that
+                # catches this continues with exact plans, and the flag stays up
+                self._plan_exact, self._plan, self.plan_bound_violated = True, None, True
                 raise L.DPVOHipError(f"dpvo_amd: {what} built at frame {n} has {c[0]} patches / {c[1]} frame pairs, more than the "
-                                     f"bounds {ub_p} / {ub_g} its launches and workspaces were sized for: results since then are invalid "
+                                     f"bounds {ub_p} / {ub_g} its launches and workspaces were sized for (id-range flag {c[2] if len(c) > 2 else 0}): results since then are invalid "
                                      "(please report this; `slam._plan_exact = True` switches to exact plans)")
 
     def plan(self):

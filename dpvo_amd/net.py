@@ -236,7 +236,7 @@ class Update(nn.Module):
     # -------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, net, inp, corr, flow, ii, jj, kk, plan=None, inp_rows=None, inp_mod=0, corr_is_padded=False,
-                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None, patch_edges_ub=None,
+                out=None, coords=None, target_out=None, weight_out=None, composite=True, fused=None,
                 net_rows=None):
         """update operator (net.py:74-92).  net [1,E,384] f32/f16, inp [1,E,384] f16 (or, with `inp_rows`, the
         un-gathered imap [1,S,384] plus int64 row ids taken modulo inp_mod), corr [1,E,882] f16.
@@ -293,15 +293,15 @@ class Update(nn.Module):
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
             res = self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
-                                    composite, fused, patch_edges_ub, E, dev, P, net_rows)
+                                    composite, fused, E, dev, P, net_rows)
             ev1.record()
             prof.append((ev0, ev1, E))
             return res
         return self.forward_impl(net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out,
-                                 composite, fused, patch_edges_ub, E, dev, P, net_rows)
+                                 composite, fused, E, dev, P, net_rows)
 
     def forward_impl(self, net2, inp2, corr2, ii, jj, kk, plan, inp_rows, inp_mod, out, coords, target_out, weight_out, composite,
-                     fused, patch_edges_ub, E, dev, P, net_rows=None):
+                     fused, E, dev, P, net_rows=None):
         if composite and net2.dtype == torch.float32:
             # the whole operator as ONE library call (dpvo_update_forward issues the same launches as the code below;
             # `composite=False` keeps the launch-by-launch path for tests)

@@ -56,7 +56,9 @@ class EdgeStore:
 
     def _alloc(self, cap):
         self.cap = cap
-        self.a, self.b = self._new(cap), self._new(cap)
+        # two sets for the store that compacts (ping-pong of keep()); the inactive store only ever appends: its second set would double
+        # every reallocation for nothing and is created by the first keep(), should one ever come
+        self.a, self.b = self._new(cap), (self._new(cap) if self.with_state else None)
 
     def reserve(self, n):
         if self.E + n <= self.cap:
@@ -268,6 +270,8 @@ class EdgeStore:
         array, which keeps the host mirror alive (applied lazily).  also = (idx2, dst_store): additionally append the edges
         idx2 to another store (the inactive edges of remove_factors) -- both gathers in one launch."""
         defer_net = defer_net and self.with_state
+        if self.b is None:
+            self.b = self._new(self.cap)
         if self.net_pending is not None:
             self.materialize_net()              # (a second removal before the update operator ran: apply the first one now)
         if also is None:

@@ -218,10 +218,10 @@ int dpvo_neighbors(const int64_t* kk, const int64_t* jj, int64_t* ix, int64_t* j
  * update operator  (replaces Update.forward, dpvo/net.py:74-92, under autocast: dpvo.py:332)
  * ---------------------------------------------------------------------------------------------- */
 
-/* The update operator of the product library is dpvo_update_forward_fused(_rows) (further down).  Its two comparators -- the
+/* The update operator of the product library is dpvo_update_forward_fused(_rows) (further down).  Its comparator -- the
  * launch-by-launch composite of generic pieces (dpvo_linear / dpvo_layernorm / dpvo_gather_add / dpvo_heads /
- * dpvo_update_forward) and the patch-major four-launch variant (dpvo_update_forward_pm) -- live in libdpvo_hip_cmp.so and are
- * declared in dpvo_hip_cmp.h: test and measurement partners, not part of the product. */
+ * dpvo_update_forward) -- lives in libdpvo_hip_cmp.so and is declared in dpvo_hip_cmp.h: a test and measurement partner, not part
+ * of the product. */
 
 /* epilogue selectors of dpvo_linear */
 #define DPVO_EPI_NONE 0        /* out_f16 = h(acc + bias)                                     */

@@ -365,6 +365,28 @@ def test_loop_closure_configuration(dev, RP, stream):
     assert int((theirs.pg.jj - theirs.pg.ii > 30).sum()) > 0 or int(theirs.pg.ii_inac.numel()) > 0
 
 
+def test_loop_closure_mid_scale(dev, RP, stream):
+    """config 5 at the mid scale (the bounded LOOP_CLOSURE run compares the global BA -- block-sparse linearisation, device
+    Cholesky, wide plans -- with EfficentE only on steps of ~1e-5, and the full-scale run ends before the first global BA fires): flow
+    head x 0.3, teacher forced, singular frames skipped -- the global BAs of the frames on which the tracker MOVES (steps 0.05-1.4).
+    Required: integer state incl. loop edges bit-exact on 85 frames, the same global-BA triggers, and at least three REGULAR frames
+    whose last BA was a global one with a reference step >= 1e-3, all within the absolute and step-relative bounds."""
+    frames, intr = stream
+    ours, theirs, _ = H.build_pair(dev, HT, WD, M, buffer=512, LOOP_CLOSURE=True, KEYFRAME_THRESH=-1.0, **MID)
+    recs = H.run_lockstep(ours, theirs, frames, 85, intr, feed=True, teacher=True, attribute_ba=True)
+    _int_exact(recs, 85)
+    first = _float_state("loop closure (mid scale)", recs, min_regular=60, skip_singular=True)
+    reg = lambda r: max(r.get("yard", 0.0), r.get("ref_exact", 0.0)) <= POSE_TOL * max(1.0, r.get("extent", 0.0))
+    gba = [r for r in recs if r.get("eff_impl") and reg(r)]
+    big = [r for r in gba if r["step_ref"] >= 1e-3]
+    gb_o, gb_r = int(ours.ran_global_ba.sum()), int(theirs.ran_global_ba.sum())
+    print(f"loop closure (mid scale): {gb_r} global BA runs on each side, {len(gba)} of them the last BA of a regular frame, {len(big)} with a "
+          f"reference step >= 1e-3" + (f" (steps {min(r['step_ref'] for r in big):.3g} .. {max(r['step_ref'] for r in big):.3g}, |our BA - "
+          f"EfficentE| / step <= {max(r['ba_dist'] / r['step_ref'] for r in big):.2e}, E up to {max(r['E_ba'] for r in big)})" if big else "")
+          + f", first singular frame {first}")
+    assert gb_o == gb_r >= 2 and len(big) >= 3
+
+
 def test_loop_closure_stress(dev, RP, stream):
     """config 5 with the flow head at full scale (the run-away scenario): the INTEGER state -- which loop edges edges_loop selects,
     which edges the lc rule keeps alive, when the global BA triggers -- bit-exact over 85 frames whatever the floats do; float
