@@ -107,6 +107,68 @@ def make_stream(n_frames, ht, wd, device, seed=1234):
     return torch.stack(frames).to(device)
 
 
+def make_plane_stream(n_frames, ht, wd, device, seed=1234, depth_m=4.0, step_m=0.02, yaw_deg=0.2, intr=(320.0, 320.0, 320.0, 240.0)):
+    """SURVEY.md 8(d), the stream-level input of the metric: `n_frames` uint8 frames rendered from ONE fixed low-pass-filtered random
+    texture (seed 1234) on a fronto-parallel plane `depth_m` in front of a camera that translates `step_m` per frame along x while its
+    yaw swings by +-`yaw_deg` per frame (a triangle wave of period 40 frames: |yaw| <= 2 degrees), intrinsics calib/tartan.txt.  Rendered
+    on the CPU (device independent: the same frames on every box), then staged in HBM.  The image motion is 320 * 0.02 / 4 = 1.6 px per
+    frame from the translation alone."""
+    import math
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    T = 2048
+    # two octaves of low-pass noise, 1 texel = 1 cm on the plane (the 480 x 640 view covers 6 m x 8 m of it)
+    lo = torch.nn.functional.interpolate(torch.rand(1, 3, T // 16, T // 16, generator=g), size=(T, T), mode="bicubic", align_corners=False)
+    hi = torch.nn.functional.interpolate(torch.rand(1, 3, T // 4, T // 4, generator=g), size=(T, T), mode="bicubic", align_corners=False)
+    tex = 0.6 * lo + 0.4 * hi
+    tex = (tex - tex.amin()) / (tex.amax() - tex.amin())
+    fx, fy, cx, cy = intr
+    v, u = torch.meshgrid(torch.arange(ht, dtype=torch.float64), torch.arange(wd, dtype=torch.float64), indexing="ij")
+    rays = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], -1)             # camera frame
+    frames = []
+    for t in range(n_frames):
+        ph = t % 40
+        yaw = math.radians(yaw_deg) * (ph if ph < 10 else 20 - ph if ph < 30 else ph - 40)
+        c, s_ = math.cos(yaw), math.sin(yaw)
+        R = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]], dtype=torch.float64)      # camera -> world
+        d = rays @ R.T
+        lam = depth_m / d[..., 2]
+        X = d[..., 0] * lam + (step_m * t - 0.5 * step_m * n_frames)                            # world x of the hit point (metres)
+        Y = d[..., 1] * lam
+        grid = torch.stack([X * 100.0 / (T / 2), Y * 100.0 / (T / 2)], -1).float()[None]      # texels -> [-1, 1]
+        img = torch.nn.functional.grid_sample(tex, grid, mode="bilinear", padding_mode="reflection", align_corners=False)[0]
+        frames.append((255.0 * img).clamp_(0, 255).to(torch.uint8))
+    return torch.stack(frames).to(device)
+
+
+def unforced_probe_leg(cfg, net, ht, wd, device, frames, intr, max_frames=48):
+    """The same tracker on the same stream WITHOUT the pinned initialisation probe (dpvo.py:441-444: frames are only accepted while the
+    median flow of the probe is >= 2 px): does a random-weight tracker initialise by itself on the 8(d) stream?  Reports the probe
+    values it saw (the flow head of random weights emits noise whatever the image motion is, so this says something about the
+    weights, not about the stream) and whether n reached 8."""
+    from dpvo_amd.dpvo import DPVO
+    try:
+        slam = DPVO(cfg, net, ht=ht, wd=wd, device=device)
+        probes = []
+        real = slam.motion_probe
+
+        def probe():
+            v = float(real())
+            probes.append(round(v, 3))
+            return v
+        slam.motion_probe = probe
+        with torch.no_grad():
+            for t in range(min(max_frames, frames.shape[0])):
+                slam(float(t), frames[t], intr, image_ready=False)
+                if slam.is_initialized:
+                    break
+            slam.flush()
+        torch.cuda.synchronize(device)
+        return {"initialised_by_itself": bool(slam.is_initialized), "frames_offered": t + 1, "keyframes": int(slam.n),
+                "probe_px_first": probes[:6], "probe_px_min_max": [min(probes), max(probes)] if probes else None, "threshold_px": 2.0}
+    except Exception as e:          # noqa: BLE001  (a side leg must never take the headline measurement down)
+        return {"initialised_by_itself": None, "error": repr(e)[:300]}
+
+
 def box_clock():
     """Shader clock this box sustains under a full-chip MFMA load (tools/probes/clock_probe.hip, built by
     __graft_entry__.build(); ~1 s after the timed region): the same build measures +-3 % frames/sec from box to box, and this is
@@ -309,8 +371,9 @@ def main():
     slam.motion_probe = lambda: 1.0e9                # accept the initialisation probe (random weights)
     if args.drop_every > 0:
         slam.keyframe_override = lambda counter: counter % args.drop_every == 0
-    n_img = 64
-    frames = make_stream(n_img, ht, wd, device, seed=1234 + seed_off)
+    # the perspective plane render; as many frames as the headline leg tracks (no wrap-around inside it), at least 128
+    n_img = min(300, max(128, total))
+    frames = make_plane_stream(n_img, ht, wd, device, seed=1234 + seed_off)
     torch.cuda.synchronize(device)                   # the stream is resident before the first frame is tracked
     intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=device)   # calib/tartan.txt
 
@@ -393,6 +456,12 @@ def main():
     lc_leg = None
     if world == 1 and args.drop_every == 0 and args.config == "default" and not os.environ.get("DPVO_BENCH_NO_LC_LEG"):
         lc_leg = loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed=1234 + seed_off)
+    # fourth leg (N = 1, default run only; SURVEY 8(d) / VERDICT r5 #8): the initialisation probe NOT pinned -- does this stream + these
+    # (random) weights initialise a tracker by themselves?
+    probe_leg = None
+    if world == 1 and args.drop_every == 0 and args.config == "default" and not os.environ.get("DPVO_BENCH_NO_PROBE_LEG"):
+        torch.manual_seed(1234 + seed_off)
+        probe_leg = unforced_probe_leg(cfg, VONet(), ht, wd, device, frames, intr)
     res = multiseq.gather_results(args.steps, local, extra=[1e6 * (cpu1 - cpu0) / args.steps, dev_index,
                                                            pinned[0] if pinned else -1, pinned[-1] if pinned else -1], dist=dist,
                                   device=device if backend == "nccl" else "cpu")
@@ -450,12 +519,15 @@ def main():
             "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 features / f32 accumulate, f32 BA", "data": "synthetic",
-            "config": {"workload": f"synthetic 480x640 stream, {cfg.PATCHES_PER_FRAME} patches/frame, {args.config}.yaml, "
-                                   f"steady state E={E_now} edges, random-init weights, one sequence per GPU",
+            "config": {"workload": f"synthetic 480x640 stream (SURVEY 8d: textured plane at 4 m, 2 cm per frame, +-0.2 deg per frame yaw, calib/tartan.txt, "
+                                   f"CPU-rendered with seed 1234, resident in HBM), {cfg.PATCHES_PER_FRAME} patches/frame, {args.config}.yaml, "
+                                   f"steady state E={E_now} edges, random-init weights (initialisation probe pinned, no keyframe dropped: "
+                                   f"`unforced_probe` says what happens without the pin), one sequence per GPU",
                        "patches_per_frame": cfg.PATCHES_PER_FRAME, "edges": E_now, "drop_every": args.drop_every, "parallelism": f"replicas x{world}" + ("" if backend == "nccl" or world == 1 else
                                                                 f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
             "frame_period_ms": period,
             "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg, "with_loop_closure": lc_leg,
+            "unforced_probe": probe_leg,
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "frames_per_sec": round(r[0] / r[1], 1),
                           "host_cpu_us_per_frame": round(r[2], 1), "device": int(r[3]),
                           "pinned_to": (f"{int(r[4])}-{int(r[5])}" if r[4] >= 0 else None)}
