@@ -73,15 +73,25 @@ __device__ __forceinline__ void bbox_reduce(int& mnx, int& mxx, int& mny, int& m
       : "+v"(mnx), "+v"(mxx), "+v"(mny), "+v"(mxy));
 }
 
+// Which position and which bytes a lane fetches for the MFMA B fragment of a tile.  MODE 0 is the product: lane (n = lane & 15, kg = lane >> 4)
+// fetches the 16-byte channel chunk 4 s + kg of position 16 tile + n -- what v_mfma_f32_16x16x32_f16 wants in that lane.  The measurement
+// kernel (tools/probes/corr_variant.hip) specialises other modes -- other lane -> address maps, wrong results on purpose -- to time what the
+// vector L1 makes of them; the product library instantiates MODE 0 only.
+template <int MODE> struct CorrLoad {
+  static constexpr bool ALIGN4 = false;          // bounding-box columns aligned to groups of four
+  static constexpr int STEP = 64;                // bytes between a lane's four loads of a tile
+  static __device__ __forceinline__ int pos(int tile, int n, int lane) { return tile * 16 + n; }
+  static __device__ __forceinline__ unsigned addr(int y, int x, int W, int kg, int lane) {
+    return (unsigned)(__mul24(y, W) + x) * (CORR_C * 2) + kg * 16;       // (24-bit multiply: the caller's `any_in` keeps |y| < 2^11, W < 2^15)
+  }
+};
+
 // raw[pos][m] for pos < np = bw*bh (and the padding positions of the last tile), m < 12: dot(template m, feature(y0+pos/bw, x0+pos%bw)),
 // 0 if out of the image.  Features are fetched with bounds-checked buffer loads: a lane whose position is outside the image or is tile
 // padding gets the offset 0x8000'0000 (beyond num_records, and far from the 2^32 wrap of offset + instruction offset + 16) and reads
 // zeros without a branch.  CORR_U tiles (= 16 x 16 B per lane) are put in flight before the first MFMA consumes them.
 #define CORR_U 4
-// QUADLOAD (tools/probes/corr_variant.hip only; results WRONG on purpose): four consecutive lanes fetch the 64 contiguous bytes of ONE
-// position instead of 16 bytes of four positions 256 bytes apart -- what the window loads would cost if the L1's request stream were
-// coalesced per quad (the MFMA fragment layout ties a lane's low four bits to the position, so the product cannot load this way).
-template <bool QUADLOAD = false>
+template <int MODE = 0>
 __device__ __forceinline__ void corr_bbox_mfma(const h8 (&a)[4], __amdgpu_buffer_rsrc_t rsrc, int H, int W, int x0, int y0, int bw, int np,
                                                bool any_in, float* __restrict__ raw, int lane) {
   const int n = lane & 15, kg = lane >> 4;
@@ -98,18 +108,17 @@ __device__ __forceinline__ void corr_bbox_mfma(const h8 (&a)[4], __amdgpu_buffer
     u4 b[CORR_U][4];
 #pragma unroll
     for (int u = 0; u < CORR_U; ++u) {
-      const int pos = (t0 + u) * 16 + (QUADLOAD ? (lane >> 2) : n);
+      const int pos = CorrLoad<MODE>::pos(t0 + u, n, lane);
       const int py = (int)fmaf((float)pos, inv_bw, half_inv), px = pos - __mul24(py, bw);
       const int y = y0 + py, x = x0 + px;
       const bool ok = (pos < np) & ((unsigned)x < (unsigned)W) & ((unsigned)y < (unsigned)H);
-      // (24-bit multiplies: the caller's `any_in` keeps |y| < 2^11, W < 2^15.  The address is computed for every lane and the invalid
-      //  ones are redirected by mask arithmetic: as `ok ? address : 0x80000000` the compiler computes the address under an exec mask --
-      //  two scalar instructions and a branch shadow per tile)
-      const unsigned addr = (unsigned)(__mul24(y, W) + x) * (CORR_C * 2) + (QUADLOAD ? (lane & 3) : kg) * 16;
+      // (the address is computed for every lane and the invalid ones are redirected by mask arithmetic: as `ok ? address : 0x80000000`
+      //  the compiler computes the address under an exec mask -- two scalar instructions and a branch shadow per tile)
+      const unsigned addr = CorrLoad<MODE>::addr(y, x, W, kg, lane);
       const unsigned keep = ok ? 0xffffffffu : 0u;
       const unsigned voff = (addr & keep) | (~keep & 0x80000000u);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) b[u][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + s * 64, 0, 0);
+      for (int s = 0; s < 4; ++s) b[u][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + s * CorrLoad<MODE>::STEP, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < CORR_U; ++u) {
@@ -124,7 +133,7 @@ __device__ __forceinline__ void corr_bbox_mfma(const h8 (&a)[4], __amdgpu_buffer
 
 // One level: blends this level's 441 outputs from the raw volume into the LDS row image
 // orow[q*2 + level] (f16), q = ((x*7+y)*3+i0)*3+j0.
-template <bool QUADLOAD = false>
+template <int MODE = 0>
 __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fmap, int H, int W, float cx, float cy, CorrShared& sm,
                                            int lane, int level) {
   float* __restrict__ raw = sm.raw;
@@ -137,17 +146,18 @@ __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fma
   bbox_reduce(rnx, rxx, rny, rxy);
   const int mnx = __builtin_amdgcn_readlane(rnx, 15), mxx = __builtin_amdgcn_readlane(rxx, 15);
   const int mny = __builtin_amdgcn_readlane(rny, 15), mxy = __builtin_amdgcn_readlane(rxy, 15);
-  const int bw = mxx - mnx + CORR_D, bh = mxy - mny + CORR_D;      // (|coordinates| <= 1e6: no overflow)
-  const bool single = (bw <= CORR_MAXPOS) & (bh <= CORR_MAXPOS) && (bw * bh <= CORR_MAXPOS);
+  constexpr bool A4 = CorrLoad<MODE>::ALIGN4;       // (measurement modes only: columns aligned to groups of four, the width rounded up)
+  const int x0 = (mnx - CORR_R) & (A4 ? ~3 : ~0), y0 = mny - CORR_R;
+  const int bw = A4 ? ((mxx - CORR_R + CORR_D + 3) & ~3) - x0 : mxx - mnx + CORR_D, bh = mxy - mny + CORR_D;      // (|coordinates| <= 1e6: no overflow)
+  const bool single = (bw <= CORR_MAXPOS) & (bh <= CORR_MAXPOS) && (bw * bh <= (A4 ? CORR_RAWPOS : CORR_MAXPOS));
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)fmap, (short)0, H * W * CORR_C * 2, 0x00020000);
 
   if (single) {
-    const int x0 = mnx - CORR_R, y0 = mny - CORR_R;
     const int np = bw * bh;
-    if (pl) sm.meta[lane] = (f4){dx, dy, __int_as_float((fy - mny) * bw + (fx - mnx)), 0.f};
+    if (pl) sm.meta[lane] = (f4){dx, dy, __int_as_float((fy - mny) * bw + (fx - CORR_R - x0)), 0.f};
     const bool any_in = (x0 + bw > 0) & (x0 < W) & (y0 + bh > 0) & (y0 < H);
-    corr_bbox_mfma<QUADLOAD>(a, rsrc, H, W, x0, y0, bw, np, any_in, raw, lane);
+    corr_bbox_mfma<MODE>(a, rsrc, H, W, x0, y0, bw, np, any_in, raw, lane);
     __syncthreads();
     CORR_T(2 + 2 * level);
     // Blend (correlation_kernel.cu:221-230): lane = (patch pixel p = lane % 9, window column bx = lane / 9) walks the 7 window
@@ -183,7 +193,7 @@ __device__ __forceinline__ void corr_level(const h8 (&a)[4], const _Float16* fma
       const int pfx = __builtin_amdgcn_readlane(fx, p), pfy = __builtin_amdgcn_readlane(fy, p);
       const int x0 = pfx - CORR_R, y0 = pfy - CORR_R;
       const bool any_in = (x0 + CORR_D > 0) & (x0 < W) & (y0 + CORR_D > 0) & (y0 < H);
-      corr_bbox_mfma<QUADLOAD>(a, rsrc, H, W, x0, y0, CORR_D, CORR_D * CORR_D, any_in, raw, lane);
+      corr_bbox_mfma<MODE>(a, rsrc, H, W, x0, y0, CORR_D, CORR_D * CORR_D, any_in, raw, lane);
       __syncthreads();
       if (lane < 49) {                       // 49 outputs of pixel p: lane = bx*7 + ay
         const int bx = lane / 7, ay = lane - bx * 7;

@@ -192,4 +192,6 @@ def test_committed_pmc_pass_belongs_to_the_committed_correlation_kernel():
     import bench
     traffic, source = bench.pmc_traffic("default")
     assert traffic is not None, f"stale PMC pass: {source} (run tools/pmc_corr.sh on a GPU box and commit profiles/rNN_corr_pmc.json)"
-    assert 1.0e9 < traffic < 2.6e9 and source.endswith("_corr_pmc.json"), (traffic, source)
+    # (0.98 GB on the SURVEY 8d stream of round 6, 1.65-1.68 GB on the 2-D crop stream of rounds 1-5: how many window bytes the per-XCD L2s serve
+    #  depends on how coherent the reprojected coordinates are; compulsory 0.28 GB, streaming model 2.52 GB)
+    assert 0.3e9 < traffic < 2.6e9 and source.endswith("_corr_pmc.json"), (traffic, source)

@@ -10,5 +10,5 @@ cd $root/dpvo_amd/csrc
 [ "$1" = build ] && exit 0
 cd $root
 echo "product:"; python tools/corr_bench.py 2>&1 | grep "per launch"
-for v in 0 1 2 4 5 6 7 8; do echo "CORR_VARIANT=$v:"; CORR_VARIANT=$v DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_corrvar.so python tools/corr_bench.py 2>&1 | grep "per launch"; done
+for v in 0 1 2 4 5 6 7 8 9 10 11 12; do echo "CORR_VARIANT=$v:"; CORR_VARIANT=$v DPVO_HIP_LIB=$root/dpvo_amd/libdpvo_hip_corrvar.so python tools/corr_bench.py 2>&1 | grep "per launch"; done
 echo "product:"; python tools/corr_bench.py 2>&1 | grep "per launch"

@@ -9,9 +9,36 @@
 //      coordinates still loaded: the most that several edges of one patch per workgroup sharing the index / template round trips
 //       could save;  7: as 6, and the output row is not written (the most a correlation fused into the update
 //      operator's first kernel could save on THIS side of the fusion);
-//   8: the window loads with four consecutive lanes fetching 64 contiguous bytes of ONE position (corr_dev.h: QUADLOAD) -- what the
-//      kernel would cost if the L1's request stream were coalesced per quad of lanes (round 6).
+//   8 .. 12: other lane -> address maps of the window loads (the CorrLoad specialisations below): what the vector L1 makes of the same
+//      bytes requested differently (round 6; profiles/r06_d_corr_diet_and_quad_probe.txt).
 #include "../../dpvo_amd/csrc/corr_dev.h"
+
+// ---- other lane -> address maps of the window loads (CorrLoad<MODE>, corr_dev.h), results wrong on purpose: what does the vector L1 make of them?
+template <> struct CorrLoad<1> {       // variant 8: four consecutive lanes fetch 64 contiguous bytes of ONE position
+  static constexpr bool ALIGN4 = false; static constexpr int STEP = 64;
+  static __device__ __forceinline__ int pos(int tile, int n, int lane) { return tile * 16 + (lane >> 2); }
+  static __device__ __forceinline__ unsigned addr(int y, int x, int W, int kg, int lane) { return (unsigned)(__mul24(y, W) + x) * 256 + (lane & 3) * 16; }
+};
+template <> struct CorrLoad<2> {       // variant 10: sixteen consecutive lanes fetch the 256 contiguous bytes of ONE position
+  static constexpr bool ALIGN4 = false; static constexpr int STEP = 1024;
+  static __device__ __forceinline__ int pos(int tile, int n, int lane) { return tile * 16 + (lane >> 4); }
+  static __device__ __forceinline__ unsigned addr(int y, int x, int W, int kg, int lane) { return (unsigned)(__mul24(y, W) + x) * 256 + (lane & 15) * 16; }
+};
+template <> struct CorrLoad<3> {       // variant 9: the addressing of an x4-interleaved map [y][x / 4][chunk 16][x % 4][8 halves], boxes aligned to 4 columns
+  static constexpr bool ALIGN4 = true; static constexpr int STEP = 256;
+  static __device__ __forceinline__ int pos(int tile, int n, int lane) { return tile * 16 + n; }
+  static __device__ __forceinline__ unsigned addr(int y, int x, int W, int kg, int lane) { return (unsigned)(__mul24(y, W >> 2) + (x >> 2)) * 1024 + kg * 64 + (x & 3) * 16; }
+};
+template <> struct CorrLoad<4> {       // variant 11: the same with a group stride of 1 088 bytes (no power-of-two stride between the groups of a quarter wave)
+  static constexpr bool ALIGN4 = true; static constexpr int STEP = 256;
+  static __device__ __forceinline__ int pos(int tile, int n, int lane) { return tile * 16 + n; }
+  static __device__ __forceinline__ unsigned addr(int y, int x, int W, int kg, int lane) { return (unsigned)(__mul24(y, W >> 2) + (x >> 2)) * 1088 + kg * 64 + (x & 3) * 16; }
+};
+template <> struct CorrLoad<5> {       // variant 12: an x16-blocked map [y][x / 16][kg 4][(x / 4) % 4][s 4][x % 4][8 halves]: variant 8's address pattern made legal, boxes aligned to 4
+  static constexpr bool ALIGN4 = true; static constexpr int STEP = 64;
+  static __device__ __forceinline__ int pos(int tile, int n, int lane) { return tile * 16 + n; }
+  static __device__ __forceinline__ unsigned addr(int y, int x, int W, int kg, int lane) { return (unsigned)(__mul24(y, W >> 4) + (x >> 4)) * 4096 + kg * 1024 + ((x >> 2) & 3) * 256 + (x & 3) * 16; }
+};
 
 template <int VARIANT>
 __global__ __launch_bounds__(64, 3) void corr_pyramid_variant_kernel(
@@ -19,7 +46,7 @@ __global__ __launch_bounds__(64, 3) void corr_pyramid_variant_kernel(
     const float* __restrict__ coords, const int64_t* __restrict__ us, const int64_t* __restrict__ vs, _Float16* __restrict__ out,
     int64_t ld_out, int64_t E, int H0, int W0, int H1, int W1, int N1, int N2) {
   __shared__ CorrShared sm;
-  constexpr bool Q = VARIANT == 8;
+  constexpr int Q = VARIANT == 8 ? 1 : VARIANT == 10 ? 2 : VARIANT == 9 ? 3 : VARIANT == 11 ? 4 : VARIANT == 12 ? 5 : 0;
   const int lane = threadIdx.x;
   if (lane < 14) sm.orow[2 * CORR_NOUT + lane] = (_Float16)0;
   for (int64_t e = blockIdx.x; e < E; e += gridDim.x) {
@@ -88,6 +115,10 @@ extern "C" int dpvo_corr_pyramid_variant(const void* gmap, const void* fmap0, co
     case 6: CV(6); break;
     case 7: CV(7); break;
     case 8: CV(8); break;
+    case 9: CV(9); break;
+    case 10: CV(10); break;
+    case 11: CV(11); break;
+    case 12: CV(12); break;
     default: return DPVO_E_UNSUPPORTED;
   }
 #undef CV
