@@ -395,18 +395,35 @@ __global__ __launch_bounds__(384) void softagg_kernel(const _Float16* __restrict
     float m[4], s[4], a[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; s[r] = 0.f; a[r] = 0.f; }
-    for (int p = b + q; p < e; p += 4) {
-      const _Float16* rowp = fg + (int64_t)perm[p] * ldfg + 4 * cq;
-      const h4 fx = *reinterpret_cast<const h4*>(rowp), gx = *reinterpret_cast<const h4*>(rowp + D);
+    // SA_U members of the slice in flight at a time: first their row ids, then their rows, then the (sequential) online-softmax
+    // steps in member order -- the same operations in the same order as one member per trip, which was two DEPENDENT round trips per
+    // member (id, then row): 24 trips for a frame-pair group at ~1 us each were the kernel's 24 us (round 6)
+    constexpr int SA_U = 6;
+    for (int p0 = b + q; p0 < e; p0 += 4 * SA_U) {
+      int rid[SA_U];
+      h4 fx[SA_U], gx[SA_U];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float g_ = (float)gx[r];
-        const float mn = fmaxf(m[r], g_);
-        const float sc = __expf(m[r] - mn), w = __expf(g_ - mn);
-        s[r] = s[r] * sc + w;
-        a[r] = a[r] * sc + w * (float)fx[r];
-        m[r] = mn;
-      }
+      for (int u = 0; u < SA_U; ++u) rid[u] = p0 + 4 * u < e ? perm[p0 + 4 * u] : -1;
+#pragma unroll
+      for (int u = 0; u < SA_U; ++u)
+        if (rid[u] >= 0) {
+          const _Float16* rowp = fg + (int64_t)rid[u] * ldfg + 4 * cq;
+          fx[u] = *reinterpret_cast<const h4*>(rowp);
+          gx[u] = *reinterpret_cast<const h4*>(rowp + D);
+        }
+#pragma unroll
+      for (int u = 0; u < SA_U; ++u)
+        if (rid[u] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g_ = (float)gx[u][r];
+            const float mn = fmaxf(m[r], g_);
+            const float sc = __expf(m[r] - mn), w = __expf(g_ - mn);
+            s[r] = s[r] * sc + w;
+            a[r] = a[r] * sc + w * (float)fx[u][r];
+            m[r] = mn;
+          }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { part[q][0][4 * cq + r] = m[r]; part[q][1][4 * cq + r] = s[r]; part[q][2][4 * cq + r] = a[r]; }
