@@ -99,6 +99,19 @@ def test_environment_reads_are_on_the_allow_list():
     assert "DPVO_HIP_LIB" in seen
 
 
+def test_integration_md_quotes_the_stub_file():
+    """INTEGRATION.md sections 1-3 quote dpvo_amd/integration_stubs.py verbatim: every ```python block of those sections is a substring of
+    the file (the file is what tests/test_gpu_integration_stubs.py executes; the document must not drift from it)"""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "dpvo_amd", "integration_stubs.py")).read()
+    sec = md[md.index("## 1-3. The three import sites"):md.index("## 4. ")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 4
+    for b in blocks:
+        assert b.strip() in src, b[:200]
+    assert sum(len(b) for b in blocks) > 0.85 * len(src[src.index("import ctypes"):])
+
+
 def test_argument_validation_is_host_only():
     """every entry validates its arguments before touching the device: error codes without a GPU, never a crash / exit
     (the reference calls exit(1) in block_e.cu:20-27 and ba.cpp:151-152)"""
