@@ -30,6 +30,7 @@ SYMBOLS = [
     "dpvo_update_fused_pack_bytes", "dpvo_update_fused_pack", "dpvo_update_fused_workspace_bytes", "dpvo_update_forward_fused", "dpvo_update_forward_fused_rows", "dpvo_update_fused_default_tiling",
     "dpvo_ba_workspace_bytes", "dpvo_ba",
     "dpvo_gba_workspace_bytes", "dpvo_gba_linearize", "dpvo_gba_relinearize", "dpvo_gba_retract", "dpvo_gba_solve_workspace_bytes", "dpvo_gba_solve",
+    "dpvo_solve_system_workspace_bytes", "dpvo_solve_system",
     "dpvo_normalize_image", "dpvo_patch_colors", "dpvo_store_features", "dpvo_append_edges", "dpvo_gather_edges", "dpvo_gather_edges2",
     "dpvo_motion_model", "dpvo_median_depth", "dpvo_frame_patches", "dpvo_frame_state", "dpvo_frame_state_part", "dpvo_keyframe_step", "dpvo_frame_update", "dpvo_debug_stamp",
     "dpvo_encoders_workspace_bytes", "dpvo_encoders_forward", "dpvo_encoders_forward_hold", "dpvo_pool4_nhwc",
@@ -114,7 +115,7 @@ def lib():
             if not hasattr(L, s):
                 raise DPVOHipError(f"libdpvo_hip.so does not export {s}")
         for s in ("dpvo_plan_workspace_bytes", "dpvo_plan_wide_workspace_bytes", "dpvo_normalize_scratch_bytes", "dpvo_neighbors_workspace_bytes", "dpvo_ba_workspace_bytes",
-                  "dpvo_gba_workspace_bytes", "dpvo_gba_solve_workspace_bytes", "dpvo_encoders_workspace_bytes",
+                  "dpvo_gba_workspace_bytes", "dpvo_gba_solve_workspace_bytes", "dpvo_solve_system_workspace_bytes", "dpvo_encoders_workspace_bytes",
                   "dpvo_update_fused_workspace_bytes", "dpvo_update_fused_pack_bytes"):
             getattr(L, s).restype = ctypes.c_size_t
         L.dpvo_abi_version.restype = ctypes.c_int

@@ -1,1 +1,1 @@
-from .ba import BA, neighbors, reproject
+from .ba import BA, neighbors, reproject, solve_system

@@ -71,3 +71,34 @@ def BA(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1, M,
                             L.i32(iterations), L.ptr(info), L.ptr(ws), ctypes.c_size_t(ws.numel()), L.stream()),
             "dpvo_ba")
     return []
+
+
+def solve_system(J_Ginv_i, J_Ginv_j, ii, jj, res, ep, lm, freen):
+    """cuda_ba.solve_system (ba.cpp:120-180, called by loop_closure/optim_utils.py:229): one Levenberg-Marquardt step of the Sim(3)
+    pose-graph optimisation -> [delta [n, 7]] (a one-element list, like the pybind entry returns).  J_Ginv_i / J_Ginv_j [r,7,7], ii / jj
+    [r] long, res [r,7]; n = max(ii, jj) + 1 (read back, as the reference does at :131).  Assembled and solved in f64 on the device
+    (csrc/pgo.hip).  Raises where the reference calls exit(1) (an edge with ii == jj) and when the damped system is not positive
+    definite (the reference's Eigen solve would return garbage silently)."""
+    L.require_cuda(J_Ginv_i, J_Ginv_j, ii, jj, res)
+    Ji = J_Ginv_i.reshape(-1, 7, 7).float().contiguous()
+    Jj = J_Ginv_j.reshape(-1, 7, 7).float().contiguous()
+    rs = res.reshape(-1, 7).float().contiguous()
+    ii = ii.long().contiguous(); jj = jj.long().contiguous()
+    r = ii.numel()
+    if not (Ji.shape[0] == Jj.shape[0] == rs.shape[0] == jj.numel() == r) or r == 0:
+        raise L.DPVOHipError("solve_system: J_Ginv_i, J_Ginv_j [r,7,7], ii, jj [r], res [r,7] with r > 0")
+    n = int(torch.maximum(ii.max(), jj.max()).item()) + 1
+    freen = int(freen)
+    delta = torch.empty(n, 7, dtype=torch.float32, device=rs.device)
+    info = torch.zeros(1, dtype=torch.int32, device=rs.device)
+    nbytes = L.lib().dpvo_solve_system_workspace_bytes(L.i64(n), L.i64(freen))
+    ws = workspace.get(nbytes, rs.device, "pgo")
+    L.check(L.lib().dpvo_solve_system(L.ptr(Ji), L.ptr(Jj), L.ptr(ii), L.ptr(jj), L.ptr(rs), L.i64(r), L.i64(n), L.f32(float(ep)),
+                                      L.f32(float(lm)), L.i64(freen), L.ptr(delta), L.ptr(info), L.ptr(ws), ctypes.c_size_t(ws.numel()),
+                                      L.stream()), "dpvo_solve_system")
+    code = int(info.item())
+    if code == 1:
+        raise L.DPVOHipError("solve_system: an edge connects a node with itself (the reference exits the process here, ba.cpp:139-140)")
+    if code == 2:
+        raise L.DPVOHipError("solve_system: the damped normal equations are not positive definite")
+    return [delta]

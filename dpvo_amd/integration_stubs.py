@@ -18,7 +18,7 @@ import os
 import torch
 
 _L = ctypes.CDLL(os.environ.get("DPVO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdpvo_hip.so"))
-for _n in ("dpvo_neighbors_workspace_bytes", "dpvo_plan_workspace_bytes", "dpvo_ba_workspace_bytes"):
+for _n in ("dpvo_neighbors_workspace_bytes", "dpvo_plan_workspace_bytes", "dpvo_ba_workspace_bytes", "dpvo_solve_system_workspace_bytes"):
     getattr(_L, _n).restype = ctypes.c_size_t            # (every other entry returns int: 0 ok, < 0 DPVO_E_*, > 0 hipError_t)
 _p = lambda t: ctypes.c_void_p(t.data_ptr())
 _i64 = ctypes.c_int64
@@ -102,6 +102,17 @@ class cuda_ba:                                             # replaces: import cu
         _check(_L.dpvo_reproject(_p(poses), _p(patches), _p(intrinsics), _p(ii), _p(jj), _p(kk), _p(coords), _i64(E), int(P), 0, _st()),
                "dpvo_reproject")
         return coords
+
+    @staticmethod
+    def solve_system(J_Ginv_i, J_Ginv_j, ii, jj, res, ep, lm, freen):      # ba.cpp:188 -> dpvo_solve_system (f64 on the device; the reference: Eigen on the CPU)
+        Ji, Jj, rs = J_Ginv_i.float().contiguous(), J_Ginv_j.float().contiguous(), res.reshape(-1, 7).float().contiguous()
+        ii, jj = ii.long().contiguous(), jj.long().contiguous()
+        r, n = ii.numel(), int(max(ii.max().item(), jj.max().item())) + 1
+        delta = torch.empty(n, 7, dtype=torch.float32, device=rs.device)
+        ws = torch.empty(_L.dpvo_solve_system_workspace_bytes(_i64(n), _i64(int(freen))), dtype=torch.uint8, device=rs.device)
+        _check(_L.dpvo_solve_system(_p(Ji), _p(Jj), _p(ii), _p(jj), _p(rs), _i64(r), _i64(n), ctypes.c_float(float(ep)), ctypes.c_float(float(lm)),
+                                    _i64(int(freen)), _p(delta), None, _p(ws), ctypes.c_size_t(ws.numel()), _st()), "dpvo_solve_system")
+        return [delta]
 
 
 class lietorch_backends:                                   # replaces: import lietorch_backends (lietorch.cpp:286-316), SE3 forward

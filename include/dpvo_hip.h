@@ -531,6 +531,24 @@ int dpvo_gba_retract(float* poses, float* patches, const int32_t* plan, int64_t 
 size_t dpvo_gba_solve_workspace_bytes(int n);
 int dpvo_gba_solve(const float* S, const float* y, int n, float* dX, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * classical loop closure, numerics only  
+ * ---------------------------------------------------------------------------------------------- */
+
+/* cuda_ba.solve_system(J_Ginv_i, J_Ginv_j, ii, jj, res, ep, lm, freen) -- dpvo/fastba/ba.cpp:120-180 (exported :188; caller
+ * dpvo/loop_closure/optim_utils.py:229): ONE Levenberg-Marquardt step of the Sim(3) pose-graph optimisation.
+ *   J_Ginv_i, J_Ginv_j [r,7,7] f32: per-edge Jacobian blocks w.r.t. nodes ii[x], jj[x] (int64 [r], ii[x] != jj[x]); res [r,7] f32.
+ *   A = J^T J, b = -J^T res assembled in f64 (the reference: Eigen sparse, double); A.diag += A.diag * lm, then += ep (:152-153);
+ *   delta = A^-1 b over the leading 7 freen x 7 freen block when 0 <= freen < n_nodes (the other nodes get 0, :102-118), over all nodes
+ *   otherwise; delta [n_nodes,7] f32.  n_nodes = max(ii, jj) + 1 (the reference reads it back with .item(), :131).
+ * Dense f64 blocked Cholesky on the device (pgo.hip); info (device int32, may be NULL): 0 ok, 1 an edge with ii == jj or a negative
+ * index (the reference calls exit(1), :139-140; this library never exits), 2 the damped matrix is not positive definite. */
+size_t dpvo_solve_system_workspace_bytes(int64_t n_nodes, int64_t freen);
+int dpvo_solve_system(const float* J_Ginv_i, const float* J_Ginv_j, const int64_t* ii, const int64_t* jj, const float* res, int64_t r,
+                      int64_t n_nodes, float ep, float lm, int64_t freen, float* delta, int32_t* info, void* ws, size_t ws_bytes,
+                      void* stream);
+
+
 /* Dev aid: a one-thread kernel that stores the 100 MHz wall clock into *slot (uint64) when it executes: stream-ordered time
  * stamps across streams without a profiler (tools/stream_stamps.py). */
 int dpvo_debug_stamp(void* slot, void* stream);

@@ -337,3 +337,37 @@ def test_ref_standins_lietorch_and_scatter(oracle):
         assert torch.allclose(ss[0, k], src[0, m].sum(0), atol=1e-5)
     h = RS.scatter_softmax(src.half(), idx, dim=1)
     assert h.dtype == torch.float16 and torch.allclose(h.float(), sm, atol=2e-3)
+
+
+def test_pgo_ref_solves_the_triplet_normal_equations():
+    """oracle/pgo_ref.py (cuda_ba.solve_system restated, ba.cpp:102-180) pinned by what it restates: its delta solves the damped normal
+    equations of a Jacobian assembled INDEPENDENTLY entry by entry the way the reference's triplet loop does (:136-146, duplicates add up),
+    the freen variant leaves the nodes behind freen at zero and solves the leading block alone (:102-118), and an edge from a node to
+    itself is refused (the reference exits, :139-140).  Eigen is not in the image: there is no reference binary for this path -- parity
+    unpinned beyond the algebra, stated here and in DESIGN.md."""
+    from oracle import pgo_ref
+    rng = np.random.default_rng(5)
+    n = 15
+    ii = np.concatenate([np.arange(n - 1), [0, 2, 2]]); jj = np.concatenate([np.arange(1, n), [9, 12, 12]])      # chain + loops + a duplicate
+    r = len(ii)
+    Ji = (-np.eye(7)[None] + 0.3 * rng.standard_normal((r, 7, 7))).astype(np.float32)
+    Jj = (np.eye(7)[None] + 0.3 * rng.standard_normal((r, 7, 7))).astype(np.float32)
+    res = rng.standard_normal((r, 7)).astype(np.float32)
+    J = np.zeros((7 * r, 7 * n))
+    for x in range(r):
+        for k in range(7):
+            for l in range(7):
+                J[7 * x + k, 7 * ii[x] + l] += float(Ji[x, k, l])
+                J[7 * x + k, 7 * jj[x] + l] += float(Jj[x, k, l])
+    v = res.reshape(-1).astype(np.float64)
+    for ep, lm, freen in ((0.0, 1e-6, -1), (1e-3, 1e-4, -1), (0.0, 1e-6, 9)):
+        d = pgo_ref.solve_system(Ji, Jj, ii, jj, res, ep, lm, freen).astype(np.float64).reshape(-1)
+        m = 7 * (n if freen < 0 else freen)
+        A = (J.T @ J)[:m, :m]
+        dg = np.diag(A).copy()
+        A[np.diag_indices_from(A)] = dg + dg * np.float64(np.float32(lm)) + np.float64(np.float32(ep))
+        b = -(J.T @ v)[:m]
+        assert np.abs(A @ d[:m] - b).max() <= 2e-5 * max(1.0, np.abs(b).max())
+        assert np.all(d[m:] == 0)
+    with pytest.raises(ValueError):
+        pgo_ref.solve_system(Ji, Jj, ii, ii, res, 0.0, 1e-6, -1)
