@@ -14,6 +14,7 @@ from .lietorch import SE3
 from .utils import flatmeshgrid
 
 _NORMALIZE_FUSED = True     # tools/lc_ab.py sets it False: PatchGraph.normalize as torch operations (measurements)
+MAX_LOOP_PAIRS = 1000       # reduce_edges(max_num_edges=1000) of the reference's edges_loop (patchgraph.py:76)
 _INAC_PREALLOC_FRAC = 0.02  # the inactive-edge store is preallocated from at most this fraction of the device memory that is free
 
 
@@ -367,7 +368,14 @@ class PatchGraph:
         self.delta = {}
 
         ### edge information: preallocated stores, exposed under the reference's attribute names ###
-        self.edges = EdgeStore(DIM, dev, with_state=True, mirror=True)
+        # Capacity from the configuration, for the same reason as the inactive store's below: a doubling in the middle of a tracked frame
+        # reallocates both sets, the one-call path's scratch and four pinned staging buffers (measured with LOOP_CLOSURE, the first time
+        # a batch of loop edges took E past 65 536: one frame of 9.9 ms, profiles/r06_h_lc_host_trace.txt).  Bound: every frame of the removal
+        # window (+ the newest two) with its 2 PATCH_LIFETIME + 2 neighbours, plus -- LOOP_CLOSURE -- the MAX_LOOP_PAIRS frame pairs
+        # edges_loop() can return at once, M edges each.  Growing by doubling remains the fallback (append_factors of a caller's own edges).
+        r_, w_ = int(getattr(self.cfg, "PATCH_LIFETIME", 13)), int(getattr(self.cfg, "REMOVAL_WINDOW", 22))
+        need = self.M * (w_ + 2) * (2 * r_ + 2) + (MAX_LOOP_PAIRS * self.M if getattr(self.cfg, "LOOP_CLOSURE", False) else 0)
+        self.edges = EdgeStore(DIM, dev, with_state=True, mirror=True, cap=max(1 << 16, 1 << (need - 1).bit_length()))
         ### inactive edge information (i.e., no longer updated, but useful for BA) ###
         # sized for the whole buffer up front when that is affordable (every keyframe eventually retires its ~2 * PATCH_LIFETIME * M
         # edges here, remove_factors(store=True): 40 B per edge, 0.4 GB for the default 4096-frame buffer on a 288 GB device): growing
@@ -422,9 +430,15 @@ class PatchGraph:
         flow_mag = torch.where(num_val > (self.M * 0.75), flow_mg_sum / num_val,
                                torch.full_like(num_val, float("inf")))
 
-        mask = (flow_mag < self.cfg.BACKEND_THRESH)
-        es = reduce_edges(flow_mag[mask].cpu().numpy(), ii[::self.M][mask].cpu().numpy(),
-                          jj[::self.M][mask].cpu().numpy(), max_num_edges=1000, nms=1)
+        # mask = flow_mag < BACKEND_THRESH; reduce_edges(flow_mag[mask], ii[::M][mask], jj[::M][mask], ...) (patchgraph.py:73-76) with ONE
+        # read-back instead of three boolean-mask selections (a nonzero() round trip each) and three copies: the candidates' frame
+        # numbers are a function of n (target-major, source frame fastest: flatmeshgrid above; ix[k] == k // M, dpvo.py:405), so only
+        # the flow magnitudes come back and the selection happens on the host -- same values, same order
+        fm_h = flow_mag.cpu().numpy()
+        j_f = np.arange(n - self.cfg.GLOBAL_OPT_FREQ, n - self.cfg.KEYFRAME_INDEX, dtype=np.int64)
+        i_f = np.arange(max(l - lc_range, 0), l, dtype=np.int64)
+        mask = fm_h < np.float32(self.cfg.BACKEND_THRESH)
+        es = reduce_edges(fm_h[mask], np.tile(i_f, j_f.size)[mask], np.repeat(j_f, i_f.size)[mask], max_num_edges=MAX_LOOP_PAIRS, nms=1)
 
         # how many of the edges this call returns are long-range ones by update()'s test `ii < n - REMOVAL_WINDOW - 1` (dpvo.py:348)
         # at the frame count they were evaluated for: known here on the host, the tracker need not ask the device

@@ -441,6 +441,12 @@ def test_patchgraph_edges_loop_and_normalize_match_the_reference(dev):
     cfg = SimpleNamespace(PATCHES_PER_FRAME=M, BUFFER_SIZE=64, LOOP_CLOSURE=True, REMOVAL_WINDOW=22, GLOBAL_OPT_FREQ=15,
                           KEYFRAME_INDEX=4, MAX_EDGE_AGE=1000, BACKEND_THRESH=64.0)
     pg = PatchGraph(cfg, 3, 384, 1000, device=dev, dtype=torch.float)
+    # the active edge store holds the window's edges AND the largest batch edges_loop can return (1000 frame pairs x M) without growing:
+    # a doubling inside a tracked frame cost one frame of 9.9 ms (profiles/r06_h_lc_host_trace.txt)
+    from dpvo_amd.patchgraph import MAX_LOOP_PAIRS
+    assert pg.edges.cap >= M * 24 * 28 + MAX_LOOP_PAIRS * M
+    cfg0 = SimpleNamespace(**{**vars(cfg), "LOOP_CLOSURE": False})
+    assert PatchGraph(cfg0, 3, 384, 1000, device=dev, dtype=torch.float).edges.cap == max(1 << 16, 1 << (M * 24 * 28 - 1).bit_length())
     pg.n, pg.m = n, n * M
     pg.poses_[:n] = torch.from_numpy(g["pg_poses"]).to(dev)
     pg.patches_[:n] = torch.from_numpy(g["pg_patches"]).to(dev).view(n, M, 3, 3, 3)
