@@ -20,7 +20,7 @@ ABI_VERSION = 7         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding
 SYMBOLS = [
     "dpvo_abi_version",
     "dpvo_corr_forward", "dpvo_corr_pyramid_forward", "dpvo_patchify_forward", "dpvo_patchify_bilinear",
-    "dpvo_reproject", "dpvo_flow_mag", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud", "dpvo_point_cloud_motionmag",
+    "dpvo_reproject", "dpvo_flow_mag", "dpvo_loop_flow", "dpvo_motionmag", "dpvo_motionmag_status", "dpvo_point_cloud", "dpvo_point_cloud_motionmag",
     "dpvo_normalize_scratch_bytes", "dpvo_normalize",
     "dpvo_se3_inv", "dpvo_se3_mul", "dpvo_se3_act4", "dpvo_se3_exp", "dpvo_se3_log",
     "dpvo_plan_layout", "dpvo_plan_workspace_bytes", "dpvo_plan_build", "dpvo_plan_build_ranged", "dpvo_plan_build_window", "dpvo_plan_build_window_flow",

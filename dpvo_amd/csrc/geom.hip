@@ -129,6 +129,38 @@ __global__ void flow_mag_kernel(const float* __restrict__ poses, const float* __
     edge_flow(poses, patches, intr, ii[e], jj[e], kk[e], beta, P, flow + e, valid + e);
 }
 
+// PatchGraph.edges_loop's candidate test (patchgraph.py:56-72), one workgroup per candidate frame pair (target j = j0 + b / n_i, source
+// frame f = i0 + b % n_i): thread p takes the CENTRE pixel of patch k = f M + p (the reference hands pops.flow_mag patches[..., 1, 1]),
+// i = ix[k]; flow and validity exactly as flow_mag_kernel computes them for a 1 x 1 patch (same flow_pixel).  Then the reference's
+// reduction: val = nvalid > 0.5; sum (flow * val) and sum val over the M patches; flow_mag = sum / max(count, 1) if count > 0.75 M,
+// else +inf.  Fixed reduction tree (wave butterflies, then the waves in order): bit-repeatable.  The result may be pinned host memory.
+__global__ __launch_bounds__(256) void loop_flow_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                        const float* __restrict__ intr, const int64_t* __restrict__ ix, int64_t j0,
+                                                        int64_t i0, int64_t n_i, int M, int P, float beta, float* __restrict__ out) {
+  __shared__ float red[2][4];
+  const int64_t b = blockIdx.x, j = j0 + b / n_i, f = i0 + b % n_i;
+  const int PP = P * P, c = (P / 2) * P + P / 2;
+  float s = 0.f, cnt = 0.f;
+  for (int p = threadIdx.x; p < M; p += 256) {            // (M <= 256 in every configuration: one pass)
+    const int64_t k = f * M + p;
+    const FlowPair F = flow_pair(poses, intr, ix[k], j);
+    const float* pk = patches + k * 3 * PP + c;
+    float fl = 0.f, v = 0.f;
+    flow_pixel(F, pk[0], pk[PP], pk[2 * PP], beta, fl, v);
+    const float val = v > 0.5f ? 1.f : 0.f;
+    s += fl * val;                                          // (a product, as in the reference: inf * 0 = NaN stays NaN)
+    cnt += val;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); cnt += __shfl_xor(cnt, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], C = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    out[b] = C > (float)M * 0.75f ? S / fmaxf(C, 1.f) : __builtin_inff();
+  }
+}
+
 // scan variant: no plan needed, one 1024-thread block walks every edge
 __global__ __launch_bounds__(1024) void motionmag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
                                                          const float* __restrict__ intr, const int64_t* __restrict__ ii,
@@ -282,6 +314,17 @@ extern "C" int dpvo_reproject(const float* poses, const float* patches, const fl
   if (!poses || !patches || !intrinsics || !ii || !jj || !kk || !coords) return DPVO_E_INVALID;
   hipLaunchKernelGGL(reproject_kernel, dim3(grid_for(E * P * P)), dim3(256), 0, (hipStream_t)stream, poses, patches,
                      intrinsics, ii, jj, kk, coords, E, P, clamp_z);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+
+extern "C" int dpvo_loop_flow(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix, int64_t j0,
+                              int64_t n_j, int64_t i0, int64_t n_i, int M, int P, float beta, float* flow_mag, void* stream) {
+  if (n_j < 0 || n_i < 0 || M <= 0 || P <= 0 || j0 < 0 || i0 < 0) return DPVO_E_INVALID;
+  if (n_j == 0 || n_i == 0) return DPVO_OK;
+  if (!poses || !patches || !intrinsics || !ix || !flow_mag || n_j * n_i > 0x7fffffffll) return DPVO_E_INVALID;
+  hipLaunchKernelGGL(loop_flow_kernel, dim3((unsigned)(n_j * n_i)), dim3(256), 0, (hipStream_t)stream, poses, patches, intrinsics, ix, j0,
+                     i0, n_i, M, P, beta, flow_mag);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

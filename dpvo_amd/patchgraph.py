@@ -356,6 +356,7 @@ class PatchGraph:
 
         self.points_ = torch.zeros(self.N * self.M, 3, dtype=torch.float, device=dev)
         self._norm_scratch = None   # dpvo_normalize's scratch (scale, pose 0, partial sums)
+        self._loop_host = self._loop_ev = None      # edges_loop: pinned result buffer of dpvo_loop_flow + its event
         self.colors_ = torch.zeros(self.N, self.M, 3, dtype=torch.uint8, device=dev)
 
         self.index_ = torch.zeros(self.N, self.M, dtype=torch.long, device=dev)
@@ -414,29 +415,29 @@ class PatchGraph:
         if l <= 0:
             return torch.empty(2, 0, dtype=torch.long, device=dev)
 
-        # create candidate edges
-        jj, kk = flatmeshgrid(
-            torch.arange(n - self.cfg.GLOBAL_OPT_FREQ, n - self.cfg.KEYFRAME_INDEX, device=dev),
-            torch.arange(max(l - lc_range, 0) * self.M, l * self.M, device=dev), indexing='ij')
-        ii = self.ix[kk]
-
-        # Remove edges which have too large flow magnitude (centre pixel only: patches[...,1,1] in the reference)
-        c = self.P // 2
-        centre = self.patches[..., c, c].reshape(1, -1, 3, 1, 1)
-        flow_mg, nval = pops.flow_mag(self.poses, centre, self.intrinsics, ii, jj, kk, beta=0.5)
-        val = (nval > 0.5).float()
-        flow_mg_sum = (flow_mg * val).view(-1, self.M).sum(dim=1).float()
-        num_val = val.view(-1, self.M).sum(dim=1).clamp(min=1)
-        flow_mag = torch.where(num_val > (self.M * 0.75), flow_mg_sum / num_val,
-                               torch.full_like(num_val, float("inf")))
-
-        # mask = flow_mag < BACKEND_THRESH; reduce_edges(flow_mag[mask], ii[::M][mask], jj[::M][mask], ...) (patchgraph.py:73-76) with ONE
-        # read-back instead of three boolean-mask selections (a nonzero() round trip each) and three copies: the candidates' frame
-        # numbers are a function of n (target-major, source frame fastest: flatmeshgrid above; ix[k] == k // M, dpvo.py:405), so only
-        # the flow magnitudes come back and the selection happens on the host -- same values, same order
-        fm_h = flow_mag.cpu().numpy()
-        j_f = np.arange(n - self.cfg.GLOBAL_OPT_FREQ, n - self.cfg.KEYFRAME_INDEX, dtype=np.int64)
-        i_f = np.arange(max(l - lc_range, 0), l, dtype=np.int64)
+        # candidate edges: every (target frame j, old source frame i) pair, j-major (the reference's flatmeshgrid of jj and the old
+        # frames' patch ids kk, ii = ix[kk]); flow magnitude of the M patches' centre pixels, validity rule and masked mean of
+        # patchgraph.py:64-72 in ONE launch whose result lands in pinned host memory (dpvo_loop_flow) -- the reference's ~20 small
+        # operations and its three boolean-mask selections cost six host round trips with the GPU idle behind them, on EVERY frame
+        # while no loop is found (tools/lc_host_trace.py: 752 us; LOOP_CLOSURE without loops ran at 740-800 frames/sec instead of 1 000)
+        j0, n_j = n - self.cfg.GLOBAL_OPT_FREQ, self.cfg.GLOBAL_OPT_FREQ - self.cfg.KEYFRAME_INDEX
+        i0 = max(l - lc_range, 0)
+        n_i = l - i0
+        if n_j <= 0 or j0 < 0:
+            return torch.empty(2, 0, dtype=torch.long, device=dev)
+        if self._loop_host is None or self._loop_host.numel() < n_j * n_i:
+            self._loop_host = torch.empty(max(n_j * min(lc_range, self.N), n_j * n_i), dtype=torch.float32).pin_memory()
+            self._loop_ev = torch.cuda.Event()
+        L.check(L.lib().dpvo_loop_flow(L.ptr(self.poses_), L.ptr(self.patches_), L.ptr(self.intrinsics_), L.ptr(self.index_),
+                                       L.i64(j0), L.i64(n_j), L.i64(i0), L.i64(n_i), L.i32(self.M), L.i32(self.P), L.f32(0.5),
+                                       ctypes.c_void_p(self._loop_host.data_ptr()), L.stream()), "dpvo_loop_flow")
+        self._loop_ev.record()
+        self._loop_ev.synchronize()
+        fm_h = self._loop_host[:n_j * n_i].numpy().copy()
+        # mask = flow_mag < BACKEND_THRESH; reduce_edges(flow_mag[mask], ii[::M][mask], jj[::M][mask], ...) (patchgraph.py:73-76) on the
+        # host: the candidates' frame numbers are a function of n (ix[k] == k // M: index_ rows hold their own frame number, dpvo.py:405)
+        j_f = np.arange(j0, j0 + n_j, dtype=np.int64)
+        i_f = np.arange(i0, l, dtype=np.int64)
         mask = fm_h < np.float32(self.cfg.BACKEND_THRESH)
         es = reduce_edges(fm_h[mask], np.tile(i_f, j_f.size)[mask], np.repeat(j_f, i_f.size)[mask], max_num_edges=MAX_LOOP_PAIRS, nms=1)
 

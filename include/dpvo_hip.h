@@ -109,6 +109,14 @@ int dpvo_flow_mag(const float* poses, const float* patches, const float* intrins
                   const int64_t* jj, const int64_t* kk, float beta, float* flow, float* valid, int64_t E, int P,
                   void* stream);
 
+/* PatchGraph.edges_loop's candidate test (dpvo/patchgraph.py:56-72) in one launch: for every pair (target frame j in [j0, j0 + n_j),
+ * source frame f in [i0, i0 + n_i)) the flow magnitude of the reference -- pops.flow_mag(beta) on the CENTRE pixel of the M patches
+ * k = f M + p with i = ix[k], val = nvalid > 0.5, sum(flow val) / max(sum val, 1) when more than 0.75 M are valid, +inf otherwise.
+ *   ix [.] int64 (PatchGraph.index_ flattened), patches [NK,3,P,P];  flow_mag out [n_j * n_i] f32, target-major (the order of the
+ *   reference's flatmeshgrid), device memory or pinned host memory (the caller's one read-back). */
+int dpvo_loop_flow(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix, int64_t j0, int64_t n_j,
+                   int64_t i0, int64_t n_i, int M, int P, float beta, float* flow_mag, void* stream);
+
 /* DPVO.motionmag(i,j) + DPVO.motionmag(j,i) (dpvo/dpvo.py:257-264,269): out4 = {sum_ij, n_ij, sum_ji, n_ji} of
  * the per-edge pixel-mean flow over the edges i->j and j->i (mean = sum/n; 0/0 = NaN like torch's empty mean). */
 int dpvo_motionmag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,

@@ -465,6 +465,49 @@ def test_patchgraph_edges_loop_and_normalize_match_the_reference(dev):
     H.assert_close(pg.delta[7][1].data.cpu().numpy(), g["pg_norm_delta"], 2e-6, 2e-6, "normalize: delta")
 
 
+def test_loop_flow_kernel_matches_the_reference_composition(dev):
+    """dpvo_loop_flow (one launch, PatchGraph.edges_loop's candidate test) against the reference's own sequence of operations
+    (patchgraph.py:56-72: flatmeshgrid, pops.flow_mag on the centre pixels, validity mask, masked mean, the 0.75 M rule) built from
+    dpvo_flow_mag + torch: same +inf pattern, values to f32 rounding of a 96-term sum (the reduction order is the only difference)."""
+    import ctypes
+    from dpvo_amd import _lib as L
+    from dpvo_amd import projective_ops as pops
+    from dpvo_amd import synthetic as S
+    from dpvo_amd.utils import flatmeshgrid
+    N, M, P = 60, 96, 3
+    poses, patches, intr = S.make_scene(N, M, ht=120, wd=160, seed=5, noise=0.02)[:3]
+    poses, patches, intr = poses.to(dev), patches.to(dev).view(N * M, 3, P, P).clone(), intr.to(dev)
+    # invalid pixels (Z <= 0.2 after the transform): inverse depths of +-40 put a point behind the camera for one sign of the baseline's
+    # z component -- sprinkled over all frames, and ALL of frame 5 (half of them invalid whichever sign: under the 0.75 M rule -> +inf)
+    patches[::7, 2] = 40.0
+    patches[3::7, 2] = -40.0
+    patches[5 * M:6 * M:2, 2] = 40.0
+    patches[5 * M + 1:6 * M:2, 2] = -40.0
+    ix = torch.arange(N, device=dev)[:, None].expand(N, M).contiguous()
+    j0, n_j, i0, n_i = 45, 11, 3, 30
+    out = torch.full((n_j * n_i,), -1.0, device=dev)
+    L.check(L.lib().dpvo_loop_flow(L.ptr(poses), L.ptr(patches), L.ptr(intr), L.ptr(ix), L.i64(j0), L.i64(n_j), L.i64(i0), L.i64(n_i),
+                                   L.i32(M), L.i32(P), L.f32(0.5), L.ptr(out), L.stream()), "dpvo_loop_flow")
+    jj, kk = flatmeshgrid(torch.arange(j0, j0 + n_j, device=dev), torch.arange(i0 * M, (i0 + n_i) * M, device=dev), indexing="ij")
+    ii = ix.view(-1)[kk]
+    centre = patches[..., P // 2, P // 2].reshape(1, -1, 3, 1, 1)
+    flow_mg, nval = pops.flow_mag(poses[None], centre, intr[None], ii, jj, kk, beta=0.5)
+    val = (nval > 0.5).float()
+    s = (flow_mg * val).view(-1, M).sum(dim=1).float()
+    c = val.view(-1, M).sum(dim=1).clamp(min=1)
+    ref = torch.where(c > (M * 0.75), s / c, torch.full_like(c, float("inf")))
+    a, b = out.cpu().numpy(), ref.cpu().numpy()
+    assert np.array_equal(np.isinf(a), np.isinf(b)) and 0 < np.isinf(b).sum() < b.size
+    fin = ~np.isinf(b)
+    assert np.allclose(a[fin], b[fin], rtol=2e-6, atol=1e-6), np.abs(a[fin] - b[fin]).max()
+    # ... and into pinned host memory, as edges_loop uses it
+    host = torch.empty(n_j * n_i, dtype=torch.float32).pin_memory()
+    L.check(L.lib().dpvo_loop_flow(L.ptr(poses), L.ptr(patches), L.ptr(intr), L.ptr(ix), L.i64(j0), L.i64(n_j), L.i64(i0), L.i64(n_i),
+                                   L.i32(M), L.i32(P), L.f32(0.5), ctypes.c_void_p(host.data_ptr()), L.stream()), "dpvo_loop_flow")
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), a)
+
+
 def test_tracker_does_not_load_the_comparator_library(dev):
     """the product path is libdpvo_hip.so alone: a tracker run (initialisation, steady-state frames through the one-call frame
     path, terminate) never maps libdpvo_hip_cmp.so (the launch-by-launch / patch-major update operators are test partners)"""
