@@ -284,6 +284,42 @@ def loop_closure_leg(cfg, ht, wd, device, frames, intr, n_img, seed, warm=70, ti
         return {"frames_per_sec": None, "error": repr(e)[:300]}
 
 
+def host_image_leg(cfg, ht, wd, device, frames, intr, n_img, seed, warm=50, timed=40):
+    """The PCIe-inclusive rates (never `value`: the metric is quoted with the inputs resident in HBM).  The frames start in PAGEABLE host
+    memory as HWC uint8 arrays, the way a reader process delivers them, and reach the tracker in two ways:
+      reference_loop  -- demo.py:38-44 as written: `torch.from_numpy(image).permute(2, 0, 1).cuda()` on the caller's stream, then
+                         slam(t, image, intrinsics); the upload from pageable memory synchronises that stream, i.e. drains the pipeline
+      host_handoff    -- slam(t, torch.from_numpy(image).permute(2, 0, 1), intrinsics): the CPU tensor itself; the tracker uploads it
+                         through its pinned ring on the encoder stream (DPVO._upload_image)."""
+    from dpvo_amd.dpvo import DPVO
+    from dpvo_amd.net import VONet
+    try:
+        host = [f.permute(1, 2, 0).contiguous().cpu().numpy() for f in frames[:min(n_img, 64)]]
+        torch.manual_seed(seed)
+        slam = DPVO(cfg, VONet(), ht=ht, wd=wd, device=device)
+        slam.motion_probe = lambda: 1.0e9
+        out, t = {}, 0
+        with torch.no_grad():
+            for name, n_warm in (("reference_loop", warm), ("host_handoff", 15)):
+                def step(t):
+                    img = torch.from_numpy(host[t % len(host)]).permute(2, 0, 1)
+                    slam(float(t), img.cuda() if name == "reference_loop" else img, intr)
+                for _ in range(n_warm):
+                    step(t); t += 1
+                slam.flush(); torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(timed):
+                    step(t); t += 1
+                slam.flush(); torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                out[name] = {"frames": timed, "frames_per_sec": round(timed / dt, 1), "ms_per_frame": round(1e3 * dt / timed, 4)}
+        out["finite"] = bool(torch.isfinite(slam.pg.poses_[:slam.n]).all().item())
+        out["edges"] = int(slam.pg.ii.numel())
+        return out
+    except Exception as e:          # noqa: BLE001  (a side leg must never take the headline measurement down)
+        return {"error": repr(e)[:300]}
+
+
 def launcher_command(gpus, argv, port=None, environ=None):
     """(command, environment) with which `python bench.py --gpus N` re-executes itself: N ranks of ONE node under torch.distributed.run,
     rendezvous on 127.0.0.1 (the container's hostname may not resolve), dmabuf IPC for RCCL.  Every rank then places itself from
@@ -472,6 +508,10 @@ def main():
     if world == 1 and args.drop_every == 0 and args.config == "default" and not os.environ.get("DPVO_BENCH_NO_PROBE_LEG"):
         torch.manual_seed(1234 + seed_off)
         probe_leg = unforced_probe_leg(cfg, VONet(), ht, wd, device, frames, intr)
+    # fifth leg (N = 1, default run only): the frames handed over in host memory (tier rule 4: the PCIe-inclusive rate beside the metric)
+    host_leg = None
+    if world == 1 and args.drop_every == 0 and args.config == "default" and not os.environ.get("DPVO_BENCH_NO_HOST_LEG"):
+        host_leg = host_image_leg(cfg, ht, wd, device, frames, intr, n_img, seed=1234 + seed_off)
     res = multiseq.gather_results(args.steps, local, extra=[1e6 * (cpu1 - cpu0) / args.steps, dev_index,
                                                            pinned[0] if pinned else -1, pinned[-1] if pinned else -1], dist=dist,
                                   device=device if backend == "nccl" else "cpu")
@@ -542,7 +582,7 @@ def main():
                                                                 f" sharing {n_dev} device(s) over gloo (launch-path smoke mode)")},
             "frame_period_ms": period,
             "roofline": roof, "roofline_update": roof_u, "with_keyframe_drops": drop_leg, "with_loop_closure": lc_leg,
-            "unforced_probe": probe_leg,
+            "unforced_probe": probe_leg, "images_from_host_memory": host_leg,
             "per_rank": [{"rank": i, "frames": r[0], "seconds": round(r[1], 6), "frames_per_sec": round(r[0] / r[1], 1),
                           "host_cpu_us_per_frame": round(r[2], 1), "device": int(r[3]),
                           "pinned_to": (f"{int(r[4])}-{int(r[5])}" if r[4] >= 0 else None)}

@@ -65,6 +65,7 @@ class DPVO:
         self.overlap_encoders = bool(overlap_encoders)
         self._enc_stream = None
         self._fp_done = None
+        self._img_ring = None       # _upload_image: pinned / device slots for images handed over in host memory
         self._fs = None             # dpvo_frame_state_t, reused
         self._kf_pending = None
         self._fu = None             # buffers + dpvo_frame_update_t of the one-call frame path
@@ -940,6 +941,33 @@ class DPVO:
         return flatmeshgrid(torch.arange(t0, t1, device=self.device),
                             torch.arange(max(self.n - r, 0), self.n, device=self.device), indexing='ij')
 
+    def _upload_image(self, img):
+        """host uint8 [3,H,W] (any strides; the reader's HWC buffer seen through .permute(2,0,1) is the common case) -> device [3,H,W]
+        contiguous, enqueued on the CURRENT stream (the encoder stream when there is one).  Three pinned and three device slots: a device
+        slot is read by the frame that owns it (normalisation on this stream, patch colours on the main stream) and rewritten three
+        frames later, behind that frame's _fp_done; a pinned slot is rewritten once its own copy has completed."""
+        H, W = img.shape[-2:]
+        r = self._img_ring
+        if r is None or r["hw"] != (H, W):
+            r = self._img_ring = {"hw": (H, W), "i": 0,
+                                  "pin": [torch.empty(3 * H * W, dtype=torch.uint8).pin_memory() for _ in range(3)],
+                                  "raw": [torch.empty(3 * H * W, dtype=torch.uint8, device=self.device) for _ in range(3)],
+                                  "chw": [torch.empty(3, H, W, dtype=torch.uint8, device=self.device) for _ in range(3)],
+                                  "ev": [torch.cuda.Event() for _ in range(3)]}
+        k = r["i"]
+        r["i"] = (k + 1) % 3
+        if r["ev"][k].cuda_event:
+            r["ev"][k].synchronize()
+        hwc = img.stride() == (1, 3 * W, 3)                 # HWC memory behind a CHW view: copied as it lies, transposed on the device
+        src = img.permute(1, 2, 0) if hwc else img
+        r["pin"][k].view(src.shape).copy_(src)
+        r["raw"][k].copy_(r["pin"][k], non_blocking=True)
+        r["ev"][k].record()
+        if not hwc:
+            return r["raw"][k].view(3, H, W)
+        r["chw"][k].copy_(r["raw"][k].view(H, W, 3).permute(2, 0, 1))
+        return r["chw"][k]
+
     def __call__(self, tstamp, image, intrinsics, patch_coords=None, depth_init=None, image_ready=None):
         """slam(tstamp, image, intrinsics) -- dpvo/dpvo.py:377-473 (see _call)"""
         self._busy += 1
@@ -968,14 +996,22 @@ class DPVO:
         if torch.cuda.current_device() != self.device.index and self.device.index is not None:
             raise L.DPVOHipError(f"DPVO was built on {self.device} but the current device is cuda:{torch.cuda.current_device()}: "
                                  "wrap the call in torch.cuda.device(...)")
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(image)
         if image.dim() != 3 or image.shape[0] != 3:
             raise ValueError(f"image must be [3,H,W] (got {tuple(image.shape)})")
-        if image.dtype != torch.uint8 or image.device != self.device:
+        # A uint8 image still in HOST memory (what a reader process hands over) is uploaded by the tracker itself, on the encoder
+        # stream, through a pinned ring (_upload_image): the copy then overlaps the previous frame instead of draining the pipeline
+        # the way the reference's own loop does (demo.py:38 `.cuda()` from pageable memory synchronises the caller's stream)
+        host_img = image if (image.device.type == "cpu" and image.dtype == torch.uint8) else None
+        if host_img is None and (image.dtype != torch.uint8 or image.device != self.device):
             image = image.to(self.device).clamp(0, 255).to(torch.uint8)
         if isinstance(intrinsics, torch.Tensor) and (intrinsics.dtype != torch.float32 or intrinsics.device != self.device):
             intrinsics = intrinsics.to(self.device, torch.float32)
-        image_u8 = image.contiguous()
-        H, W = image_u8.shape[-2:]
+        image_u8 = image.contiguous() if host_img is None else None
+        H, W = image.shape[-2:]
+        if host_img is not None:
+            image_ready = False                 # (the upload is ordered on the stream that reads the image)
         hip_enc = self._hip_enc is not None and H % 16 == 0 and W % 16 == 0 and self.cfg.CENTROID_SEL_STRAT == 'RANDOM'
         side = pre_rng = fs_deferred = rng_done = None
         appended = False
@@ -1016,6 +1052,8 @@ class DPVO:
                 rng_done = self._rng_done_ev[self.counter & 1]
                 rng_done.record(side)
             self._stamp(1)
+            if host_img is not None:
+                image_u8 = self._upload_image(host_img)
             img32 = torch.empty(1, 1, 3, H, W, dtype=torch.float32, device=self.device) if not self._enc_half else None
             img16 = torch.empty(1, 1, 3, H, W, dtype=torch.float16, device=self.device) if self._enc_half else None
             L.check(L.lib().dpvo_normalize_image(L.ptr(image_u8), L.ptr(img32), L.ptr(img16), L.i64(image_u8.numel()),

@@ -15,7 +15,7 @@ from dpvo_amd.net import VONet
 pytestmark = pytest.mark.gpu
 
 
-def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, overlap=False, frame_call=True):
+def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, overlap=False, frame_call=True, host_images=None):
     """frame_call: steady-state frames through dpvo_frame_update + the device-side keyframe step (default), or the
     Python-paced round-2 path with its host mirror (dpvo_amd.dpvo._FRAME_CALL = False)"""
     from oracle.graph_ref import GraphRef
@@ -45,7 +45,13 @@ def _run(dev, decisions, M=16, seed=0, ht=96, wd=128, defer=False, check=True, o
     try:
         for t, (accept, drop) in enumerate(decisions):
             state["accept"], state["drop"] = accept, drop
-            img = torch.randint(0, 255, (3, ht, wd), generator=g, dtype=torch.uint8).to(dev)
+            img = torch.randint(0, 255, (3, ht, wd), generator=g, dtype=torch.uint8)
+            if host_images is None:
+                img = img.to(dev)
+            elif host_images == "hwc":            # the reader's HWC buffer seen as CHW (demo.py:38 without its .cuda())
+                img = img.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+            elif host_images == "numpy":
+                img = img.numpy()
             slam(float(t), img, intr)
             ev = ref.frame(accept, drop)
             if not check:
@@ -104,6 +110,27 @@ def test_deferred_keyframe_is_bit_identical(dev):
     assert torch.equal(a.pg.net, b.pg.net) and torch.equal(a._fmap1_cl, b._fmap1_cl) and torch.equal(a._gmap_cl, b._gmap_cl)
     pa, _ = a.terminate(); pb, _ = b.terminate()
     assert np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_images_handed_over_in_host_memory(dev, overlap):
+    """slam(t, image, intrinsics) with the image still in host memory -- a CHW tensor, the reader's HWC buffer behind a CHW view, a numpy
+    array -- is uploaded by the tracker through its pinned ring on the encoder stream (DPVO._upload_image): the same tracker state, bit
+    for bit, as with the image uploaded by the caller, with keyframes dropped along the way and the three ring slots reused many times."""
+    decisions = [(True, False)] * 12 + [(True, True)] * 2 + [(True, False)] * 14 + [(True, True), (True, False)] + [(True, False)] * 4
+    kw = dict(seed=11, defer=overlap, check=False, overlap=overlap)
+    a, _, _ = _run(dev, decisions, **kw)
+    a.flush(); torch.cuda.synchronize()
+    for mode in ("chw", "hwc", "numpy"):
+        b, _, _ = _run(dev, decisions, host_images=mode, **kw)
+        b.flush(); torch.cuda.synchronize()
+        assert b._img_ring is not None and a._img_ring is None
+        assert a.n == b.n and a.pg.edges.E == b.pg.edges.E
+        for k in ("ii", "jj", "kk", "net", "target", "weight"):
+            assert torch.equal(getattr(a.pg, k), getattr(b.pg, k)), (mode, k)
+        for k in ("poses_", "patches_", "colors_"):
+            assert torch.equal(getattr(a.pg, k)[:a.n], getattr(b.pg, k)[:b.n]), (mode, k)
+        assert torch.equal(a._fmap1_cl, b._fmap1_cl) and torch.equal(a.imap_, b.imap_), mode
 
 
 def test_device_keyframe_step_equals_the_host_path(dev):

@@ -9,7 +9,7 @@ python bench.py --steps 60 --warmup 45 --config fast --no-cpu-baseline --no-ref-
 for t in 1 13 29 1 13; do python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-ref-baseline --update-tiling $t 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('update tiling $t: frames/sec', d['value'], 'period', d['frame_period_ms']['median'], 'update ms', d['roofline_update']['avg_ms'], 'corr ms', d['roofline']['avg_launch_ms'], 'config 5 leg', d['with_loop_closure']['frames_per_sec'], 'drop leg', d['with_keyframe_drops']['frames_per_sec'])"; done > $out/bench_tilings.txt 2>&1; cat $out/bench_tilings.txt
-( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && DPVO_BENCH_NO_BOX=1 DPVO_BENCH_NO_DROP_LEG=1 DPVO_BENCH_NO_LC_LEG=1 DPVO_BENCH_NO_PROBE_LEG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 60 --warmup 45 --no-cpu-baseline --no-ref-baseline > $out/bench_under_rocprof.json 2> /tmp/ks.err )
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks && DPVO_BENCH_NO_BOX=1 DPVO_BENCH_NO_DROP_LEG=1 DPVO_BENCH_NO_LC_LEG=1 DPVO_BENCH_NO_PROBE_LEG=1 DPVO_BENCH_NO_HOST_LEG=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $root/bench.py --steps 60 --warmup 45 --no-cpu-baseline --no-ref-baseline > $out/bench_under_rocprof.json 2> /tmp/ks.err )
 f=$(find /tmp/ks -name "*kernel_stats.csv" | xargs ls -S | head -1); cp $f $out/kernel_stats.csv; python tools/kstats.py $f 45 > $out/kernel_stats_short.txt
 t=$(find /tmp/ks -name "*kernel_trace.csv" | xargs ls -S | head -1); python tools/frame_timeline.py $t 3 > $out/frame_timeline.txt
 python tools/kernel_tail_avg.py $t corr_pyramid 20 > $out/corr_steady_state.txt
