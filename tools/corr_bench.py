@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """corr_pyramid_kernel alone on the BASELINE config-2 tensors (E = 47 712 as inside update(), all edges in bounds pattern of
-dpvo_amd.synthetic): HIP-event time per launch and a checksum (variants must agree bit for bit).  Dev tool: DPVO_CORR_STAGED /
-DPVO_CORR_OCC select the variant (read once per process)."""
+dpvo_amd.synthetic): HIP-event time per launch and a checksum (variants must agree bit for bit).  Dev tool: CORR_VARIANT=k times
+the measurement kernel of tools/probes/corr_variant.hip instead (tools/corr_variants.sh builds the library that carries it)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,6 +36,6 @@ s.record()
 for _ in range(reps):
     run()
 e.record(); torch.cuda.synchronize()
-print(f"E={E} variant={variant} staged={os.environ.get('DPVO_CORR_STAGED', '0')} occ={os.environ.get('DPVO_CORR_OCC', '3')}: "
+print(f"E={E} variant={variant if variant is not None else 'product'}: "
       f"{s.elapsed_time(e) / reps * 1e3:.1f} us per launch; checksum {out[:, :882].float().abs().sum().item():.6f} "
       f"{out[:, :882].view(torch.int16).to(torch.int64).sum().item()}")

@@ -15,7 +15,7 @@ from dpvo_amd.net import VONet
 dev = torch.device("cuda:0")
 cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML); cfg.KEYFRAME_THRESH = -1.0
 torch.manual_seed(1234)
-slam = DPVO(cfg, VONet(), ht=480, wd=640, device=dev, defer_keyframe=True, overlap_encoders=bool(int(os.environ.get("DPVO_OVERLAP_ENC", "1"))))
+slam = DPVO(cfg, VONet(), ht=480, wd=640, device=dev, defer_keyframe=True, overlap_encoders=bool(int(os.environ.get("OVERLAP_ENC", "1"))))       # (this tool's own switch)
 slam.motion_probe = lambda: 1.0e9
 frames = bench.make_stream(64, 480, 640, dev)
 intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=dev)

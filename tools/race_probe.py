@@ -31,8 +31,8 @@ cfg = base_cfg.clone(); cfg.merge_from_dict(DEFAULT_YAML)
 cfg.KEYFRAME_THRESH = -1.0
 cfg.BUFFER_SIZE = max(cfg.BUFFER_SIZE, nfr + 16)
 torch.manual_seed(1234)
-slam = DPVO(cfg, VONet(), ht=480, wd=640, device=dev, defer_keyframe=bool(int(os.environ.get("DPVO_DEFER_KEYFRAME", "1"))),
-            overlap_encoders=int(os.environ.get("DPVO_OVERLAP_ENC", "1")))
+slam = DPVO(cfg, VONet(), ht=480, wd=640, device=dev, defer_keyframe=bool(int(os.environ.get("DEFER_KEYFRAME", "1"))),      # (this tool's own switches)
+            overlap_encoders=int(os.environ.get("OVERLAP_ENC", "1")))
 slam.motion_probe = lambda: 1.0e9
 frames = bench.make_stream(64, 480, 640, dev)
 intr = torch.tensor([320.0, 320.0, 320.0, 240.0], device=dev)
