@@ -533,6 +533,16 @@ def test_loop_flow_kernel_matches_the_reference_composition(dev):
                                    L.i32(M), L.i32(P), L.f32(0.5), ctypes.c_void_p(host.data_ptr()), L.stream()), "dpvo_loop_flow")
     torch.cuda.synchronize()
     assert np.array_equal(host.numpy(), a)
+    # edge cases of the entry: an empty candidate range is a no-op, nonsense is refused (never a launch with a zero / negative grid)
+    args = lambda n_j_, n_i_, j0_=j0: (L.ptr(poses), L.ptr(patches), L.ptr(intr), L.ptr(ix), L.i64(j0_), L.i64(n_j_), L.i64(i0), L.i64(n_i_),
+                                       L.i32(M), L.i32(P), L.f32(0.5), L.ptr(out), L.stream())
+    before = out.clone()
+    assert L.lib().dpvo_loop_flow(*args(0, n_i)) == 0 and L.lib().dpvo_loop_flow(*args(n_j, 0)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, before)
+    assert L.lib().dpvo_loop_flow(*args(-1, n_i)) != 0 and L.lib().dpvo_loop_flow(*args(n_j, n_i, -3)) != 0
+    assert L.lib().dpvo_loop_flow(L.ptr(None), L.ptr(patches), L.ptr(intr), L.ptr(ix), L.i64(j0), L.i64(n_j), L.i64(i0), L.i64(n_i),
+                                  L.i32(M), L.i32(P), L.f32(0.5), L.ptr(out), L.stream()) != 0
 
 
 def test_tracker_does_not_load_the_comparator_library(dev):
