@@ -527,6 +527,17 @@ def test_loop_flow_kernel_matches_the_reference_composition(dev):
     assert np.array_equal(np.isinf(a), np.isinf(b)) and 0 < np.isinf(b).sum() < b.size
     fin = ~np.isinf(b)
     assert np.allclose(a[fin], b[fin], rtol=2e-6, atol=1e-6), np.abs(a[fin] - b[fin]).max()
+    # ... and against the ORACLE (oracle/: the f64 C restatement of pops.flow_mag, then patchgraph.py:64-72 in numpy): the +inf pattern may
+    # differ only where a point sits on the validity threshold in f32 vs f64 (none here), the values agree to f32 rounding
+    import oracle
+    of, ov = oracle.flow_mag(poses.cpu().numpy(), centre.cpu().numpy().reshape(-1, 3, 1, 1), intr.cpu().numpy(),
+                             ii.cpu().numpy(), jj.cpu().numpy(), kk.cpu().numpy(), beta=0.5)
+    of, ov = of.reshape(-1, M), ov.reshape(-1, M).astype(np.float64)
+    oc = ov.sum(1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        oref = np.where(oc > 0.75 * M, (of * ov).sum(1) / np.maximum(oc, 1.0), np.inf)
+    assert np.array_equal(np.isinf(a), np.isinf(oref))
+    assert np.allclose(a[fin], oref[fin], rtol=2e-4, atol=1e-4), np.abs(a[fin] - oref[fin]).max()
     # ... and into pinned host memory, as edges_loop uses it
     host = torch.empty(n_j * n_i, dtype=torch.float32).pin_memory()
     L.check(L.lib().dpvo_loop_flow(L.ptr(poses), L.ptr(patches), L.ptr(intr), L.ptr(ix), L.i64(j0), L.i64(n_j), L.i64(i0), L.i64(n_i),
