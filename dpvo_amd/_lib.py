@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPVO_HIP_LIB") or os.path.join(_HERE, "libdpvo_hip.so")      # (override: development builds)
 
 F16, F32 = 0, 1
-ABI_VERSION = 7         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
+ABI_VERSION = 8         # == DPVO_ABI_VERSION of include/dpvo_hip.h this binding (struct layouts, signatures) was written against
 
 # every symbol include/dpvo_hip.h declares (tests/test_capi.py checks the .so exports all of them)
 SYMBOLS = [
@@ -91,7 +91,8 @@ class FrameUpdate(ctypes.Structure):
                 [("result_dev", ctypes.c_void_p), ("ev", ctypes.c_void_p * 4), ("m", ctypes.c_int64), ("n_buffer", ctypes.c_int64)] +
                 [(k, ctypes.c_int32) for k in ("P", "pmem", "mem", "H0", "W0", "H1", "W1", "patch_lifetime", "ba_window",
                                                "iterations")] +
-                [("lmbda", ctypes.c_float), ("mm_beta", ctypes.c_float)])
+                [("lmbda", ctypes.c_float), ("mm_beta", ctypes.c_float), ("loop_out", ctypes.c_void_p), ("ev_loop", ctypes.c_void_p),
+                 ("loop_freq", ctypes.c_int32), ("loop_max_age", ctypes.c_int32)])
 
 
 class PlanLayout(ctypes.Structure):

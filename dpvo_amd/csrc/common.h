@@ -72,5 +72,8 @@ extern "C" int dpvo_plan_build_window_job(const int64_t* ii, const int64_t* jj, 
                                           size_t ws_bytes, int64_t frame_lo, int64_t n_frames_win, int64_t patch_lo,
                                           int64_t n_patches_win, int64_t qi, int64_t qj, int counters_cleared, const float* r_poses,
                                           const float* r_patches, const float* r_intr, float* r_coords, int r_P, void* stream);
+extern "C" int dpvo_loop_flow_next(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                                   const int32_t* decision, int n, int removal_window, int keyframe_index, int freq, int max_age, int M,
+                                   int P, float beta, float* out, void* stream);
 extern "C" int dpvo_frame_state_part_clear(dpvo_frame_state_t* p, int part, int32_t* clear_ptr, int64_t clear_count, void* stream);
 

@@ -134,19 +134,39 @@ __global__ void flow_mag_kernel(const float* __restrict__ poses, const float* __
 // i = ix[k]; flow and validity exactly as flow_mag_kernel computes them for a 1 x 1 patch (same flow_pixel).  Then the reference's
 // reduction: val = nvalid > 0.5; sum (flow * val) and sum val over the M patches; flow_mag = sum / max(count, 1) if count > 0.75 M,
 // else +inf.  Fixed reduction tree (wave butterflies, then the waves in order): bit-repeatable.  The result may be pinned host memory.
-__global__ __launch_bounds__(256) void loop_flow_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
-                                                        const float* __restrict__ intr, const int64_t* __restrict__ ix, int64_t j0,
-                                                        int64_t i0, int64_t n_i, int M, int P, float beta, float* __restrict__ out) {
+// ONE kernel for both callers, so that both compute the same bits: dpvo_loop_flow passes the candidate ranges; dpvo_frame_update's tail
+// (decision != NULL) derives them on the device from the frame count the keyframe step leaves behind, n_eval = n - decision + 1, and
+// puts {n_eval, number of pairs} in front of the magnitudes (the launch is sized for decision == 0; surplus workgroups leave).
+struct LoopFlowArgs {
+  const float *poses, *patches, *intr; const int64_t* ix;
+  int64_t j0, i0, n_i; int M, P; float beta; float* out;
+  const int32_t* decision; int n, removal_window, keyframe_index, freq, max_age;
+};
+__global__ __launch_bounds__(256) void loop_flow_kernel(const LoopFlowArgs A) {
   __shared__ float red[2][4];
-  const int64_t b = blockIdx.x, j = j0 + b / n_i, f = i0 + b % n_i;
-  const int PP = P * P, c = (P / 2) * P + P / 2;
+  int64_t j0 = A.j0, i0 = A.i0, n_i = A.n_i;
+  float* out = A.out;
+  const int64_t b = blockIdx.x;
+  if (A.decision) {
+    const int64_t n_eval = (int64_t)A.n - (*A.decision != 0 ? 1 : 0) + 1, l = n_eval - A.removal_window;
+    const int64_t n_j = A.freq - A.keyframe_index;
+    j0 = n_eval - A.freq;
+    i0 = l - A.max_age > 0 ? l - A.max_age : 0;
+    n_i = l - i0;
+    const int64_t pairs = (l > 0 && n_j > 0 && j0 >= 0) ? n_j * n_i : 0;
+    if (b == 0 && threadIdx.x == 0) { out[0] = (float)n_eval; out[1] = (float)pairs; }
+    if (b >= pairs) return;
+    out += 2;
+  }
+  const int64_t j = j0 + b / n_i, f = i0 + b % n_i;
+  const int M = A.M, PP = A.P * A.P, c = (A.P / 2) * A.P + A.P / 2;
   float s = 0.f, cnt = 0.f;
   for (int p = threadIdx.x; p < M; p += 256) {            // (M <= 256 in every configuration: one pass)
     const int64_t k = f * M + p;
-    const FlowPair F = flow_pair(poses, intr, ix[k], j);
-    const float* pk = patches + k * 3 * PP + c;
+    const FlowPair F = flow_pair(A.poses, A.intr, A.ix[k], j);
+    const float* pk = A.patches + k * 3 * PP + c;
     float fl = 0.f, v = 0.f;
-    flow_pixel(F, pk[0], pk[PP], pk[2 * PP], beta, fl, v);
+    flow_pixel(F, pk[0], pk[PP], pk[2 * PP], A.beta, fl, v);
     const float val = v > 0.5f ? 1.f : 0.f;
     s += fl * val;                                          // (a product, as in the reference: inf * 0 = NaN stays NaN)
     cnt += val;
@@ -323,8 +343,22 @@ extern "C" int dpvo_loop_flow(const float* poses, const float* patches, const fl
   if (n_j < 0 || n_i < 0 || M <= 0 || P <= 0 || j0 < 0 || i0 < 0) return DPVO_E_INVALID;
   if (n_j == 0 || n_i == 0) return DPVO_OK;
   if (!poses || !patches || !intrinsics || !ix || !flow_mag || n_j * n_i > 0x7fffffffll) return DPVO_E_INVALID;
-  hipLaunchKernelGGL(loop_flow_kernel, dim3((unsigned)(n_j * n_i)), dim3(256), 0, (hipStream_t)stream, poses, patches, intrinsics, ix, j0,
-                     i0, n_i, M, P, beta, flow_mag);
+  const LoopFlowArgs A = {poses, patches, intrinsics, ix, j0, i0, n_i, M, P, beta, flow_mag, nullptr, 0, 0, 0, 0, 0};
+  hipLaunchKernelGGL(loop_flow_kernel, dim3((unsigned)(n_j * n_i)), dim3(256), 0, (hipStream_t)stream, A);
+  DPVO_LAUNCH_CHECK();
+  return DPVO_OK;
+}
+// (internal, common.h) the same test for the frame count the keyframe step of THIS call leaves behind: dpvo_frame_update_t.loop_out
+extern "C" int dpvo_loop_flow_next(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                                   const int32_t* decision, int n, int removal_window, int keyframe_index, int freq, int max_age, int M,
+                                   int P, float beta, float* out, void* stream) {
+  if (!poses || !patches || !intrinsics || !ix || !decision || !out || M <= 0 || P <= 0 || n < 1 || max_age < 0) return DPVO_E_INVALID;
+  const int64_t l = (int64_t)n + 1 - removal_window, n_j = freq - keyframe_index;         // (the larger of the two possible ranges: no drop)
+  const int64_t n_i = l > 0 ? l - (l - max_age > 0 ? l - max_age : 0) : 0;
+  const int64_t grid = (n_j > 0 && n_i > 0) ? n_j * n_i : 1;                               // (one workgroup writes the header even when empty)
+  if (grid > 0x7fffffffll) return DPVO_E_INVALID;
+  const LoopFlowArgs A = {poses, patches, intrinsics, ix, 0, 0, 1, M, P, beta, out, decision, n, removal_window, keyframe_index, freq, max_age};
+  hipLaunchKernelGGL(loop_flow_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, A);
   DPVO_LAUNCH_CHECK();
   return DPVO_OK;
 }

@@ -485,6 +485,13 @@ extern "C" int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream) {
   if (a->ev_record && hipEventRecord((hipEvent_t)a->ev_record, st) != hipSuccess) return DPVO_E_INVALID;
   STEP(dpvo_point_cloud(a->poses, a->patches, a->intrinsics, a->ix, a->points, a->m, a->P, stream));
   kf_apply_launch(&kf, st);
+  // ---- LOOP_CLOSURE: the candidate test PatchGraph.edges_loop will ask for at the start of the next frame (patchgraph.py:56-72), on the
+  //      state this call leaves behind (poses after the BA, rings after the shifts), for the frame count the decision leaves behind
+  if (a->loop_out) {
+    STEP(dpvo_loop_flow_next(a->poses, a->patches, a->intrinsics, a->ix, kf.result + RES_DECISION, n, K.removal_window, K.keyframe_index,
+                             a->loop_freq, a->loop_max_age, M, a->P, 0.5f, a->loop_out, stream));
+    if (a->ev_loop && hipEventRecord((hipEvent_t)a->ev_loop, st) != hipSuccess) return DPVO_E_INVALID;
+  }
   HT(11);    // keyframe step + record + point cloud
   DPVO_LAUNCH_CHECK();
 #undef STEP

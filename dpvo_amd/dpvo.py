@@ -66,6 +66,7 @@ class DPVO:
         self._enc_stream = None
         self._fp_done = None
         self._img_ring = None       # _upload_image: pinned / device slots for images handed over in host memory
+        self._loop_pre = None       # (pinned buffer, event) of the loop-closure candidate test the last frame call ran in its tail
         self._fs = None             # dpvo_frame_state_t, reused
         self._kf_pending = None
         self._fu = None             # buffers + dpvo_frame_update_t of the one-call frame path
@@ -690,6 +691,23 @@ class DPVO:
             a.plan_stream, a.ev_plan_fork, a.ev_plan_done = ps.cuda_stream, evs[0].cuda_event, evs[1].cuda_event
         else:
             a.plan_stream = a.ev_plan_fork = a.ev_plan_done = None
+        # LOOP_CLOSURE: if the NEXT frame will ask PatchGraph.edges_loop for candidates ((n' + 1) - last_global_ba >= GLOBAL_OPT_FREQ with
+        # n' = n or n - 1, whichever this call's keyframe step decides: the test below is the superset), their flow test runs in the tail
+        # of this call, on the device, for the frame count the decision leaves behind (dpvo_frame_update_t.loop_out) -- the next frame
+        # finds the magnitudes in pinned memory instead of paying a launch and a round trip in front of its own frame call
+        a.loop_out = a.ev_loop = None
+        self._loop_pre = None
+        if cfg.LOOP_CLOSURE and (n + 1) - self.last_global_ba >= cfg.GLOBAL_OPT_FREQ:
+            lp = fu.get("loop")
+            if lp is None:
+                cap = 2 + max(cfg.GLOBAL_OPT_FREQ - cfg.KEYFRAME_INDEX, 0) * min(cfg.MAX_EDGE_AGE, self.N)
+                lp = fu["loop"] = [(torch.zeros(cap, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+                for _, e_ in lp:
+                    e_.record()         # (creates the handles)
+            host_l, ev_l = lp[par]
+            a.loop_out, a.ev_loop = host_l.data_ptr(), ev_l.cuda_event
+            a.loop_freq, a.loop_max_age = cfg.GLOBAL_OPT_FREQ, cfg.MAX_EDGE_AGE
+            self._loop_pre = (host_l, ev_l)
         self._stamp(3)
         if _HOST_TRACE is not None: _HOST_TRACE.append(("call", __import__("time").perf_counter()))
         # the event the host waits for is recorded INSIDE the call, as soon as the keyframe step's result record is final -- the
@@ -989,6 +1007,7 @@ class DPVO:
 
         if (self.n + 1) >= self.N:
             raise Exception(f'The buffer size is too small. You can increase it using "--opts BUFFER_SIZE={self.N*2}"')
+        loop_pre, self._loop_pre = self._loop_pre, None         # (the previous frame call's tail: valid for THIS call's evaluation or for none)
 
         # image = 2 * (image[None,None] / 255.0) - 0.5, plus the f16 copy the encoders eat: one kernel.  The kernel reads raw
         # uint8 [3,H,W] on this device; anything else the reference's arithmetic would accept (CPU tensor, float image) is
@@ -1128,7 +1147,7 @@ class DPVO:
             # takes the call-by-call path (they go in front of the frame's own edges, and update() then runs the global BA)
             self._loop_try = None
             if self.cfg.LOOP_CLOSURE and self.is_initialized and (n + 1) - self.last_global_ba >= self.cfg.GLOBAL_OPT_FREQ:
-                self._loop_try = self.pg.edges_loop(n=n + 1)
+                self._loop_try = self.pg.edges_loop(n=n + 1, pre=loop_pre)
             loop_found = self._loop_try is not None and self._loop_try[0].numel() > 0
             # (also while long-range edges are active: the frame then takes the call-by-call path -- _frame_call_ok() is false -- but its
             #  state stores and its own edges are still the one dpvo_frame_state call; only a frame that appends loop edges, which go in

@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version: bumped on ANY change of a signature, a struct layout or the exported set (round 3 changed all three without a
  * bump: ADVICE r3).  The Python binding refuses a library whose version differs from the one it was written against. */
-#define DPVO_ABI_VERSION 7
+#define DPVO_ABI_VERSION 8
 int dpvo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -479,6 +479,15 @@ typedef struct {
   int64_t m, n_buffer;              /* patches so far; BUFFER_SIZE */
   int32_t P, pmem, mem, H0, W0, H1, W1, patch_lifetime, ba_window, iterations;
   float lmbda, mm_beta;
+  float* loop_out; void* ev_loop;   /* loop_out != NULL (LOOP_CLOSURE): behind the keyframe step's gathers the call runs dpvo_loop_flow for the
+                                       frame count the NEXT frame will ask PatchGraph.edges_loop for -- n_eval = (kf.n - decision) + 1, the
+                                       decision read from the result record on the device: targets [n_eval - loop_freq, n_eval - keyframe_index),
+                                       sources [max(l - loop_max_age, 0), l), l = n_eval - removal_window -- into loop_out (device or pinned host
+                                       memory): [0] = n_eval, [1] = number of pairs as floats, the flow magnitudes from [2] on (target-major;
+                                       capacity: 2 + (loop_freq - keyframe_index) * min(loop_max_age, kf.n + 1 - removal_window) floats).
+                                       ev_loop (hipEvent_t or NULL) is recorded behind it.  The next frame's candidate test then costs
+                                       no launch and no extra round trip */
+  int32_t loop_freq, loop_max_age;  /* GLOBAL_OPT_FREQ, MAX_EDGE_AGE */
 } dpvo_frame_update_t;
 int dpvo_frame_update(const dpvo_frame_update_t* a, void* stream);
 

@@ -326,6 +326,10 @@ def test_loop_closure_on_the_one_call_path(dev):
     gb = int(a.ran_global_ba.sum())
     print(f"loop closure: {fast} of 60 frames on the one-call path, {gb} global BA runs, {a.pg.ii_inac.numel()} inactive edges")
     assert none == 0 and fast >= 15, "both paths must have been exercised"
+    # the one-call path runs edges_loop's candidate test in the TAIL of the previous frame's call (dpvo_frame_update_t.loop_out): same
+    # kernel, same state, same ranges -- the states below are bit-identical to the run that launches it in front of every frame
+    print(f"   candidate tests served by the previous call's tail: {a.pg.loop_pre_hits} (call-by-call run: {b.pg.loop_pre_hits})")
+    assert a.pg.loop_pre_hits >= 5 and b.pg.loop_pre_hits == 0
     assert gb >= 2 and gb == int(b.ran_global_ba.sum()) and np.array_equal(a.ran_global_ba, b.ran_global_ba)
     assert a.n == b.n and a.m == b.m and a.last_global_ba == b.last_global_ba
     for k in ("ii", "jj", "kk", "ii_inac", "jj_inac", "kk_inac", "net", "target", "weight", "target_inac", "weight_inac"):
